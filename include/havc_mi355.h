@@ -1,0 +1,178 @@
+/*
+ * havc_mi355.h — C ABI of libhavc_mi355.so: MI355X (gfx950) per-frame colorization inference for
+ * the HAVC / vs-deoldify filter API.
+ *
+ * This is the drop-in boundary of the hot path.  The reference has no
+ * FFI today: its boundary is three Python call shapes invoked once per frame from VapourSynth
+ * ModifyFrame selectors.  Each entry point below cites the reference interface it replaces
+ * (paths relative to the reference tree, vsdeoldify/...).  Plain pointers and sizes only; no
+ * torch / numpy / PIL types.  All functions return 0 (HAVC_OK) or a negative HAVC_E_* code;
+ * havc_last_error() returns a human-readable message for the calling thread's context.
+ *
+ * Threading: a havc_ctx owns one GPU, one HIP stream and one workspace arena.  Calls on the same
+ * ctx are serialised by an internal mutex (ctypes releases the GIL, VapourSynth has several worker
+ * threads); create one ctx per GPU (and per worker if concurrency on one GPU is wanted).
+ * Buffers passed in are never retained after return.
+ */
+#ifndef HAVC_MI355_H
+#define HAVC_MI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAVC_OK 0
+#define HAVC_E_INVALID (-1)   /* bad argument / malformed plan            -> Python raises ValueError          */
+#define HAVC_E_OOM (-2)       /* device allocation failed                 -> Python shim returns input + warns  */
+                              /*   (deoldify/filters.py:55-63 semantics)                                       */
+#define HAVC_E_HIP (-3)       /* any other HIP runtime failure            -> Python raises RuntimeError        */
+#define HAVC_E_NODEVICE (-4)  /* no gfx950 device visible                 -> Python raises RuntimeError        */
+
+typedef struct havc_ctx havc_ctx;
+typedef struct havc_weights havc_weights;
+typedef struct havc_net havc_net;
+
+/* ------------------------------------------------------------------------------------------------
+ * Execution plan.  A network is a flat list of ops over numbered activation buffers (NHWC fp16,
+ * channel count padded to a multiple of 8, pad channels always zero).  The plan is emitted by the
+ * host-side model builder (vsdeoldify_amd/deoldify_plan.py) from the reference topology
+ * (deoldify/unet.py:94-285, Appendix B of SURVEY.md) for one input size S; weights are packed once
+ * per model (vsdeoldify_amd/packing.py) with spectral/weight norm and conv->BN folded.
+ * ---------------------------------------------------------------------------------------------- */
+enum havc_op_type {
+    HAVC_OP_CONV = 1,        /* implicit-GEMM convolution on MFMA with fused epilogue                     */
+    HAVC_OP_MAXPOOL = 2,     /* 3x3 stride 2 pad 1 max pool (resnet stem)                                 */
+    HAVC_OP_BLUR_RESIZE = 3, /* replicate-pad(1,0,1,0) + avgpool2x2 s1 (+ nearest resize) into dst@coff  */
+    HAVC_OP_AFFINE = 4,      /* y = act(x*scale+shift) per channel, into dst@coff (skip BN+ReLU, layers.1) */
+    HAVC_OP_ATTENTION = 5,   /* fastai SelfAttention, flash form: out = gamma * softmax_i(f_i.g_j) h + x   */
+    HAVC_OP_PREP_RGB8 = 6,   /* u8 RGB -> PIL 'L' gray x3 -> /255 -> imagenet normalise -> fp16 C8         */
+    HAVC_OP_COPY_CH = 7,     /* copy channel slice src@coff -> dst@coff (dense MergeLayer, layers.9)       */
+};
+
+/* conv epilogue flags: v = acc + bias; RELU_PRE; v = v*scale+shift; v += residual; RELU_POST */
+#define HAVC_F_RELU_PRE 0x1
+#define HAVC_F_AFFINE 0x2
+#define HAVC_F_RESIDUAL 0x4
+#define HAVC_F_RELU_POST 0x8
+#define HAVC_F_OUT_PIXSHUF 0x10   /* weight rows ordered (dy,dx,c): store to (2h+dy, 2w+dx, c)             */
+#define HAVC_F_OUT_TRANSPOSED 0x20 /* store as [b][n][pix_pitch] (V^T for attention)                       */
+#define HAVC_F_OUT_RGB8 0x40      /* SigmoidRange(f0,f1) -> *std+mean -> clamp01 -> trunc(*255) -> u8 RGB   */
+#define HAVC_F_LEAKY 0x80         /* RELU_* use LeakyReLU(f2)                                              */
+
+typedef struct havc_op {
+    int32_t type, flags;
+    int32_t src, src2, dst;              /* buffer ids; src2 = residual (conv) / qk buffer (attention)      */
+    int32_t src_coff, src_cpitch;        /* channel offset / pitch (elements, multiples of 8)               */
+    int32_t dst_coff, dst_cpitch;
+    int32_t res_coff, res_cpitch;
+    int32_t Hi, Wi, Ci;                  /* input spatial size, input channels used (multiple of 8)         */
+    int32_t Ho, Wo, Co;                  /* output spatial size, output channels stored (multiple of 8)     */
+    int32_t kh, kw, stride, pad, dil;
+    int32_t Kc, Npad;                    /* packed weight matrix: Npad rows x Kc 16-byte chunks             */
+    int32_t aux0, aux1;                  /* conv TRANSPOSED: aux0 = pixel pitch.  ATTENTION: x = src, out = dst,
+                                            qk = src2 (pitch res_cpitch, f at res_coff, g at res_coff + d),
+                                            aux0 = d, aux1 = V^T buffer id, Kc = V^T pixel pitch, Ci = dv,
+                                            f0 = gamma.  PREP_RGB8: second destination = src2@res_coff      */
+    int64_t w_off, bias_off, scale_off, shift_off; /* byte offsets into the weight blob, -1 = none          */
+    float f0, f1, f2, f3;
+    int64_t flops;                       /* algorithmic FLOPs per frame of this op (2*MAC), for stats       */
+    int32_t tag;                         /* builder's label (index into its name table), for profiling      */
+    int32_t reserved;
+} havc_op;
+
+typedef struct havc_buf {
+    int64_t elems_per_frame;             /* elements (fp16 unless u8 flag) per frame                        */
+    int32_t elem_bytes;                  /* 2 = fp16, 1 = u8                                                */
+    int32_t zero_init;                   /* 1: memset once at allocation (pad channels nobody writes)       */
+} havc_buf;
+
+typedef struct havc_stats {
+    double last_ms;          /* GPU time of the last havc_net_run / havc_*_frames call (HIP events)         */
+    double total_ms;         /* accumulated GPU time since create / reset                                   */
+    double total_flops;      /* accumulated algorithmic FLOPs                                               */
+    int64_t frames;          /* frames processed                                                            */
+    int64_t launches;        /* kernel launches issued                                                      */
+    int64_t bytes_resident;  /* device bytes held (weights + activations + staging)                         */
+} havc_stats;
+
+/* ---- context (replaces: device.set(DeviceId(device_index)), deoldify/_device.py:21-30;
+ *      vsdeoldify/__init__.py:2487).  device_id = HIP ordinal as seen by this process. ---- */
+int havc_create(havc_ctx** out, int device_id);
+void havc_destroy(havc_ctx* ctx);
+const char* havc_last_error(const havc_ctx* ctx);      /* ctx may be NULL: last creation error            */
+int havc_device_count(void);
+int havc_synchronize(havc_ctx* ctx);
+int havc_get_stats(havc_ctx* ctx, havc_stats* out);
+int havc_reset_stats(havc_ctx* ctx);
+const char* havc_version(void);
+
+/* ---- weights (replaces: Learner.load -> torch.load(models/<name>.pth) + load_state_dict,
+ *      fastai/basic_train.py:264-286; the blob is produced by vsdeoldify_amd/packing.py) ---- */
+int havc_weights_load(havc_ctx* ctx, const void* blob, size_t nbytes, havc_weights** out);
+void havc_weights_free(havc_weights* w);
+
+/* ---- network = weights + plan for one input size (replaces: the nn.Module graph built by
+ *      gen_inference_wide/deep, deoldify/generators.py:12-21,85-95).  max_batch frames of
+ *      activations are allocated up front from the ctx arena (288 GB HBM: no per-frame
+ *      allocation, no empty_cache() churn — deoldify/visualize.py:30-36). ---- */
+int havc_net_create(havc_ctx* ctx, havc_weights* w, const havc_op* ops, int n_ops, const havc_buf* bufs,
+                    int n_bufs, int in_buf, int out_buf, int S, int max_batch, havc_net** out);
+void havc_net_free(havc_net* net);
+/* run `batch` frames: d_in  = device u8 RGB interleaved [batch][S][S][3];
+ *                     d_out = device u8 RGB interleaved [batch][S][S][3] (raw colour, trunc(x*255),
+ *                     i.e. BaseFilter._model_process output, deoldify/filters.py:45-68). */
+int havc_net_run_rgb8(havc_net* net, const uint8_t* d_in, uint8_t* d_out, int batch);
+/* debug / unit-test access to activation buffers (host <-> device, blocking) */
+int havc_net_upload(havc_net* net, int buf, const void* host, size_t nbytes);
+int havc_net_download(havc_net* net, int buf, void* host, size_t nbytes);
+int havc_net_run_ops(havc_net* net, int first_op, int n_ops, int batch);  /* run a slice of the plan */
+/* per-op GPU time of one run (ms, n_ops entries), measured with HIP events around every op */
+int havc_net_profile(havc_net* net, int batch, float* ms_per_op, int n_ops);
+
+/* ---- frame-in / frame-out entry points (host buffers, blocking) ---------------------------------
+ * havc_deoldify_frames replaces ModelImageRender.get_transformed_image (deoldify/visualize.py:118-137)
+ * for frames already at the render size S x S (the HAVC_colorizer flow, vsdeoldify/__init__.py:2502-2506):
+ *   video pass ALWAYS; if `second` != NULL also the stable/artistic pass and
+ *   Image.blend(second, video, video_weight) (visualize.py:129,135); post_process = ColorizerFilter.
+ *   _post_process (deoldify/filters.py:100-110: cv2 YUV, keep Y of the source, UV of the colour).
+ * rgb_in/rgb_out: host u8 interleaved RGB, n frames of S*S*3 bytes, tightly packed. */
+int havc_deoldify_frames(havc_ctx* ctx, havc_net* video, havc_net* second, float video_weight, int post_process,
+                         const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames);
+
+/* ---- per-pixel filters on host buffers (vsslib/imfilters.py); u8 interleaved RGB, w*h pixels ---- */
+/* Image.blend(a, b, w): trunc(a + w*(b-a)) in fp32 — image_weighted_merge, imfilters.py:113-124 */
+int havc_blend(havc_ctx* ctx, const uint8_t* a, const uint8_t* b, float w, uint8_t* out, int width, int height);
+/* chroma_post_process(img_m, orig): Y of orig + UV of img_m — imfilters.py:312-321 (cv2 BT.601 fixed point) */
+int havc_chroma_post_process(havc_ctx* ctx, const uint8_t* color, const uint8_t* orig, uint8_t* out, int width,
+                             int height);
+/* chroma_stabilizer(img_stable, img_new, alpha, weight) — imfilters.py:160-200 */
+int havc_chroma_stabilizer(havc_ctx* ctx, const uint8_t* img_stable, const uint8_t* img_new, double alpha,
+                           double weight, uint8_t* out, int width, int height);
+
+/* ---- device-resident clip pipeline (bench + multi-GPU shard path) -----------------
+ * One call colours n_frames 1080p-class frames that are ALREADY in HBM:
+ *   d_src [n][h][w][3] u8 gray-as-RGB  -> Spline64 squash to S x S (harness stand-in for zimg,
+ *   vsdeoldify/__init__.py:2504) -> havc_deoldify (video [+second], blend, YUV merge) -> Spline64 back to
+ *   w x h (__init__.py:3547) -> chroma_post_process with the source luma (vsfilters.py:863-899) -> d_dst.
+ * Frames are processed in batches of the nets' max_batch. */
+int havc_colorize_clip(havc_ctx* ctx, havc_net* video, havc_net* second, float video_weight, const uint8_t* d_src,
+                       uint8_t* d_dst, int n_frames, int width, int height);
+/* device memory helpers for callers that keep clips resident (bench.py, sharded runner) */
+int havc_dev_alloc(havc_ctx* ctx, size_t nbytes, void** out);
+int havc_dev_free(havc_ctx* ctx, void* p);
+int havc_dev_upload(havc_ctx* ctx, void* d_dst, const void* h_src, size_t nbytes);
+int havc_dev_download(havc_ctx* ctx, void* h_dst, const void* d_src, size_t nbytes);
+
+/* timing of the dominant kernel for bench.py's roofline object: average duration (ms) and launch count
+ * of HAVC_OP_CONV ops with the given tag over the launches since havc_reset_stats (HIP events on the
+ * ctx stream are recorded around those launches only while enabled). */
+int havc_tag_timing_enable(havc_ctx* ctx, int tag, int enable);
+int havc_tag_timing_read(havc_ctx* ctx, double* avg_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HAVC_MI355_H */

@@ -1,0 +1,18 @@
+"""CPU oracle for the HAVC per-frame colorization hot path.  TEST INFRASTRUCTURE ONLY.
+
+Everything under oracle/ is a CPU restatement of the reference algorithm (dan64/vs-deoldify
+5.6.7) used as the *checker*: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may import it.  The product path (havc_mi355/) never imports this package and fails
+loudly when the HIP library is missing.
+
+Pinning status:
+  * decoder / attention / shuffle / norm folding / pre+post tensor math / PIL resize, L, blend:
+    PINNED by golden vectors produced by executing the reference itself in the build container
+    (tools/gen_golden.py -> tests/golden/*.npz).
+  * ResNet encoder: pinned to oracle/resnet.py (torchvision absent from the container; standard
+    ResNet v1.5 topology, state-dict key compatible).
+  * cv2.cvtColor RGB<->YUV: PARITY UNPINNED at LSB level (cv2 absent) — restated from OpenCV's
+    published 14-bit fixed-point BT.601 formulas in oracle/cvcolor.py.
+  * skimage rgb2lab/lab2rgb: PARITY UNPINNED (skimage absent) — restated from the CIE standard.
+  * DDColor (external vsddcolor wheel): PARITY UNPINNED (no source under /root/reference).
+"""

@@ -1,0 +1,74 @@
+"""End-to-end CPU restatement of the DeOldify per-frame path — ORACLE / TEST INFRASTRUCTURE ONLY.
+
+  colorizer_filter  <- ColorizerFilter.filter / BaseFilter._model_process / _post_process
+                       (vsdeoldify/deoldify/filters.py:23-110)
+  model_image_render <- ModelImageRender.get_transformed_image (vsdeoldify/deoldify/visualize.py:118-137)
+  chroma_post_process / chroma_stabilizer / image_weighted_merge <- vsdeoldify/vsslib/imfilters.py
+"""
+import numpy as np
+import torch
+
+from . import cvcolor, imaging, unet
+
+
+def _to_torch_sd(sd):
+    return {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))) for k, v in sd.items()}
+
+
+def raw_color_square(sd, arch, sq_u8):
+    """_model_process on an image already at the render size: uint8 [S,S,3] -> uint8 [S,S,3]."""
+    x = torch.from_numpy(imaging.model_input(sq_u8))
+    with torch.no_grad():
+        y = unet.unet_forward(_to_torch_sd(sd), x, arch)
+    return imaging.model_output_u8(y[0].numpy())
+
+
+def post_process(raw_color, orig):
+    """ColorizerFilter._post_process (filters.py:100-110) == chroma_post_process (imfilters.py:312-321)."""
+    c = cvcolor.rgb2yuv_u8(raw_color)
+    o = cvcolor.rgb2yuv_u8(orig)
+    o[..., 1:3] = c[..., 1:3]
+    return cvcolor.yuv2rgb_u8(o)
+
+
+chroma_post_process = post_process
+
+
+def colorizer_filter(sd, arch, img_u8, render_factor, do_post=True):
+    from PIL import Image
+    S = render_factor * 16
+    im = Image.fromarray(img_u8)
+    sq = np.asarray(im.resize((S, S), resample=Image.BILINEAR))          # filters.py:37-41
+    raw = raw_color_square(sd, arch, sq)
+    raw = np.asarray(Image.fromarray(raw).resize(im.size, resample=Image.BILINEAR))   # filters.py:70-73
+    return post_process(raw, img_u8) if do_post else raw
+
+
+def model_image_render(sds, modelname, img_u8, render_factor, video_weight, do_post=True):
+    """sds: {'video': sd, 'stable'|'artistic': sd}.  visualize.py:118-137."""
+    v = colorizer_filter(sds["video"], "wide", img_u8, render_factor, do_post)
+    if modelname == "video":
+        return v
+    second = colorizer_filter(sds[modelname], "deep" if modelname == "artistic" else "wide", img_u8, render_factor, do_post)
+    return imaging.pil_blend(second, v, video_weight)
+
+
+def chroma_stabilizer(img_stable, img_new, alpha=0.15, weight=1.0):
+    """vsslib/imfilters.py:160-200 (numpy float64 products, truncating uint8 casts, cap then floor)."""
+    yuv1 = cvcolor.rgb2yuv_u8(img_stable)
+    y1, u1, v1 = yuv1[..., 0], yuv1[..., 1], yuv1[..., 2]
+    u_up = np.multiply(u1, 1 + alpha).clip(0, 255).astype(np.uint8)
+    v_up = np.multiply(v1, 1 + alpha).clip(0, 255).astype(np.uint8)
+    u_dn = np.multiply(u1, 1 - alpha).clip(0, 255).astype(np.uint8)
+    v_dn = np.multiply(v1, 1 - alpha).clip(0, 255).astype(np.uint8)
+    yuv2 = cvcolor.rgb2yuv_u8(img_new)
+    out = np.copy(yuv2)
+
+    def clip(a, lo, hi):
+        a = np.where(a > hi, hi, a).astype(np.uint8)
+        return np.where(a < lo, lo, a).astype(np.uint8)
+    out[..., 0] = y1
+    out[..., 1] = clip(yuv2[..., 1], u_dn, u_up)
+    out[..., 2] = clip(yuv2[..., 2], v_dn, v_up)
+    rgb = cvcolor.yuv2rgb_u8(out)
+    return imaging.pil_blend(img_stable, rgb, weight) if weight < 1.0 else rgb

@@ -1,0 +1,54 @@
+"""Helpers for the -m gpu parity tests: run single ops / small plans through the C ABI."""
+import numpy as np
+
+from vsdeoldify_amd import _native as nat
+from vsdeoldify_amd.plan import PlanBuilder, View, WeightPack, pack_conv, pad_to
+
+
+def nhwc_pad(x_nchw, span=None):
+    """float NCHW -> fp16 NHWC with channels zero-padded to `span` (multiple of 8)."""
+    n, c, h, w = x_nchw.shape
+    span = span or pad_to(c, 8)
+    out = np.zeros((n, h, w, span), np.float16)
+    out[..., :c] = np.transpose(x_nchw, (0, 2, 3, 1)).astype(np.float16)
+    return out
+
+
+def run_plan(ctx, pack, b, uploads, downloads, batch):
+    """uploads: {buf: ndarray}; downloads: {buf: (shape, dtype)} -> {buf: ndarray}."""
+    ops, bufs = b.finish()
+    w = nat.Weights(ctx, pack.blob() or b"\0" * 256)
+    net = nat.Net(ctx, w, ops, bufs, 0, 0, 0, batch)
+    try:
+        for k, v in uploads.items():
+            net.upload(k, v)
+        net.run_ops(0, len(ops), batch)
+        return {k: net.download(k, shp, dt) for k, (shp, dt) in downloads.items()}
+    finally:
+        net.close()
+        w.close()
+
+
+def conv_op(ctx, x, W, bias=None, scale=None, shift=None, stride=1, pad=0, dil=1, flags=0, res=None, pixshuf=False):
+    """x [B,Cin,H,W] float, W [Cout,Cin,kh,kw] -> fp16 NHWC output (float32 NCHW returned) via OP_CONV."""
+    B, Cin, H, Wd = x.shape
+    pack, b = WeightPack(), PlanBuilder()
+    xv = b.tensor(H, Wd, Cin)
+    pc = pack_conv(pack, W.astype(np.float32), xv.cmap, xv.span, bias=bias, scale=scale, shift=shift, pixshuf=pixshuf)
+    kh, kw = W.shape[2:]
+    Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    Wo = (Wd + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    if pixshuf:
+        flags |= nat.F_OUT_PIXSHUF
+        yv = b.tensor(2 * Ho, 2 * Wo, W.shape[0] // 4)
+    else:
+        yv = b.tensor(Ho, Wo, W.shape[0])
+    ups = {xv.buf: nhwc_pad(x)}
+    rv = None
+    if res is not None:
+        rv = b.tensor(Ho, Wo, W.shape[0])
+        ups[rv.buf] = nhwc_pad(res)
+        flags |= nat.F_RESIDUAL
+    b.conv("t", pc, xv, yv, stride=stride, pad=pad, dil=dil, flags=flags, res=rv)
+    out = run_plan(ctx, pack, b, ups, {yv.buf: ((B, yv.H, yv.W, yv.span), np.float16)}, B)[yv.buf]
+    return out.astype(np.float32)[..., :yv.C].transpose(0, 3, 1, 2), out

@@ -1,0 +1,184 @@
+"""-m gpu: every HIP kernel against the CPU oracle (torch fp32 functional ops / numpy) on seeded inputs.
+
+Tolerances: activations are stored as fp16 and accumulated in fp32 on MFMA, so a conv output may differ
+from the fp32 oracle (fed the SAME fp16-rounded inputs and weights) by fp16 output rounding (2^-11 rel)
+plus accumulation-order noise: |diff| <= 2e-3 * max|ref| + 2e-3.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import gpu_util as gu
+from vsdeoldify_amd import _native as nat
+from vsdeoldify_amd.plan import PlanBuilder, View, WeightPack, pack_conv, pad_to
+
+pytestmark = pytest.mark.gpu
+
+
+def h16(a):
+    return np.asarray(a, np.float32).astype(np.float16).astype(np.float32)
+
+
+def assert_close(got, ref, what, rtol=2e-3, atol=2e-3):
+    ref = np.asarray(ref, np.float32)
+    err = np.abs(got - ref).max()
+    lim = rtol * np.abs(ref).max() + atol
+    assert np.isfinite(got).all(), f"{what}: non-finite output"
+    assert err <= lim, f"{what}: max|diff| {err:.4g} > {lim:.4g} (max|ref| {np.abs(ref).max():.4g})"
+
+
+CONV_CASES = [
+    # (B, Cin, Cout, k, stride, pad, dil, H, W)
+    (1, 3, 64, 7, 2, 3, 1, 48, 48),        # resnet stem (Cin 3 -> 8 padded)
+    (2, 64, 64, 1, 1, 0, 1, 20, 20),       # bottleneck 1x1
+    (1, 64, 64, 3, 1, 1, 1, 24, 24),       # 3x3
+    (1, 128, 128, 3, 2, 1, 1, 17, 17),     # stride-2 3x3, odd size
+    (1, 256, 512, 1, 2, 0, 1, 14, 14),     # downsample 1x1 stride 2
+    (1, 320, 256, 3, 1, 1, 1, 24, 24),     # decoder cat conv (layers.7 shape family)
+    (1, 264 - 5, 259, 3, 1, 1, 1, 32, 32), # tail res conv: 259 -> 259 (BN tile 272)
+    (1, 303, 303, 3, 1, 1, 1, 16, 16),     # deep tail: 303 -> 303 (BN tile 304)
+    (3, 96, 40, 3, 1, 1, 1, 9, 11),        # ragged everything, batch 3
+    (1, 512, 4096, 3, 1, 1, 1, 6, 6),      # middle conv family: tiny M, wide N
+    (1, 32, 32, 3, 1, 2, 2, 16, 16),       # dilation 2 (Zhang eccv16 family)
+    (1, 2048, 512, 1, 1, 0, 1, 5, 5),      # long K 1x1
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[str(c) for c in CONV_CASES])
+def test_conv_plain(ctx, case):
+    B, Cin, Cout, k, s, p, d, H, W = case
+    r = np.random.default_rng(hash(case) % 2**31)
+    x = h16(r.standard_normal((B, Cin, H, W)))
+    Wt = h16(r.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k))
+    bias = r.standard_normal(Cout).astype(np.float32)
+    got, raw = gu.conv_op(ctx, x, Wt, bias=bias, stride=s, pad=p, dil=d)
+    ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(Wt), torch.from_numpy(bias), s, p, d).numpy()
+    assert_close(got, ref, f"conv {case}")
+    assert (raw[..., Cout:] == 0).all(), "pad channels must stay zero"
+
+
+def test_conv_epilogue_relu_affine_residual(ctx):
+    r = np.random.default_rng(1)
+    x = h16(r.standard_normal((2, 72, 13, 15)))
+    Wt = h16(r.standard_normal((136, 72, 3, 3)) / 25)
+    bias, sc, sh = (r.standard_normal(136).astype(np.float32) for _ in range(3))
+    res = h16(r.standard_normal((2, 136, 13, 15)))
+    xt, wt = torch.from_numpy(x), torch.from_numpy(Wt)
+    conv = F.conv2d(xt, wt, torch.from_numpy(bias), 1, 1)
+    # conv -> ReLU -> BN (decoder, deoldify/layers.py:39-45)
+    got, _ = gu.conv_op(ctx, x, Wt, bias=bias, scale=sc, shift=sh, pad=1, flags=nat.F_RELU_PRE | nat.F_AFFINE)
+    ref = F.relu(conv) * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1)
+    assert_close(got, ref.numpy(), "relu->affine")
+    # bottleneck tail: relu(conv + identity)
+    got, _ = gu.conv_op(ctx, x, Wt, bias=bias, pad=1, flags=nat.F_RELU_POST, res=res)
+    assert_close(got, F.relu(conv + torch.from_numpy(res)).numpy(), "residual->relu")
+    # res_block tail: c + relu(conv + b)   (fastai/layers.py:154-161)
+    got, _ = gu.conv_op(ctx, x, Wt, bias=bias, pad=1, flags=nat.F_RELU_PRE, res=res)
+    assert_close(got, (F.relu(conv) + torch.from_numpy(res)).numpy(), "relu->residual")
+
+
+@pytest.mark.parametrize("cout4", [64, 1200])
+def test_conv_pixel_shuffle(ctx, cout4):
+    r = np.random.default_rng(2)
+    x = h16(r.standard_normal((2, 48, 7, 9)))
+    Wt = h16(r.standard_normal((cout4, 48, 1, 1)) / 7)
+    bias = r.standard_normal(cout4).astype(np.float32)
+    got, _ = gu.conv_op(ctx, x, Wt, bias=bias, flags=nat.F_RELU_PRE, pixshuf=True)
+    ref = F.pixel_shuffle(F.relu(F.conv2d(torch.from_numpy(x), torch.from_numpy(Wt), torch.from_numpy(bias))), 2)
+    assert_close(got, ref.numpy(), "pixel shuffle store")
+
+
+def test_maxpool_blur_affine(ctx):
+    r = np.random.default_rng(3)
+    x = h16(r.standard_normal((2, 64, 18, 18)))
+    pack, b = WeightPack(), PlanBuilder()
+    xv = b.tensor(18, 18, 64)
+    mp = b.tensor(9, 9, 64)
+    b.maxpool("mp", xv, mp)
+    bl = b.tensor(18, 18, 64)
+    b.blur_resize("blur", xv, bl)
+    bl2 = b.tensor(17, 17, 64)          # nearest 18 -> 17 after the blur (the rf=35 36->35 case)
+    b.blur_resize("blur_rs", xv, bl2)
+    sc, sh = r.standard_normal(64).astype(np.float32), r.standard_normal(64).astype(np.float32)
+    af = b.tensor(18, 18, 64)
+    b.affine("aff", xv, af, pack.add(sc), pack.add(sh), relu=True)
+    out = gu.run_plan(ctx, pack, b, {xv.buf: gu.nhwc_pad(x)},
+                      {v.buf: ((2, v.H, v.W, 64), np.float16) for v in (mp, bl, bl2, af)}, 2)
+    xt = torch.from_numpy(x)
+    nchw = lambda v: out[v.buf].astype(np.float32).transpose(0, 3, 1, 2)
+    assert_close(nchw(mp), F.max_pool2d(xt, 3, 2, 1).numpy(), "maxpool", 0, 0)
+    blur = F.avg_pool2d(F.pad(xt, (1, 0, 1, 0), mode="replicate"), 2, stride=1)
+    assert_close(nchw(bl), blur.numpy(), "blur", 1e-3, 1e-3)
+    assert_close(nchw(bl2), F.interpolate(blur, (17, 17), mode="nearest").numpy(), "blur+nearest", 1e-3, 1e-3)
+    ref = F.relu(xt * torch.from_numpy(sc).view(1, -1, 1, 1) + torch.from_numpy(sh).view(1, -1, 1, 1))
+    assert_close(nchw(af), ref.numpy(), "affine+relu", 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize("C,H,W,B", [(512, 6, 6, 1), (512, 13, 11, 2), (768, 9, 9, 1)])
+def test_self_attention(ctx, C, H, W, B):
+    """fastai SelfAttention (fastai/layers.py:81-96) via two 1x1 convs + the flash kernel."""
+    from oracle import unet as ou
+    r = np.random.default_rng(C + H)
+    d = C // 8
+    x = h16(r.standard_normal((B, C, H, W)))
+    wq, wk = (h16(r.standard_normal((d, C, 1)) / np.sqrt(C) * 1.5) for _ in range(2))
+    wv = h16(r.standard_normal((C, C, 1)) / np.sqrt(C))
+    gamma = 0.7
+    pack, b = WeightPack(), PlanBuilder()
+    xv = b.tensor(H, W, C)
+    pc_qk = pack_conv(pack, np.concatenate([wq, wk])[..., None], xv.cmap, xv.span)
+    pc_v = pack_conv(pack, wv[..., None], xv.cmap, xv.span)
+    qk = b.tensor(H, W, 2 * d)
+    b.conv("qk", pc_qk, xv, qk)
+    N = H * W
+    npitch = pad_to(N, 64)
+    vT = b.buf(C * npitch, 2, zero_init=True)
+    b.conv("v", pc_v, xv, vT, flags=nat.F_OUT_TRANSPOSED, Co=C, aux0=npitch)
+    y = b.tensor(H, W, C)
+    b.attention("attn", xv, qk, d, vT, npitch, y, gamma)
+    out = gu.run_plan(ctx, pack, b, {xv.buf: gu.nhwc_pad(x)}, {y.buf: ((B, H, W, C), np.float16)}, B)[y.buf]
+    got = out.astype(np.float32).transpose(0, 3, 1, 2)
+    # oracle: the restated reference layer on a state dict whose spectral fold is the identity (sigma = 1)
+    sd = {}
+    for nm, w in (("query", wq), ("key", wk), ("value", wv)):
+        wm = torch.from_numpy(w)
+        v = torch.ones(C) / np.sqrt(C)
+        t = wm.reshape(w.shape[0], -1) @ v
+        sd[f"a.{nm}.weight_orig"], sd[f"a.{nm}.weight_v"], sd[f"a.{nm}.weight_u"] = wm, v, t / t.dot(t)
+    sd["a.gamma"] = torch.tensor([gamma])
+    ref = ou.self_attention(sd, "a", torch.from_numpy(x)).numpy()
+    assert_close(got, ref, f"attention C={C} N={N}", 4e-3, 4e-3)
+
+
+def test_prep_rgb8(ctx):
+    from oracle import imaging
+    r = np.random.default_rng(5)
+    img = r.integers(0, 256, (2, 32, 32, 3), dtype=np.uint8)
+    b = PlanBuilder()
+    inb = b.buf(32 * 32 * 3, 1)
+    y0 = b.tensor(32, 32, 3, zero_init=False)
+    b.prep_rgb8("prep", inb, 32, y0)
+    out = gu.run_plan(ctx, WeightPack(), b, {inb: img}, {y0.buf: ((2, 32, 32, 8), np.float16)}, 2)[y0.buf]
+    ref = np.concatenate([imaging.model_input(im) for im in img]).transpose(0, 2, 3, 1)
+    assert (out[..., 3:] == 0).all()
+    assert np.abs(out[..., :3].astype(np.float32) - ref).max() <= 2e-3   # fp16 rounding of values <= 2.7
+
+
+def test_color_filters_bit_exact(ctx):
+    """blend / chroma_post_process / chroma_stabilizer are integer paths: bit-exact vs the oracle."""
+    from oracle import imaging, pipeline
+    from vsdeoldify_amd import imfilters
+    r = np.random.default_rng(6)
+    a = r.integers(0, 256, (61, 83, 3), dtype=np.uint8)
+    bimg = r.integers(0, 256, (61, 83, 3), dtype=np.uint8)
+    for w in (0.3, 0.4, 0.5, 0.77):
+        assert np.array_equal(imfilters.blend_np(ctx, a, bimg, w), imaging.pil_blend(a, bimg, w)), f"blend w={w}"
+    assert np.array_equal(imfilters.chroma_post_process_np(ctx, a, bimg), pipeline.chroma_post_process(a, bimg))
+    for alpha, wgt in ((0.15, 1.0), (0.2, 0.6), (0.05, 0.5)):
+        got = imfilters.chroma_stabilizer_np(ctx, a, bimg, alpha, wgt)
+        assert np.array_equal(got, pipeline.chroma_stabilizer(a, bimg, alpha, wgt)), f"chroma_stabilizer {alpha} {wgt}"
+    # exhaustive-ish: all (Y,U,V)-relevant corners
+    g = np.stack(np.meshgrid(np.arange(0, 256, 5), np.arange(0, 256, 5), np.arange(0, 256, 5)), -1).reshape(-1, 1, 3).astype(np.uint8)
+    h = g[::-1].copy()
+    assert np.array_equal(imfilters.chroma_post_process_np(ctx, g, h), pipeline.chroma_post_process(g, h))

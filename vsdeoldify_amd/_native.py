@@ -1,0 +1,243 @@
+"""ctypes binding of libhavc_mi355.so (C ABI: include/havc_mi355.h).
+
+The HIP library is the ONLY compute path of this package: there is no CPU / PyTorch fallback.
+If the shared object is missing or no gfx950 device is visible, importing consumers fail loudly
+(NativeLibraryError) instead of degrading silently.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhavc_mi355.so")
+
+HAVC_OK, HAVC_E_INVALID, HAVC_E_OOM, HAVC_E_HIP, HAVC_E_NODEVICE = 0, -1, -2, -3, -4
+
+# op types / flags (mirror include/havc_mi355.h)
+OP_CONV, OP_MAXPOOL, OP_BLUR_RESIZE, OP_AFFINE, OP_ATTENTION, OP_PREP_RGB8, OP_COPY_CH = 1, 2, 3, 4, 5, 6, 7
+F_RELU_PRE, F_AFFINE, F_RESIDUAL, F_RELU_POST = 0x1, 0x2, 0x4, 0x8
+F_OUT_PIXSHUF, F_OUT_TRANSPOSED, F_OUT_RGB8, F_LEAKY = 0x10, 0x20, 0x40, 0x80
+
+# numpy mirror of `struct havc_op` (natural C alignment; checked against sizeof in tests)
+OP_DTYPE = np.dtype([
+    ("type", "<i4"), ("flags", "<i4"),
+    ("src", "<i4"), ("src2", "<i4"), ("dst", "<i4"),
+    ("src_coff", "<i4"), ("src_cpitch", "<i4"),
+    ("dst_coff", "<i4"), ("dst_cpitch", "<i4"),
+    ("res_coff", "<i4"), ("res_cpitch", "<i4"),
+    ("Hi", "<i4"), ("Wi", "<i4"), ("Ci", "<i4"),
+    ("Ho", "<i4"), ("Wo", "<i4"), ("Co", "<i4"),
+    ("kh", "<i4"), ("kw", "<i4"), ("stride", "<i4"), ("pad", "<i4"), ("dil", "<i4"),
+    ("Kc", "<i4"), ("Npad", "<i4"),
+    ("aux0", "<i4"), ("aux1", "<i4"),
+    ("w_off", "<i8"), ("bias_off", "<i8"), ("scale_off", "<i8"), ("shift_off", "<i8"),
+    ("f0", "<f4"), ("f1", "<f4"), ("f2", "<f4"), ("f3", "<f4"),
+    ("flops", "<i8"), ("tag", "<i4"), ("reserved", "<i4"),
+], align=True)
+BUF_DTYPE = np.dtype([("elems_per_frame", "<i8"), ("elem_bytes", "<i4"), ("zero_init", "<i4")], align=True)
+
+
+class Stats(C.Structure):
+    _fields_ = [("last_ms", C.c_double), ("total_ms", C.c_double), ("total_flops", C.c_double),
+                ("frames", C.c_int64), ("launches", C.c_int64), ("bytes_resident", C.c_int64)]
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class HavcOutOfMemory(RuntimeError):
+    """HAVC_E_OOM: the caller reproduces deoldify/filters.py:55-63 (return the input, warn)."""
+
+
+_lib = None
+
+# every symbol include/havc_mi355.h declares: (name, restype, argtypes)
+_P, _I, _F, _D, _SZ = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+SYMBOLS = [
+    ("havc_create", _I, [C.POINTER(_P), _I]),
+    ("havc_destroy", None, [_P]),
+    ("havc_last_error", C.c_char_p, [_P]),
+    ("havc_device_count", _I, []),
+    ("havc_synchronize", _I, [_P]),
+    ("havc_get_stats", _I, [_P, C.POINTER(Stats)]),
+    ("havc_reset_stats", _I, [_P]),
+    ("havc_version", C.c_char_p, []),
+    ("havc_weights_load", _I, [_P, _P, _SZ, C.POINTER(_P)]),
+    ("havc_weights_free", None, [_P]),
+    ("havc_net_create", _I, [_P, _P, _P, _I, _P, _I, _I, _I, _I, _I, C.POINTER(_P)]),
+    ("havc_net_free", None, [_P]),
+    ("havc_net_run_rgb8", _I, [_P, _P, _P, _I]),
+    ("havc_net_upload", _I, [_P, _I, _P, _SZ]),
+    ("havc_net_download", _I, [_P, _I, _P, _SZ]),
+    ("havc_net_run_ops", _I, [_P, _I, _I, _I]),
+    ("havc_net_profile", _I, [_P, _I, _P, _I]),
+    ("havc_deoldify_frames", _I, [_P, _P, _P, _F, _I, _P, _P, _I]),
+    ("havc_blend", _I, [_P, _P, _P, _F, _P, _I, _I]),
+    ("havc_chroma_post_process", _I, [_P, _P, _P, _P, _I, _I]),
+    ("havc_chroma_stabilizer", _I, [_P, _P, _P, _D, _D, _P, _I, _I]),
+    ("havc_colorize_clip", _I, [_P, _P, _P, _F, _P, _P, _I, _I, _I]),
+    ("havc_dev_alloc", _I, [_P, _SZ, C.POINTER(_P)]),
+    ("havc_dev_free", _I, [_P, _P]),
+    ("havc_dev_upload", _I, [_P, _P, _P, _SZ]),
+    ("havc_dev_download", _I, [_P, _P, _P, _SZ]),
+    ("havc_tag_timing_enable", _I, [_P, _I, _I]),
+    ("havc_tag_timing_read", _I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+]
+
+
+def load():
+    """dlopen the HIP library (idempotent).  Raises NativeLibraryError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  vsdeoldify_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the box
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, res, args in SYMBOLS:
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, ctx=None):
+    if rc == HAVC_OK:
+        return
+    msg = load().havc_last_error(ctx)
+    msg = msg.decode() if msg else ""
+    if rc == HAVC_E_OOM:
+        raise HavcOutOfMemory(msg or "out of device memory")
+    if rc == HAVC_E_INVALID:
+        raise ValueError(f"havc: invalid argument: {msg}")
+    if rc == HAVC_E_NODEVICE:
+        raise NativeLibraryError(f"havc: {msg}")
+    raise RuntimeError(f"havc: HIP failure ({rc}): {msg}")
+
+
+def as_ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU + one HIP stream (device.set(DeviceId(n)) analogue, deoldify/_device.py:21-30)."""
+
+    def __init__(self, device_id=0):
+        lib = load()
+        h = C.c_void_p()
+        check(lib.havc_create(C.byref(h), int(device_id)), None)
+        self.h, self.lib, self.device_id = h, lib, device_id
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.havc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stats(self):
+        s = Stats()
+        check(self.lib.havc_get_stats(self.h, C.byref(s)), self.h)
+        return s
+
+    def reset_stats(self):
+        check(self.lib.havc_reset_stats(self.h), self.h)
+
+    def synchronize(self):
+        check(self.lib.havc_synchronize(self.h), self.h)
+
+    # ---- device memory for resident clips ----
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        check(self.lib.havc_dev_alloc(self.h, int(nbytes), C.byref(p)), self.h)
+        return p
+
+    def dev_free(self, p):
+        check(self.lib.havc_dev_free(self.h, p), self.h)
+
+    def dev_upload(self, d, host):
+        host = np.ascontiguousarray(host)
+        check(self.lib.havc_dev_upload(self.h, d, as_ptr(host), host.nbytes), self.h)
+
+    def dev_download(self, host, d):
+        assert host.flags.c_contiguous
+        check(self.lib.havc_dev_download(self.h, as_ptr(host), d, host.nbytes), self.h)
+
+
+class Weights:
+    def __init__(self, ctx, blob):
+        self.ctx = ctx
+        blob = np.ascontiguousarray(np.frombuffer(blob, dtype=np.uint8))
+        h = C.c_void_p()
+        check(ctx.lib.havc_weights_load(ctx.h, as_ptr(blob), blob.nbytes, C.byref(h)), ctx.h)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.lib.havc_weights_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Net:
+    """weights + plan for one input size S and up to max_batch frames in flight."""
+
+    def __init__(self, ctx, weights, ops, bufs, in_buf, out_buf, S, max_batch):
+        self.ctx, self.weights = ctx, weights
+        self.ops = np.ascontiguousarray(ops, dtype=OP_DTYPE)
+        self.bufs = np.ascontiguousarray(bufs, dtype=BUF_DTYPE)
+        self.S, self.max_batch, self.in_buf, self.out_buf = S, max_batch, in_buf, out_buf
+        h = C.c_void_p()
+        check(ctx.lib.havc_net_create(ctx.h, weights.h, as_ptr(self.ops), len(self.ops), as_ptr(self.bufs),
+                                      len(self.bufs), in_buf, out_buf, S, max_batch, C.byref(h)), ctx.h)
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.lib.havc_net_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, buf, arr):
+        arr = np.ascontiguousarray(arr)
+        check(self.ctx.lib.havc_net_upload(self.h, buf, as_ptr(arr), arr.nbytes), self.ctx.h)
+
+    def download(self, buf, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        check(self.ctx.lib.havc_net_download(self.h, buf, as_ptr(out), out.nbytes), self.ctx.h)
+        return out
+
+    def run_ops(self, first, count, batch=1):
+        check(self.ctx.lib.havc_net_run_ops(self.h, first, count, batch), self.ctx.h)
+
+    def run_rgb8_dev(self, d_in, d_out, batch):
+        check(self.ctx.lib.havc_net_run_rgb8(self.h, d_in, d_out, batch), self.ctx.h)
+
+    def profile(self, batch=1):
+        ms = np.zeros(len(self.ops), dtype=np.float32)
+        check(self.ctx.lib.havc_net_profile(self.h, batch, as_ptr(ms), len(ms)), self.ctx.h)
+        return ms

@@ -1,0 +1,279 @@
+// Implicit-GEMM convolution for gfx950 (CDNA4): NHWC fp16 activations, fp16 packed weights, fp32 MFMA
+// accumulation (v_mfma_f32_16x16x32_f16), fused epilogue.
+//
+// Replaces every nn.Conv2d / conv1d on the colorization hot path (reference: cuDNN/MIOpen via torch;
+// shapes in SURVEY.md §8a-T1; graph in deoldify/unet.py:94-285, fastai/layers.py:81-220).
+//
+// GEMM view:  D[n][m] = sum_k W[n][k] * X[m][k]       (weights are the MFMA "A" operand, pixels the "B"
+//   operand, so that a lane ends up holding 4 CONSECUTIVE output channels of one pixel -> 8-byte stores)
+//   m = (b*Ho + ho)*Wo + wo,  n = output channel,  k = (tap, cin) with cin in 8-channel (16 B) chunks.
+// A 16-byte chunk never straddles a tap, so the im2col gather is one predicated 16-B global load per
+// chunk (zero for padding / M tail / K tail).  LDS tiles are [row][4 chunks] with the chunk index
+// XOR-swizzled by g(row>>2) so that ds_read_b128 fragment reads and ds_write_b128 staging writes are
+// bank-conflict free for the b128 lane groups of MI355X_MICROARCH.md §LDS.
+#include "kernels.h"
+#include "../../include/havc_mi355.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
+__device__ __forceinline__ float act(float v, bool leaky, float slope) {
+    return v > 0.f ? v : (leaky ? v * slope : 0.f);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
+    constexpr int FM = BM / WM / 16;  // 16-pixel fragments per wave
+    constexpr int FN = BN / WN / 16;  // 16-channel fragments per wave
+    constexpr int A_IT = BM * 4 / 256;
+    constexpr int B_IT = (BN * 4 + 255) / 256;
+    constexpr int STAGE = (BM + BN) * 32;  // halfs per pipeline stage
+    static_assert(BM % 64 == 0, "BM");
+    __shared__ __attribute__((aligned(16))) half_t smem[2 * STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    // XCD-aware bijective remap: each XCD (private L2) gets a contiguous run of tiles.
+    const int nwg = gridDim.x;
+    int pid;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int NT = (p.Npad + BN - 1) / BN;
+    const int m0 = (pid / NT) * BM;
+    const int n0 = (pid % NT) * BN;
+
+    const int HoWo = p.Ho * p.Wo;
+    const int j = tid & 3;
+    // ---- per-thread im2col row state -----------------------------------------------------------
+    int a_pix[A_IT], a_hi0[A_IT], a_wi0[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int row = (tid >> 2) + it * 64;
+        const int m = m0 + row;
+        a_ok[it] = m < p.M;
+        const int mm = a_ok[it] ? m : 0;
+        const int b = mm / HoWo;
+        const int rem = mm - b * HoWo;
+        const int ho = rem / p.Wo;
+        const int wo = rem - ho * p.Wo;
+        a_hi0[it] = ho * p.stride - p.pad;
+        a_wi0[it] = wo * p.stride - p.pad;
+        a_pix[it] = b * p.Hi * p.Wi;
+    }
+    int kc8 = j, kkh = 0, kkw = 0;  // this thread's current (cin chunk, tap)
+    while (kc8 >= p.C8) {
+        kc8 -= p.C8;
+        if (++kkw == p.kw) { kkw = 0; ++kkh; }
+    }
+
+    uint4 a_reg[A_IT], b_reg[B_IT];
+    const int KT = p.Kc >> 2;
+
+    auto load_tiles = [&](int kt) {
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int hi = a_hi0[it] + kkh * p.dil;
+            const int wi = a_wi0[it] + kkw * p.dil;
+            const bool ok = a_ok[it] && kkh < p.kh && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ok) {
+                const int64_t off = (int64_t)(a_pix[it] + hi * p.Wi + wi) * p.x_cpitch + p.x_coff + kc8 * 8;
+                v = *reinterpret_cast<const uint4*>(p.x + off);
+            }
+            a_reg[it] = v;
+        }
+        kc8 += 4;
+        while (kc8 >= p.C8) {
+            kc8 -= p.C8;
+            if (++kkw == p.kw) { kkw = 0; ++kkh; }
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int row = (tid >> 2) + it * 64;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (row < BN && n0 + row < p.Npad) {
+                const int64_t off = ((int64_t)(n0 + row) * p.Kc + kt * 4 + j) * 8;
+                v = *reinterpret_cast<const uint4*>(p.w + off);
+            }
+            b_reg[it] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        half_t* As = smem + buf * STAGE;
+        half_t* Bs = As + BM * 32;
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it) {
+            const int row = (tid >> 2) + it * 64;
+            *reinterpret_cast<uint4*>(As + (row * 4 + (j ^ swz(row))) * 8) = a_reg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < B_IT; ++it) {
+            const int row = (tid >> 2) + it * 64;
+            if (row < BN) *reinterpret_cast<uint4*>(Bs + (row * 4 + (j ^ swz(row))) * 8) = b_reg[it];
+        }
+    };
+
+    float4v acc[FN][FM];
+#pragma unroll
+    for (int ni = 0; ni < FN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) acc[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_tiles(kt + 1);
+        const half_t* As = smem + buf * STAGE;
+        const half_t* Bs = As + BM * 32;
+        half8 xf[FM];
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+            const int row = wm * (BM / WM) + mi * 16 + lr;
+            xf[mi] = *reinterpret_cast<const half8*>(As + (row * 4 + (lg ^ swz(row))) * 8);
+        }
+#pragma unroll
+        for (int ni = 0; ni < FN; ++ni) {
+            const int row = wn * (BN / WN) + ni * 16 + lr;
+            const half8 wf = *reinterpret_cast<const half8*>(Bs + (row * 4 + (lg ^ swz(row))) * 8);
+#pragma unroll
+            for (int mi = 0; mi < FM; ++mi)
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, xf[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (kt + 1 < KT) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- fused epilogue ------------------------------------------------------------------------
+    const bool leaky = p.flags & HAVC_F_LEAKY;
+#pragma unroll
+    for (int mi = 0; mi < FM; ++mi) {
+        const int m = m0 + wm * (BM / WM) + mi * 16 + lr;
+        if (m >= p.M) continue;
+        int64_t out_base = 0;
+        if (p.flags & HAVC_F_OUT_PIXSHUF) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int ho = rem / p.Wo;
+            const int wo = rem - ho * p.Wo;
+            out_base = ((int64_t)(b * 2 * p.Ho + 2 * ho) * (2 * p.Wo) + 2 * wo);  // pixel index of (dy=0,dx=0)
+        } else if (p.flags & HAVC_F_OUT_TRANSPOSED) {
+            const int b = m / HoWo;
+            out_base = (int64_t)b * p.Co * p.pix_pitch + (m - b * HoWo);
+        }
+#pragma unroll
+        for (int ni = 0; ni < FN; ++ni) {
+            const int n = n0 + wn * (BN / WN) + ni * 16 + lg * 4;
+            if (n >= p.Npad) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
+            if (p.bias) {
+                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+            }
+            if (p.flags & HAVC_F_OUT_RGB8) {
+                if (n == 0) {
+                    uint8_t* y = reinterpret_cast<uint8_t*>(p.y) + (int64_t)m * 3;
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        float s = 1.f / (1.f + __expf(-v[r]));
+                        s = s * (p.f1 - p.f0) + p.f0;
+                        s = s * p.istd[r] + p.mean[r];   // here istd[] carries std (denormalise)
+                        s = fminf(fmaxf(s, 0.f), 1.f);
+                        y[r] = (uint8_t)(int)(s * 255.f);
+                    }
+                }
+                continue;
+            }
+            if (p.flags & HAVC_F_RELU_PRE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = act(v[r], leaky, p.f2);
+            }
+            if (p.flags & HAVC_F_AFFINE) {
+                const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
+                const float4 sh = *reinterpret_cast<const float4*>(p.shift + n);
+                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
+                v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+            }
+            if (n >= p.Co && !(p.flags & HAVC_F_OUT_PIXSHUF)) continue;
+            if (p.flags & HAVC_F_RESIDUAL) {
+                const half4 rv = *reinterpret_cast<const half4*>(p.res + (int64_t)m * p.res_cpitch + p.res_coff + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+            }
+            if (p.flags & HAVC_F_RELU_POST) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = act(v[r], leaky, p.f2);
+            }
+            half_t* y = reinterpret_cast<half_t*>(p.y);
+            if (p.flags & HAVC_F_OUT_TRANSPOSED) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) y[out_base + (int64_t)(n + r) * p.pix_pitch] = (half_t)v[r];
+            } else {
+                half4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+                int64_t off;
+                if (p.flags & HAVC_F_OUT_PIXSHUF) {
+                    const int q = n / p.Co, c = n - q * p.Co;  // Co = channels per sub-pixel
+                    if (q >= 4) continue;
+                    off = (out_base + (int64_t)(q >> 1) * (2 * p.Wo) + (q & 1)) * p.y_cpitch + p.y_coff + c;
+                } else {
+                    off = (int64_t)m * p.y_cpitch + p.y_coff + n;
+                }
+                *reinterpret_cast<half4*>(y + off) = o;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const ConvArgs& a, hipStream_t s) {
+    const int MT = (a.M + BM - 1) / BM, NT = (a.Npad + BN - 1) / BN;
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(MT * NT), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+enum { CFG_128x128, CFG_128x64, CFG_64x64, CFG_128x272, CFG_128x304, CFG_128x16, CFG_64x128 };
+
+static int pick_config(const ConvArgs& a) {
+    if (a.Npad <= 16) return CFG_128x16;
+    if (a.Npad > 256 && a.Npad <= 272) return CFG_128x272;
+    if (a.Npad > 272 && a.Npad <= 304) return CFG_128x304;
+    const int64_t blocks128 = (int64_t)((a.M + 127) / 128) * ((a.Npad + 127) / 128);
+    if (a.Npad <= 64) return a.M >= 128 * 256 ? CFG_128x64 : CFG_64x64;
+    if (blocks128 >= 512) return CFG_128x128;     // >= 2 blocks per CU: big tile
+    const int64_t blocks64x128 = (int64_t)((a.M + 63) / 64) * ((a.Npad + 127) / 128);
+    if (blocks64x128 >= 512 || a.Npad % 128 == 0) return CFG_64x128;
+    return CFG_64x64;
+}
+
+const char* conv_config_name(const ConvArgs& a) {
+    static const char* names[] = {"128x128", "128x64", "64x64", "128x272", "128x304", "128x16", "64x128"};
+    return names[pick_config(a)];
+}
+
+int launch_conv(const ConvArgs& a, hipStream_t s) {
+    switch (pick_config(a)) {
+        case CFG_128x128: return launch_cfg<128, 128, 2, 2>(a, s);
+        case CFG_128x64: return launch_cfg<128, 64, 2, 2>(a, s);
+        case CFG_64x64: return launch_cfg<64, 64, 2, 2>(a, s);
+        case CFG_64x128: return launch_cfg<64, 128, 2, 2>(a, s);
+        case CFG_128x272: return launch_cfg<128, 272, 4, 1>(a, s);
+        case CFG_128x304: return launch_cfg<128, 304, 4, 1>(a, s);
+        case CFG_128x16: return launch_cfg<128, 16, 4, 1>(a, s);
+    }
+    return (int)hipErrorInvalidValue;
+}

@@ -1,0 +1,149 @@
+// HBM-bound NHWC fp16 helper kernels of the DeOldify generator: every thread moves one 8-channel
+// (16-byte) vector, consecutive lanes touch consecutive 16-byte chunks of a pixel (coalesced), grid-stride.
+#include "kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+static inline int grid_for(int64_t work) {
+    int64_t b = (work + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+// ---- MaxPool2d(3, stride 2, pad 1) — torchvision resnet stem (oracle/resnet.py) ----
+__global__ void maxpool3x3s2_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int B, int Hi, int Wi, int Ho,
+                                    int Wo, int C8, int x_cpitch, int x_coff, int y_cpitch, int y_coff) {
+    const int64_t total = (int64_t)B * Ho * Wo * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        int64_t pix = i / C8;
+        const int wo = (int)(pix % Wo);
+        pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        half8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (half_t)(-65504.f);
+        for (int dy = 0; dy < 3; ++dy) {
+            const int hi = ho * 2 - 1 + dy;
+            if ((unsigned)hi >= (unsigned)Hi) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int wi = wo * 2 - 1 + dx;
+                if ((unsigned)wi >= (unsigned)Wi) continue;
+                const half8 v = *reinterpret_cast<const half8*>(x + ((int64_t)(b * Hi + hi) * Wi + wi) * x_cpitch + x_coff + c8 * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+            }
+        }
+        *reinterpret_cast<half8*>(y + ((int64_t)(b * Ho + ho) * Wo + wo) * y_cpitch + y_coff + c8 * 8) = m;
+    }
+}
+
+int launch_maxpool3x3s2(const half_t* x, half_t* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int x_cpitch,
+                        int x_coff, int y_cpitch, int y_coff, hipStream_t s) {
+    const int C8 = C / 8;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for((int64_t)B * Ho * Wo * C8)), dim3(256), 0, s, x, y, B, Hi, Wi,
+                       Ho, Wo, C8, x_cpitch, x_coff, y_cpitch, y_coff);
+    return (int)hipGetLastError();
+}
+
+// ---- ReplicationPad2d((1,0,1,0)) + AvgPool2d(2, stride=1) [+ F.interpolate(nearest) to the skip size] ----
+// CustomPixelShuffle_ICNR.forward tail (deoldify/unet.py:50-52) and UnetBlock*.forward (unet.py:199-203).
+// out[y][x] = mean(in[max(sy-1,0)..sy][max(sx-1,0)..sx]) with (sy,sx) = nearest source index of (y,x);
+// torch 'nearest': src = min(floor(dst * (in/out)), in-1) computed in fp32.
+__global__ void blur_resize_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int B, int Hi, int Wi, int Ho,
+                                   int Wo, int C8, int x_cpitch, int x_coff, int y_cpitch, int y_coff, float sh,
+                                   float sw) {
+    const int64_t total = (int64_t)B * Ho * Wo * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        int64_t pix = i / C8;
+        const int wo = (int)(pix % Wo);
+        pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        int sy = ho, sx = wo;
+        if (Ho != Hi) sy = min((int)floorf(ho * sh), Hi - 1);
+        if (Wo != Wi) sx = min((int)floorf(wo * sw), Wi - 1);
+        const int y0 = max(sy - 1, 0), x0 = max(sx - 1, 0);
+        const half_t* base = x + (int64_t)b * Hi * Wi * x_cpitch + x_coff + c8 * 8;
+        const half8 v00 = *reinterpret_cast<const half8*>(base + ((int64_t)y0 * Wi + x0) * x_cpitch);
+        const half8 v01 = *reinterpret_cast<const half8*>(base + ((int64_t)y0 * Wi + sx) * x_cpitch);
+        const half8 v10 = *reinterpret_cast<const half8*>(base + ((int64_t)sy * Wi + x0) * x_cpitch);
+        const half8 v11 = *reinterpret_cast<const half8*>(base + ((int64_t)sy * Wi + sx) * x_cpitch);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)v00[e] + (float)v01[e] + (float)v10[e] + (float)v11[e]) * 0.25f);
+        *reinterpret_cast<half8*>(y + ((int64_t)(b * Ho + ho) * Wo + wo) * y_cpitch + y_coff + c8 * 8) = o;
+    }
+}
+
+int launch_blur_resize(const half_t* x, half_t* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int x_cpitch,
+                       int x_coff, int y_cpitch, int y_coff, hipStream_t s) {
+    const int C8 = C / 8;
+    const float sh = (float)Hi / (float)Ho, sw = (float)Wi / (float)Wo;
+    hipLaunchKernelGGL(blur_resize_kernel, dim3(grid_for((int64_t)B * Ho * Wo * C8)), dim3(256), 0, s, x, y, B, Hi, Wi, Ho,
+                       Wo, C8, x_cpitch, x_coff, y_cpitch, y_coff, sh, sw);
+    return (int)hipGetLastError();
+}
+
+// ---- y = [relu](x*scale + shift): skip-connection BatchNorm + the block ReLU (unet.py:204), layers.1/2 ----
+__global__ void affine_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ scale,
+                              const float* __restrict__ shift, int relu, int64_t npix, int C8, int x_cpitch, int x_coff,
+                              int y_cpitch, int y_coff) {
+    const int64_t total = npix * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        const int64_t pix = i / C8;
+        const half8 v = *reinterpret_cast<const half8*>(x + pix * x_cpitch + x_coff + c8 * 8);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float f = (float)v[e];
+            if (scale) f = f * scale[c8 * 8 + e] + shift[c8 * 8 + e];
+            if (relu) f = fmaxf(f, 0.f);
+            o[e] = (half_t)f;
+        }
+        *reinterpret_cast<half8*>(y + pix * y_cpitch + y_coff + c8 * 8) = o;
+    }
+}
+
+int launch_affine(const half_t* x, half_t* y, const float* scale, const float* shift, int relu, int64_t npix, int C,
+                  int x_cpitch, int x_coff, int y_cpitch, int y_coff, hipStream_t s) {
+    const int C8 = C / 8;
+    hipLaunchKernelGGL(affine_kernel, dim3(grid_for(npix * C8)), dim3(256), 0, s, x, y, scale, shift, relu, npix, C8,
+                       x_cpitch, x_coff, y_cpitch, y_coff);
+    return (int)hipGetLastError();
+}
+
+int launch_copy_ch(const half_t* x, half_t* y, int64_t npix, int C, int x_cpitch, int x_coff, int y_cpitch,
+                   int y_coff, hipStream_t s) {
+    return launch_affine(x, y, nullptr, nullptr, 0, npix, C, x_cpitch, x_coff, y_cpitch, y_coff, s);
+}
+
+// ---- model input: u8 RGB -> PIL convert('LA').convert('RGB') gray (filters.py:92-93) -> /255 -> imagenet
+// normalise (filters.py:50-53, fastai/vision/data.py:56-58,79) -> fp16, 3 real + 5 zero channels.
+// L = (19595 R + 38470 G + 7471 B + 0x8000) >> 16  (Pillow ImagingConvert rgb2l; verified bit-exact).
+// Writes the tensor twice: y0 = stem-conv input, y1 = the dense MergeLayer slot (layers.9) of the tail.
+__global__ void prep_rgb8_kernel(const uint8_t* __restrict__ rgb, half_t* __restrict__ y0, int y0_cpitch, int y0_coff,
+                                 half_t* __restrict__ y1, int y1_cpitch, int y1_coff, int64_t npix) {
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned r = rgb[i * 3], g = rgb[i * 3 + 1], b = rgb[i * 3 + 2];
+        const unsigned L = (19595u * r + 38470u * g + 7471u * b + 0x8000u) >> 16;
+        const float f = (float)L / 255.f;
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = (half_t)((f - mean[c]) / stdv[c]);
+        *reinterpret_cast<half8*>(y0 + i * y0_cpitch + y0_coff) = o;
+        if (y1) *reinterpret_cast<half8*>(y1 + i * y1_cpitch + y1_coff) = o;
+    }
+}
+
+int launch_prep_rgb8(const uint8_t* rgb, half_t* y0, int y0_cpitch, int y0_coff, half_t* y1, int y1_cpitch,
+                     int y1_coff, int64_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(prep_rgb8_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, y0, y0_cpitch, y0_coff, y1,
+                       y1_cpitch, y1_coff, npix);
+    return (int)hipGetLastError();
+}

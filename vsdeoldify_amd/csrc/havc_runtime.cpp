@@ -1,0 +1,696 @@
+// libhavc_mi355.so runtime: contexts, packed weights, plan executor, frame / clip entry points.
+// Implements include/havc_mi355.h.  No torch, no Python: plain HIP runtime + the kernels in this directory.
+#include "../../include/havc_mi355.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct ResizeTable {
+    int taps = 0;
+    int* d_start = nullptr;
+    float* d_w = nullptr;
+};
+
+}  // namespace
+
+struct havc_ctx {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+    havc_stats stats{};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // grow-only scratch (u8 staging + float resample rows): allocated once, reused every call
+    void* scratch[8] = {nullptr};
+    size_t scratch_sz[8] = {0};
+    std::map<std::pair<int, int>, ResizeTable> resize_tables;
+    // per-tag timing
+    int timed_tag = -1;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tag_events;
+    size_t tag_used = 0;
+    double tag_ms = 0;
+    int64_t tag_launches = 0;
+};
+
+struct havc_weights {
+    havc_ctx* ctx;
+    uint8_t* d_blob;
+    size_t nbytes;
+};
+
+struct havc_net {
+    havc_ctx* ctx;
+    havc_weights* w;
+    std::vector<havc_op> ops;
+    std::vector<havc_buf> bufdesc;
+    std::vector<void*> bufs;
+    int in_buf, out_buf, S, max_batch;
+    const void* in_override = nullptr;
+    void* out_override = nullptr;
+    double flops_per_frame = 0;
+};
+
+namespace {
+
+int fail(havc_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+int hip_fail(havc_ctx* c, hipError_t e, const char* what) {
+    std::string m = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError();
+    return fail(c, e == hipErrorOutOfMemory ? HAVC_E_OOM : HAVC_E_HIP, m);
+}
+
+#define HIP_TRY(ctx, expr)                                         \
+    do {                                                           \
+        hipError_t _e = (expr);                                    \
+        if (_e != hipSuccess) return hip_fail((ctx), _e, #expr);   \
+    } while (0)
+
+int ensure_scratch(havc_ctx* c, int slot, size_t nbytes) {
+    if (c->scratch_sz[slot] >= nbytes) return HAVC_OK;
+    if (c->scratch[slot]) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->scratch[slot]);
+        c->stats.bytes_resident -= (int64_t)c->scratch_sz[slot];
+        c->scratch[slot] = nullptr;
+        c->scratch_sz[slot] = 0;
+    }
+    HIP_TRY(c, hipMalloc(&c->scratch[slot], nbytes));
+    c->scratch_sz[slot] = nbytes;
+    c->stats.bytes_resident += (int64_t)nbytes;
+    return HAVC_OK;
+}
+
+// ---- Spline64 polyphase tables (Avisynth/zimg Spline64 kernel, support 4, widened when downscaling) ----
+double spline64(double x) {
+    x = std::fabs(x);
+    if (x < 1.0) return ((49.0 / 41.0 * x - 6387.0 / 2911.0) * x - 3.0 / 2911.0) * x + 1.0;
+    if (x < 2.0) { x -= 1.0; return ((-24.0 / 41.0 * x + 4032.0 / 2911.0) * x - 2328.0 / 2911.0) * x; }
+    if (x < 3.0) { x -= 2.0; return ((6.0 / 41.0 * x - 1008.0 / 2911.0) * x + 582.0 / 2911.0) * x; }
+    if (x < 4.0) { x -= 3.0; return ((-1.0 / 41.0 * x + 168.0 / 2911.0) * x - 97.0 / 2911.0) * x; }
+    return 0.0;
+}
+
+int get_resize_table(havc_ctx* c, int src, int dst, ResizeTable** out) {
+    auto key = std::make_pair(src, dst);
+    auto it = c->resize_tables.find(key);
+    if (it != c->resize_tables.end()) { *out = &it->second; return HAVC_OK; }
+    const double scale = (double)dst / (double)src;
+    const double fscale = scale < 1.0 ? scale : 1.0;       // kernel stretch for anti-aliasing
+    const double support = 4.0 / fscale;
+    const int taps = (int)std::ceil(2.0 * support) + 1;
+    std::vector<int> start(dst);
+    std::vector<float> w((size_t)dst * taps);
+    for (int i = 0; i < dst; ++i) {
+        const double center = (i + 0.5) / scale - 0.5;
+        const int s0 = (int)std::floor(center - support) + 1;
+        double sum = 0;
+        std::vector<double> tmp(taps);
+        for (int t = 0; t < taps; ++t) { tmp[t] = spline64((s0 + t - center) * fscale); sum += tmp[t]; }
+        for (int t = 0; t < taps; ++t) w[(size_t)i * taps + t] = (float)(tmp[t] / sum);
+        start[i] = s0;
+    }
+    ResizeTable tb;
+    tb.taps = taps;
+    HIP_TRY(c, hipMalloc((void**)&tb.d_start, dst * sizeof(int)));
+    HIP_TRY(c, hipMalloc((void**)&tb.d_w, w.size() * sizeof(float)));
+    HIP_TRY(c, hipMemcpy(tb.d_start, start.data(), dst * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(tb.d_w, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    auto res = c->resize_tables.emplace(key, tb);
+    *out = &res.first->second;
+    return HAVC_OK;
+}
+
+int resize_rgb8(havc_ctx* c, const uint8_t* d_src, int sw, int sh, uint8_t* d_dst, int dw, int dh, int n,
+                const uint8_t* d_orig) {
+    ResizeTable *th, *tv;
+    int rc = get_resize_table(c, sw, dw, &th);
+    if (rc) return rc;
+    rc = get_resize_table(c, sh, dh, &tv);
+    if (rc) return rc;
+    rc = ensure_scratch(c, 7, (size_t)n * sh * dw * 3 * sizeof(float));
+    if (rc) return rc;
+    int e = launch_resize_passes(d_src, sw, sh, d_dst, dw, dh, n, (float*)c->scratch[7], th->d_start, th->d_w, th->taps,
+                                 tv->d_start, tv->d_w, tv->taps, d_orig, c->stream);
+    c->stats.launches += 2;
+    if (e) return hip_fail(c, (hipError_t)e, "resize");
+    return HAVC_OK;
+}
+
+inline void* bufptr(havc_net* n, int id) {
+    if (id == n->in_buf && n->in_override) return const_cast<void*>(n->in_override);
+    if (id == n->out_buf && n->out_override) return n->out_override;
+    return n->bufs[id];
+}
+
+template <typename T>
+inline const T* wptr(havc_net* n, int64_t off) {
+    return off < 0 ? nullptr : reinterpret_cast<const T*>(n->w->d_blob + off);
+}
+
+int run_op(havc_net* n, const havc_op& op, int batch) {
+    havc_ctx* c = n->ctx;
+    hipStream_t s = c->stream;
+    int e = 0;
+    const bool timed = (op.tag == c->timed_tag && c->timed_tag >= 0 && op.type == HAVC_OP_CONV);
+    std::pair<hipEvent_t, hipEvent_t> evp{nullptr, nullptr};
+    if (timed) {
+        if (c->tag_used == c->tag_events.size()) {
+            hipEvent_t a, b;
+            HIP_TRY(c, hipEventCreate(&a));
+            HIP_TRY(c, hipEventCreate(&b));
+            c->tag_events.emplace_back(a, b);
+        }
+        evp = c->tag_events[c->tag_used++];
+        HIP_TRY(c, hipEventRecord(evp.first, s));
+    }
+    switch (op.type) {
+        case HAVC_OP_CONV: {
+            ConvArgs a{};
+            a.x = (const half_t*)bufptr(n, op.src);
+            a.w = wptr<half_t>(n, op.w_off);
+            a.bias = wptr<float>(n, op.bias_off);
+            a.scale = wptr<float>(n, op.scale_off);
+            a.shift = wptr<float>(n, op.shift_off);
+            a.res = (op.flags & HAVC_F_RESIDUAL) ? (const half_t*)bufptr(n, op.src2) : nullptr;
+            a.y = bufptr(n, op.dst);
+            a.x_cpitch = op.src_cpitch; a.x_coff = op.src_coff;
+            a.res_cpitch = op.res_cpitch; a.res_coff = op.res_coff;
+            a.y_cpitch = op.dst_cpitch; a.y_coff = op.dst_coff;
+            a.Hi = op.Hi; a.Wi = op.Wi; a.C8 = op.Ci / 8;
+            a.Ho = op.Ho; a.Wo = op.Wo; a.Co = op.Co;
+            a.kh = op.kh; a.kw = op.kw; a.stride = op.stride; a.pad = op.pad; a.dil = op.dil;
+            a.Kc = op.Kc; a.Npad = op.Npad;
+            a.M = batch * op.Ho * op.Wo;
+            a.flags = op.flags;
+            a.pix_pitch = op.aux0;
+            a.f0 = op.f0; a.f1 = op.f1; a.f2 = op.f2;
+            const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+            for (int i = 0; i < 3; ++i) { a.mean[i] = mean[i]; a.istd[i] = stdv[i]; }
+            if (!a.w || (op.Kc & 3) || a.C8 <= 0) return fail(c, HAVC_E_INVALID, "conv op: bad weights / Kc / Ci");
+            if ((op.flags & HAVC_F_AFFINE) && (!a.scale || !a.shift)) return fail(c, HAVC_E_INVALID, "conv op: AFFINE without scale/shift");
+            e = launch_conv(a, s);
+            break;
+        }
+        case HAVC_OP_MAXPOOL:
+            e = launch_maxpool3x3s2((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), batch, op.Hi, op.Wi, op.Ho,
+                                    op.Wo, op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff, s);
+            break;
+        case HAVC_OP_BLUR_RESIZE:
+            e = launch_blur_resize((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), batch, op.Hi, op.Wi, op.Ho,
+                                   op.Wo, op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff, s);
+            break;
+        case HAVC_OP_AFFINE:
+            e = launch_affine((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), wptr<float>(n, op.scale_off),
+                              wptr<float>(n, op.shift_off), (op.flags & HAVC_F_RELU_POST) ? 1 : 0,
+                              (int64_t)batch * op.Hi * op.Wi, op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch,
+                              op.dst_coff, s);
+            break;
+        case HAVC_OP_COPY_CH:
+            e = launch_copy_ch((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), (int64_t)batch * op.Hi * op.Wi,
+                               op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff, s);
+            break;
+        case HAVC_OP_ATTENTION:
+            e = launch_attention((const half_t*)bufptr(n, op.src2), op.res_cpitch, op.res_coff, op.res_coff + op.aux0,
+                                 op.aux0, (const half_t*)bufptr(n, op.aux1), op.Ci, op.Kc, (const half_t*)bufptr(n, op.src),
+                                 op.src_cpitch, op.src_coff, (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff, batch,
+                                 op.Hi * op.Wi, op.f0, s);
+            break;
+        case HAVC_OP_PREP_RGB8:
+            e = launch_prep_rgb8((const uint8_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
+                                 op.src2 >= 0 ? (half_t*)bufptr(n, op.src2) : nullptr, op.res_cpitch, op.res_coff,
+                                 (int64_t)batch * op.Hi * op.Wi, s);
+            break;
+        default:
+            return fail(c, HAVC_E_INVALID, "unknown op type");
+    }
+    c->stats.launches += 1;
+    if (e) return hip_fail(c, (hipError_t)e, "kernel launch");
+    if (timed) HIP_TRY(c, hipEventRecord(evp.second, s));
+    return HAVC_OK;
+}
+
+int run_ops_locked(havc_net* n, int first, int count, int batch) {
+    if (batch < 1 || batch > n->max_batch) return fail(n->ctx, HAVC_E_INVALID, "batch out of range");
+    if (first < 0 || count < 0 || first + count > (int)n->ops.size()) return fail(n->ctx, HAVC_E_INVALID, "op range");
+    for (int i = first; i < first + count; ++i) {
+        int rc = run_op(n, n->ops[i], batch);
+        if (rc) return rc;
+    }
+    return HAVC_OK;
+}
+
+int net_run_rgb8_locked(havc_net* n, const uint8_t* d_in, uint8_t* d_out, int batch) {
+    n->in_override = d_in;
+    n->out_override = d_out;
+    int rc = run_ops_locked(n, 0, (int)n->ops.size(), batch);
+    n->in_override = nullptr;
+    n->out_override = nullptr;
+    if (rc == HAVC_OK) {
+        n->ctx->stats.total_flops += n->flops_per_frame * batch;
+    }
+    return rc;
+}
+
+struct Timer {
+    havc_ctx* c;
+    explicit Timer(havc_ctx* ctx) : c(ctx) { (void)hipEventRecord(c->ev0, c->stream); }
+    int finish() {
+        HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+        HIP_TRY(c, hipEventSynchronize(c->ev1));
+        float ms = 0;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->stats.last_ms = ms;
+        c->stats.total_ms += ms;
+        return HAVC_OK;
+    }
+};
+
+// colour + blend tail at S x S for a batch already on the device.
+// d_in: source frames; d_v / d_s: raw colour of the video / second model (d_s may be null); result -> d_out.
+int deoldify_tail(havc_ctx* c, const uint8_t* d_in, uint8_t* d_v, uint8_t* d_s, float video_weight, int post_process,
+                  uint8_t* d_out, int64_t npix) {
+    int e;
+    if (!d_s) {
+        if (post_process) { e = launch_yuv_merge(d_v, d_in, d_out, npix, c->stream); c->stats.launches++; }
+        else e = (int)hipMemcpyAsync(d_out, d_v, npix * 3, hipMemcpyDeviceToDevice, c->stream);
+        if (e) return hip_fail(c, (hipError_t)e, "tail");
+        return HAVC_OK;
+    }
+    if (post_process) {
+        e = launch_yuv_merge(d_v, d_in, d_v, npix, c->stream);
+        if (e) return hip_fail(c, (hipError_t)e, "yuv_merge");
+        e = launch_yuv_merge(d_s, d_in, d_s, npix, c->stream);
+        if (e) return hip_fail(c, (hipError_t)e, "yuv_merge");
+        c->stats.launches += 2;
+    }
+    // Image.blend(img_second, img_video, video_weight)  (deoldify/visualize.py:129,135)
+    e = launch_blend_u8(d_s, d_v, video_weight, d_out, npix * 3, c->stream);
+    c->stats.launches++;
+    if (e) return hip_fail(c, (hipError_t)e, "blend");
+    return HAVC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* havc_version(void) { return "havc_mi355 0.1.0 (gfx950)"; }
+
+int havc_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int havc_create(havc_ctx** out, int device_id) {
+    if (!out) return fail(nullptr, HAVC_E_INVALID, "out is NULL");
+    *out = nullptr;
+    int n = havc_device_count();
+    if (n <= 0) return fail(nullptr, HAVC_E_NODEVICE, "no HIP device visible (libhavc_mi355 needs an MI355X / gfx950 GPU)");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, HAVC_E_INVALID, "device_id out of range");
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return fail(nullptr, HAVC_E_HIP, "hipGetDeviceProperties failed");
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, HAVC_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+    havc_ctx* c = new havc_ctx();
+    c->dev = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return fail(nullptr, HAVC_E_HIP, "failed to create stream/events");
+    }
+    *out = c;
+    return HAVC_OK;
+}
+
+void havc_destroy(havc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->dev);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 8; ++i)
+        if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    for (auto& kv : c->resize_tables) { (void)hipFree(kv.second.d_start); (void)hipFree(kv.second.d_w); }
+    for (auto& p : c->tag_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
+    (void)hipEventDestroy(c->ev0);
+    (void)hipEventDestroy(c->ev1);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* havc_last_error(const havc_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int havc_synchronize(havc_ctx* c) {
+    if (!c) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HAVC_OK;
+}
+
+int havc_get_stats(havc_ctx* c, havc_stats* out) {
+    if (!c || !out) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    *out = c->stats;
+    return HAVC_OK;
+}
+
+int havc_reset_stats(havc_ctx* c) {
+    if (!c) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    int64_t res = c->stats.bytes_resident;
+    c->stats = havc_stats{};
+    c->stats.bytes_resident = res;
+    c->tag_used = 0;
+    c->tag_ms = 0;
+    c->tag_launches = 0;
+    return HAVC_OK;
+}
+
+int havc_weights_load(havc_ctx* c, const void* blob, size_t nbytes, havc_weights** out) {
+    if (!c || !blob || !out || nbytes == 0) return fail(c, HAVC_E_INVALID, "weights_load: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    uint8_t* d = nullptr;
+    HIP_TRY(c, hipMalloc((void**)&d, nbytes));
+    hipError_t e = hipMemcpy(d, blob, nbytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d); return hip_fail(c, e, "weights H2D"); }
+    c->stats.bytes_resident += (int64_t)nbytes;
+    *out = new havc_weights{c, d, nbytes};
+    return HAVC_OK;
+}
+
+void havc_weights_free(havc_weights* w) {
+    if (!w) return;
+    std::lock_guard<std::mutex> lk(w->ctx->mu);
+    (void)hipStreamSynchronize(w->ctx->stream);
+    (void)hipFree(w->d_blob);
+    w->ctx->stats.bytes_resident -= (int64_t)w->nbytes;
+    delete w;
+}
+
+int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops, const havc_buf* bufs, int n_bufs,
+                    int in_buf, int out_buf, int S, int max_batch, havc_net** out) {
+    if (!c || !w || !ops || !bufs || !out || n_ops <= 0 || n_bufs <= 0 || max_batch < 1)
+        return fail(c, HAVC_E_INVALID, "net_create: bad args");
+    if (in_buf < 0 || in_buf >= n_bufs || out_buf < 0 || out_buf >= n_bufs) return fail(c, HAVC_E_INVALID, "net_create: in/out buffer id");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    for (int i = 0; i < n_ops; ++i) {
+        const havc_op& o = ops[i];
+        auto bad = [&](int id) { return id < -1 || id >= n_bufs; };
+        if (bad(o.src) || bad(o.src2) || bad(o.dst) || o.src < 0 || o.dst < 0) return fail(c, HAVC_E_INVALID, "net_create: op buffer id out of range");
+        if (o.type == HAVC_OP_ATTENTION && (o.aux1 < 0 || o.aux1 >= n_bufs)) return fail(c, HAVC_E_INVALID, "net_create: attention V^T buffer id");
+        for (int64_t off : {o.w_off, o.bias_off, o.scale_off, o.shift_off})
+            if (off >= 0 && ((size_t)off >= w->nbytes || (off & 15))) return fail(c, HAVC_E_INVALID, "net_create: weight offset out of range / unaligned");
+    }
+    havc_net* n = new havc_net();
+    n->ctx = c; n->w = w;
+    n->ops.assign(ops, ops + n_ops);
+    n->bufdesc.assign(bufs, bufs + n_bufs);
+    n->bufs.assign(n_bufs, nullptr);
+    n->in_buf = in_buf; n->out_buf = out_buf; n->S = S; n->max_batch = max_batch;
+    for (int i = 0; i < n_ops; ++i) n->flops_per_frame += (double)ops[i].flops;
+    for (int i = 0; i < n_bufs; ++i) {
+        // +256 B tail so a predicated-off 16-byte vector address is never formed past the allocation
+        size_t nb = (size_t)bufs[i].elems_per_frame * bufs[i].elem_bytes * max_batch + 256;
+        hipError_t e = hipMalloc(&n->bufs[i], nb);
+        if (e == hipSuccess && bufs[i].zero_init) e = hipMemset(n->bufs[i], 0, nb);
+        if (e != hipSuccess) {
+            for (int k = 0; k <= i; ++k) if (n->bufs[k]) (void)hipFree(n->bufs[k]);
+            delete n;
+            return hip_fail(c, e, "activation buffer allocation");
+        }
+        c->stats.bytes_resident += (int64_t)nb;
+    }
+    *out = n;
+    return HAVC_OK;
+}
+
+void havc_net_free(havc_net* n) {
+    if (!n) return;
+    std::lock_guard<std::mutex> lk(n->ctx->mu);
+    (void)hipStreamSynchronize(n->ctx->stream);
+    for (size_t i = 0; i < n->bufs.size(); ++i) {
+        if (n->bufs[i]) (void)hipFree(n->bufs[i]);
+        n->ctx->stats.bytes_resident -= (int64_t)((size_t)n->bufdesc[i].elems_per_frame * n->bufdesc[i].elem_bytes * n->max_batch + 256);
+    }
+    delete n;
+}
+
+int havc_net_run_rgb8(havc_net* n, const uint8_t* d_in, uint8_t* d_out, int batch) {
+    if (!n || !d_in || !d_out) return HAVC_E_INVALID;
+    havc_ctx* c = n->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    Timer t(c);
+    int rc = net_run_rgb8_locked(n, d_in, d_out, batch);
+    if (rc) return rc;
+    c->stats.frames += batch;
+    return t.finish();
+}
+
+int havc_net_upload(havc_net* n, int buf, const void* host, size_t nbytes) {
+    if (!n || buf < 0 || buf >= (int)n->bufs.size() || !host) return HAVC_E_INVALID;
+    havc_ctx* c = n->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (nbytes > (size_t)n->bufdesc[buf].elems_per_frame * n->bufdesc[buf].elem_bytes * n->max_batch) return fail(c, HAVC_E_INVALID, "upload too large");
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(n->bufs[buf], host, nbytes, hipMemcpyHostToDevice));
+    return HAVC_OK;
+}
+
+int havc_net_download(havc_net* n, int buf, void* host, size_t nbytes) {
+    if (!n || buf < 0 || buf >= (int)n->bufs.size() || !host) return HAVC_E_INVALID;
+    havc_ctx* c = n->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (nbytes > (size_t)n->bufdesc[buf].elems_per_frame * n->bufdesc[buf].elem_bytes * n->max_batch) return fail(c, HAVC_E_INVALID, "download too large");
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(host, n->bufs[buf], nbytes, hipMemcpyDeviceToHost));
+    return HAVC_OK;
+}
+
+int havc_net_run_ops(havc_net* n, int first_op, int n_ops, int batch) {
+    if (!n) return HAVC_E_INVALID;
+    havc_ctx* c = n->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    Timer t(c);
+    int rc = run_ops_locked(n, first_op, n_ops, batch);
+    if (rc) return rc;
+    return t.finish();
+}
+
+int havc_net_profile(havc_net* n, int batch, float* ms_per_op, int n_ops) {
+    if (!n || !ms_per_op || n_ops != (int)n->ops.size()) return HAVC_E_INVALID;
+    havc_ctx* c = n->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    if (batch < 1 || batch > n->max_batch) return fail(c, HAVC_E_INVALID, "batch out of range");
+    std::vector<hipEvent_t> ev(n_ops + 1);
+    for (auto& e : ev) HIP_TRY(c, hipEventCreate(&e));
+    HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+    int rc = HAVC_OK;
+    for (int i = 0; i < n_ops && rc == HAVC_OK; ++i) {
+        rc = run_op(n, n->ops[i], batch);
+        if (rc == HAVC_OK && hipEventRecord(ev[i + 1], c->stream) != hipSuccess) rc = HAVC_E_HIP;
+    }
+    if (rc == HAVC_OK) {
+        if (hipStreamSynchronize(c->stream) != hipSuccess) rc = HAVC_E_HIP;
+        for (int i = 0; i < n_ops && rc == HAVC_OK; ++i)
+            if (hipEventElapsedTime(&ms_per_op[i], ev[i], ev[i + 1]) != hipSuccess) rc = HAVC_E_HIP;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (rc == HAVC_E_HIP) return fail(c, rc, "profile failed");
+    return rc;
+}
+
+int havc_deoldify_frames(havc_ctx* c, havc_net* video, havc_net* second, float video_weight, int post_process,
+                         const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames) {
+    if (!c || !video || !rgb_in || !rgb_out || n_frames < 0) return fail(c, HAVC_E_INVALID, "deoldify_frames: bad args");
+    if (video->ctx != c || (second && (second->ctx != c || second->S != video->S))) return fail(c, HAVC_E_INVALID, "deoldify_frames: nets from another ctx / size");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const int S = video->S;
+    const int64_t npix1 = (int64_t)S * S;
+    int maxb = video->max_batch;
+    if (second) maxb = std::min(maxb, second->max_batch);
+    const size_t fb = (size_t)npix1 * 3;
+    int rc;
+    for (int slot = 0; slot < 4; ++slot)
+        if ((rc = ensure_scratch(c, slot, fb * maxb))) return rc;
+    uint8_t *d_in = (uint8_t*)c->scratch[0], *d_v = (uint8_t*)c->scratch[1], *d_s = (uint8_t*)c->scratch[2],
+            *d_out = (uint8_t*)c->scratch[3];
+    Timer t(c);
+    for (int f0 = 0; f0 < n_frames; f0 += maxb) {
+        const int b = std::min(maxb, n_frames - f0);
+        HIP_TRY(c, hipMemcpyAsync(d_in, rgb_in + (size_t)f0 * fb, fb * b, hipMemcpyHostToDevice, c->stream));
+        if ((rc = net_run_rgb8_locked(video, d_in, d_v, b))) return rc;
+        if (second && (rc = net_run_rgb8_locked(second, d_in, d_s, b))) return rc;
+        if ((rc = deoldify_tail(c, d_in, d_v, second ? d_s : nullptr, video_weight, post_process, d_out, npix1 * b))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(rgb_out + (size_t)f0 * fb, d_out, fb * b, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->stats.frames += n_frames;
+    return t.finish();
+}
+
+static int host_filter_prologue(havc_ctx* c, const uint8_t* a, const uint8_t* b, size_t nbytes, uint8_t** da, uint8_t** db,
+                                uint8_t** dout) {
+    int rc;
+    for (int slot = 0; slot < 3; ++slot)
+        if ((rc = ensure_scratch(c, slot, nbytes))) return rc;
+    *da = (uint8_t*)c->scratch[0]; *db = (uint8_t*)c->scratch[1]; *dout = (uint8_t*)c->scratch[2];
+    HIP_TRY(c, hipMemcpyAsync(*da, a, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(*db, b, nbytes, hipMemcpyHostToDevice, c->stream));
+    return HAVC_OK;
+}
+
+static int host_filter_epilogue(havc_ctx* c, uint8_t* out, const uint8_t* dout, size_t nbytes, int e) {
+    c->stats.launches++;
+    if (e) return hip_fail(c, (hipError_t)e, "filter launch");
+    HIP_TRY(c, hipMemcpyAsync(out, dout, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HAVC_OK;
+}
+
+int havc_blend(havc_ctx* c, const uint8_t* a, const uint8_t* b, float w, uint8_t* out, int width, int height) {
+    if (!c || !a || !b || !out || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "blend: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t nb = (size_t)width * height * 3;
+    uint8_t *da, *db, *dout;
+    int rc = host_filter_prologue(c, a, b, nb, &da, &db, &dout);
+    if (rc) return rc;
+    return host_filter_epilogue(c, out, dout, nb, launch_blend_u8(da, db, w, dout, (int64_t)nb, c->stream));
+}
+
+int havc_chroma_post_process(havc_ctx* c, const uint8_t* color, const uint8_t* orig, uint8_t* out, int width, int height) {
+    if (!c || !color || !orig || !out || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "chroma_post_process: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t nb = (size_t)width * height * 3;
+    uint8_t *da, *db, *dout;
+    int rc = host_filter_prologue(c, color, orig, nb, &da, &db, &dout);
+    if (rc) return rc;
+    return host_filter_epilogue(c, out, dout, nb, launch_yuv_merge(da, db, dout, (int64_t)width * height, c->stream));
+}
+
+int havc_chroma_stabilizer(havc_ctx* c, const uint8_t* img_stable, const uint8_t* img_new, double alpha, double weight,
+                           uint8_t* out, int width, int height) {
+    if (!c || !img_stable || !img_new || !out || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "chroma_stabilizer: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t nb = (size_t)width * height * 3;
+    uint8_t *da, *db, *dout;
+    int rc = host_filter_prologue(c, img_stable, img_new, nb, &da, &db, &dout);
+    if (rc) return rc;
+    return host_filter_epilogue(c, out, dout, nb,
+                                launch_chroma_stabilizer(da, db, alpha, (float)weight, dout, (int64_t)width * height, c->stream));
+}
+
+int havc_colorize_clip(havc_ctx* c, havc_net* video, havc_net* second, float video_weight, const uint8_t* d_src,
+                       uint8_t* d_dst, int n_frames, int width, int height) {
+    if (!c || !video || !d_src || !d_dst || n_frames < 0 || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "colorize_clip: bad args");
+    if (video->ctx != c || (second && (second->ctx != c || second->S != video->S))) return fail(c, HAVC_E_INVALID, "colorize_clip: nets from another ctx / size");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const int S = video->S;
+    const int64_t npix1 = (int64_t)S * S;
+    int maxb = video->max_batch;
+    if (second) maxb = std::min(maxb, second->max_batch);
+    const size_t fb = (size_t)npix1 * 3, fbig = (size_t)width * height * 3;
+    int rc;
+    for (int slot = 0; slot < 4; ++slot)
+        if ((rc = ensure_scratch(c, slot, fb * maxb))) return rc;
+    uint8_t *d_sq = (uint8_t*)c->scratch[0], *d_v = (uint8_t*)c->scratch[1], *d_s = (uint8_t*)c->scratch[2],
+            *d_col = (uint8_t*)c->scratch[3];
+    Timer t(c);
+    for (int f0 = 0; f0 < n_frames; f0 += maxb) {
+        const int b = std::min(maxb, n_frames - f0);
+        const uint8_t* src = d_src + (size_t)f0 * fbig;
+        if (width == S && height == S) {
+            HIP_TRY(c, hipMemcpyAsync(d_sq, src, fb * b, hipMemcpyDeviceToDevice, c->stream));
+        } else if ((rc = resize_rgb8(c, src, width, height, d_sq, S, S, b, nullptr))) return rc;
+        if ((rc = net_run_rgb8_locked(video, d_sq, d_v, b))) return rc;
+        if (second && (rc = net_run_rgb8_locked(second, d_sq, d_s, b))) return rc;
+        if ((rc = deoldify_tail(c, d_sq, d_v, second ? d_s : nullptr, video_weight, 1, d_col, npix1 * b))) return rc;
+        // Spline64 back to full size fused with vs_recover_clip_luma (chroma_post_process vs the source frame)
+        if ((rc = resize_rgb8(c, d_col, S, S, d_dst + (size_t)f0 * fbig, width, height, b, src))) return rc;
+    }
+    c->stats.frames += n_frames;
+    return t.finish();
+}
+
+int havc_dev_alloc(havc_ctx* c, size_t nbytes, void** out) {
+    if (!c || !out) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipMalloc(out, nbytes));
+    return HAVC_OK;
+}
+int havc_dev_free(havc_ctx* c, void* p) {
+    if (!c) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipFree(p));
+    return HAVC_OK;
+}
+int havc_dev_upload(havc_ctx* c, void* d_dst, const void* h_src, size_t nbytes) {
+    if (!c || !d_dst || !h_src) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipMemcpyAsync(d_dst, h_src, nbytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HAVC_OK;
+}
+int havc_dev_download(havc_ctx* c, void* h_dst, const void* d_src, size_t nbytes) {
+    if (!c || !h_dst || !d_src) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipMemcpyAsync(h_dst, d_src, nbytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HAVC_OK;
+}
+
+int havc_tag_timing_enable(havc_ctx* c, int tag, int enable) {
+    if (!c) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->timed_tag = enable ? tag : -1;
+    c->tag_used = 0;
+    return HAVC_OK;
+}
+
+int havc_tag_timing_read(havc_ctx* c, double* avg_ms, int64_t* launches) {
+    if (!c || !avg_ms || !launches) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double total = 0;
+    for (size_t i = 0; i < c->tag_used; ++i) {
+        float ms = 0;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->tag_events[i].first, c->tag_events[i].second));
+        total += ms;
+    }
+    *launches = (int64_t)c->tag_used;
+    *avg_ms = c->tag_used ? total / (double)c->tag_used : 0.0;
+    return HAVC_OK;
+}
+
+}  // extern "C"

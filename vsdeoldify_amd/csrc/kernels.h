@@ -1,0 +1,59 @@
+// Internal launcher declarations shared by the HIP translation units of libhavc_mi355.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+
+struct ConvArgs {
+    const half_t* x;       // input NHWC fp16
+    const half_t* w;       // packed weights [Npad][Kc][8] fp16
+    const float* bias;     // [Npad] or null
+    const float* scale;    // [Npad] or null (AFFINE)
+    const float* shift;
+    const half_t* res;     // residual NHWC fp16 or null
+    void* y;               // output (fp16 NHWC / transposed fp16 / u8 RGB)
+    int x_cpitch, x_coff;  // elements
+    int res_cpitch, res_coff;
+    int y_cpitch, y_coff;
+    int Hi, Wi, C8;        // input spatial, number of 8-channel chunks
+    int Ho, Wo, Co;        // output spatial, channels stored (multiple of 8; 3 for RGB8)
+    int kh, kw, stride, pad, dil;
+    int Kc, Npad;          // weight matrix: Npad rows, Kc chunks (multiple of 4)
+    int M;                 // batch*Ho*Wo
+    int flags;
+    int pix_pitch;         // transposed store: elements per channel row
+    float f0, f1, f2;      // sigmoid range lo/hi, leaky slope
+    float mean[3], istd[3];
+};
+
+// returns hipError_t as int
+int launch_conv(const ConvArgs& a, hipStream_t s);
+const char* conv_config_name(const ConvArgs& a);
+
+int launch_maxpool3x3s2(const half_t* x, half_t* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int x_cpitch,
+                        int x_coff, int y_cpitch, int y_coff, hipStream_t s);
+int launch_blur_resize(const half_t* x, half_t* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int x_cpitch,
+                       int x_coff, int y_cpitch, int y_coff, hipStream_t s);
+int launch_affine(const half_t* x, half_t* y, const float* scale, const float* shift, int relu, int64_t npix, int C,
+                  int x_cpitch, int x_coff, int y_cpitch, int y_coff, hipStream_t s);
+int launch_copy_ch(const half_t* x, half_t* y, int64_t npix, int C, int x_cpitch, int x_coff, int y_cpitch,
+                   int y_coff, hipStream_t s);
+int launch_prep_rgb8(const uint8_t* rgb, half_t* y0, int y0_cpitch, int y0_coff, half_t* y1, int y1_cpitch,
+                     int y1_coff, int64_t npix, hipStream_t s);
+// attention: qk [B][N][qk_pitch] (f at f_coff, g at g_coff, d channels each), vT [B][dv][npitch],
+// x/out NHWC; out = gamma*attn + x
+int launch_attention(const half_t* qk, int qk_pitch, int f_coff, int g_coff, int d, const half_t* vT, int dv,
+                     int npitch, const half_t* x, int x_cpitch, int x_coff, half_t* out, int o_cpitch, int o_coff,
+                     int B, int N, float gamma, hipStream_t s);
+
+// u8 colour filters (device pointers, interleaved RGB)
+int launch_blend_u8(const uint8_t* a, const uint8_t* b, float w, uint8_t* out, int64_t nbytes, hipStream_t s);
+int launch_yuv_merge(const uint8_t* color, const uint8_t* orig, uint8_t* out, int64_t npix, hipStream_t s);
+int launch_chroma_stabilizer(const uint8_t* stable, const uint8_t* inew, double alpha, float weight, uint8_t* out,
+                             int64_t npix, hipStream_t s);
+// separable polyphase resample of interleaved u8 RGB (tap tables from the host; Spline64 = harness stand-in
+// for zimg resize.Spline64).  orig != null fuses chroma_post_process (luma of orig, chroma of the resampled).
+int launch_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int n_frames, float* tmp,
+                         const int* h_start, const float* h_w, int h_taps, const int* v_start, const float* v_w,
+                         int v_taps, const uint8_t* orig, hipStream_t s);

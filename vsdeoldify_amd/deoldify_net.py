@@ -1,0 +1,202 @@
+"""DeOldify generators (video / stable = DynamicUnetWide on resnet101, artistic = DynamicUnetDeep on
+resnet34) as a libhavc_mi355 weight blob + execution plan.
+
+Topology restated from the reference (deoldify/unet.py:94-285, deoldify/layers.py:8-46,
+fastai/layers.py:81-220, torchvision resnet via fastai/vision/learner.py:54-63):
+this module only decides WHAT runs (op order, shapes, which buffers are concatenated); all arithmetic
+is in the HIP kernels.
+"""
+import numpy as np
+
+from . import _native as nat
+from .plan import (TAG_TAIL_RES, PlanBuilder, View, WeightPack, bn_scale_shift, conv_weight, fold_spectral, pack_conv,
+                   pad_to, to_np)
+
+RESNET = {"wide": ("bottleneck", [3, 4, 23, 3]), "deep": ("basic", [3, 4, 6, 3])}
+Y_RANGE = (-3.0, 3.0)          # SigmoidRange(*y_range), deoldify/generators.py:33,111
+
+
+def conv_out(n, k, s, p, d=1):
+    return (n + 2 * p - d * (k - 1) - 1) // s + 1
+
+
+class DeoldifyGenerator:
+    """Packs a reference state dict once; emits a plan per render size S = render_factor * 16."""
+
+    def __init__(self, state_dict, arch="wide"):
+        assert arch in RESNET
+        self.sd, self.arch = to_np(state_dict), arch
+        self.pack, self._pc, self._vec = WeightPack(), {}, {}
+        self._frozen = False
+        self.plan(64)                      # dry run: packs every tensor
+        self.blob = self.pack.blob()
+        self._frozen = True
+
+    # ---- cached packing helpers -------------------------------------------------------------
+    def _conv(self, key, fn):
+        if key not in self._pc:
+            assert not self._frozen, key
+            self._pc[key] = fn()
+        return self._pc[key]
+
+    def _vecs(self, key, fn):
+        if key not in self._vec:
+            assert not self._frozen, key
+            self._vec[key] = tuple(self.pack.add(np.asarray(v, np.float32)) for v in fn())
+        return self._vec[key]
+
+    def _enc_conv(self, wkey, bnkey, x):
+        """conv (no bias) -> BN folded into weight/bias (no activation in between in torchvision resnet)."""
+        def make():
+            W = self.sd[wkey + ".weight"].astype(np.float32)
+            s, sh = bn_scale_shift(self.sd, bnkey)
+            return pack_conv(self.pack, W * s[:, None, None, None], x.cmap, x.span, bias=sh)
+        return self._conv(wkey, make)
+
+    def _dec_conv(self, b, p, x, ks=3):
+        """custom_conv_layer(norm=Spectral, extra_bn): conv -> ReLU -> BN  (deoldify/layers.py:28-45)."""
+        def make():
+            s, sh = bn_scale_shift(self.sd, p + ".2")
+            return pack_conv(self.pack, conv_weight(self.sd, p + ".0"), x.cmap, x.span, scale=s, shift=sh)
+        pc = self._conv(p, make)
+        y = b.tensor(x.H, x.W, pc.Cout)
+        b.conv(p, pc, x, y, pad=ks // 2, flags=nat.F_RELU_PRE | nat.F_AFFINE)
+        return y
+
+    def _attention(self, b, p, x):
+        """fastai SelfAttention (fastai/layers.py:81-96)."""
+        sd, C = self.sd, x.C
+        d = C // 8
+        pc_qk = self._conv(p + ".qk", lambda: pack_conv(
+            self.pack, np.concatenate([fold_spectral(sd, p + ".query"), fold_spectral(sd, p + ".key")])[..., None],
+            x.cmap, x.span))
+        pc_v = self._conv(p + ".value", lambda: pack_conv(self.pack, fold_spectral(sd, p + ".value")[..., None],
+                                                          x.cmap, x.span))
+        qk = b.tensor(x.H, x.W, 2 * d)
+        b.conv(p + ".qk", pc_qk, x, qk)
+        N = x.H * x.W
+        npitch = pad_to(N, 64)
+        vT = b.buf(C * npitch, 2, zero_init=True)
+        b.conv(p + ".value", pc_v, x, vT, flags=nat.F_OUT_TRANSPOSED, Co=C, aux0=npitch)
+        y = b.tensor(x.H, x.W, C)
+        b.attention(p, x, qk, d, vT, npitch, y, float(sd[p + ".gamma"].reshape(-1)[0]))
+        return y
+
+    # ---- plan ---------------------------------------------------------------------------------
+    def plan(self, S):
+        assert S % 16 == 0 and S >= 32, "render size must be render_factor*16"
+        sd, deep = self.sd, self.arch == "deep"
+        kind, nblk = RESNET[self.arch]
+        b = PlanBuilder()
+        in_buf, out_buf = b.buf(S * S * 3, 1), b.buf(S * S * 3, 1)
+
+        c8 = sd["layers.8.conv.0.weight_v"].shape[0] // 4          # channels after the last pixel shuffle
+        c8s = pad_to(c8, 8)
+        tail_span = c8s + 8
+        tail_buf = b.buf(S * S * tail_span, 2, zero_init=c8s != c8)
+        tail_cmap = np.concatenate([np.arange(c8), c8s + np.arange(3)])
+        x0 = b.tensor(S, S, 3, zero_init=False)
+        b.prep_rgb8("prep", in_buf, S, x0, View(tail_buf, c8s, tail_span, S, S, 3, 8))
+
+        # ---- encoder: torchvision resnet children()[:-2] ----
+        e = "layers.0"
+        H2 = conv_out(S, 7, 2, 3)
+        e2 = b.tensor(H2, H2, 64)
+        b.conv(e + ".0", self._enc_conv(e + ".0", e + ".1", x0), x0, e2, stride=2, pad=3, flags=nat.F_RELU_PRE)
+        H4 = conv_out(H2, 3, 2, 1)
+        x = b.tensor(H4, H4, 64)
+        b.maxpool(e + ".3", e2, x)
+        skips = [e2]
+        for li, n in enumerate(nblk):
+            planes = 64 * 2 ** li
+            for bi in range(n):
+                q = f"{e}.{4 + li}.{bi}"
+                stride = 2 if (li > 0 and bi == 0) else 1
+                Ho = conv_out(x.H, 3, stride, 1)
+                idt = x
+                if q + ".downsample.0.weight" in sd:
+                    pc = self._enc_conv(q + ".downsample.0", q + ".downsample.1", x)
+                    idt = b.tensor(Ho, Ho, pc.Cout)
+                    b.conv(q + ".downsample", pc, x, idt, stride=stride)
+                if kind == "bottleneck":
+                    t1 = b.tensor(x.H, x.W, planes)
+                    b.conv(q + ".conv1", self._enc_conv(q + ".conv1", q + ".bn1", x), x, t1, flags=nat.F_RELU_PRE)
+                    t2 = b.tensor(Ho, Ho, planes)
+                    b.conv(q + ".conv2", self._enc_conv(q + ".conv2", q + ".bn2", t1), t1, t2, stride=stride, pad=1,
+                           flags=nat.F_RELU_PRE)
+                    y = b.tensor(Ho, Ho, planes * 4)
+                    b.conv(q + ".conv3", self._enc_conv(q + ".conv3", q + ".bn3", t2), t2, y,
+                           flags=nat.F_RESIDUAL | nat.F_RELU_POST, res=idt)
+                else:
+                    t1 = b.tensor(Ho, Ho, planes)
+                    b.conv(q + ".conv1", self._enc_conv(q + ".conv1", q + ".bn1", x), x, t1, stride=stride, pad=1,
+                           flags=nat.F_RELU_PRE)
+                    y = b.tensor(Ho, Ho, planes)
+                    b.conv(q + ".conv2", self._enc_conv(q + ".conv2", q + ".bn2", t1), t1, y, pad=1,
+                           flags=nat.F_RESIDUAL | nat.F_RELU_POST, res=idt)
+                x = y
+            if li < 3:
+                skips.append(x)
+
+        # ---- layers.1 BN, layers.2 ReLU, layers.3 middle_conv (unet.py:236-246) ----
+        so, sho = self._vecs("layers.1", lambda: bn_scale_shift(sd, "layers.1"))
+        m = b.tensor(x.H, x.W, x.C)
+        b.affine("layers.1", x, m, so, sho, relu=True)
+        x = self._dec_conv(b, "layers.3.0", m)
+        x = self._dec_conv(b, "layers.3.1", x)
+
+        # ---- layers.4-7 UnetBlockWide / UnetBlockDeep (unet.py:55-91,170-205) ----
+        for i, skip in enumerate(reversed(skips)):
+            p = f"layers.{4 + i}"
+
+            def make_shuf(p=p, x=x):
+                s, sh = bn_scale_shift(sd, p + ".shuf.conv.1")      # conv -> BN, no activation between: fold
+                W = conv_weight(sd, p + ".shuf.conv.0")
+                return pack_conv(self.pack, W * s[:, None, None, None], x.cmap, x.span, bias=sh, pixshuf=True)
+            pc = self._conv(p + ".shuf", make_shuf)
+            up_c = pc.Cout // 4
+            ps = b.tensor(2 * x.H, 2 * x.W, up_c)
+            b.conv(p + ".shuf", pc, x, ps, flags=nat.F_RELU_PRE | nat.F_OUT_PIXSHUF)
+            ups, sks = pad_to(up_c, 8), pad_to(skip.C, 8)
+            cat_span = ups + sks
+            cat_buf = b.buf(skip.H * skip.W * cat_span, 2, zero_init=(ups != up_c or sks != skip.C))
+            # blur (+ nearest resize when the shuffled size != skip size, e.g. 36 -> 35 at rf=35)
+            b.blur_resize(p + ".blur", ps, View(cat_buf, 0, cat_span, skip.H, skip.W, up_c, ups))
+            so, sho = self._vecs(p + ".bn", lambda p=p: bn_scale_shift(sd, p + ".bn"))
+            b.affine(p + ".bn", skip, View(cat_buf, ups, cat_span, skip.H, skip.W, skip.C, sks), so, sho, relu=True)
+            cat = View(cat_buf, 0, cat_span, skip.H, skip.W, up_c + skip.C, cat_span,
+                       np.concatenate([np.arange(up_c), ups + np.arange(skip.C)]))
+            if deep:
+                x = self._dec_conv(b, p + ".conv1", cat)
+                x = self._dec_conv(b, p + ".conv2", x)
+                if p + ".conv2.3.gamma" in sd:
+                    x = self._attention(b, p + ".conv2.3", x)
+            else:
+                x = self._dec_conv(b, p + ".conv", cat)
+                if p + ".conv.3.gamma" in sd:
+                    x = self._attention(b, p + ".conv.3", x)
+
+        # ---- layers.8 PixelShuffle_ICNR (weight norm, bias, no BN) -> blur -> layers.9 dense merge ----
+        pc = self._conv("layers.8", lambda x=x: pack_conv(self.pack, conv_weight(sd, "layers.8.conv.0"), x.cmap, x.span,
+                                                           bias=sd["layers.8.conv.0.bias"], pixshuf=True))
+        ps8 = b.tensor(2 * x.H, 2 * x.W, c8)
+        assert ps8.H == S
+        b.conv("layers.8", pc, x, ps8, flags=nat.F_RELU_PRE | nat.F_OUT_PIXSHUF)
+        b.blur_resize("layers.8.blur", ps8, View(tail_buf, 0, tail_span, S, S, c8, c8s))
+        cat = View(tail_buf, 0, tail_span, S, S, c8 + 3, tail_span, tail_cmap)
+
+        # ---- layers.10 res_block: 2 x (spectral conv3x3 + bias -> ReLU), + input; layers.11/12 ----
+        def res_pc(key):
+            return self._conv(key, lambda: pack_conv(self.pack, conv_weight(sd, key), tail_cmap, tail_span,
+                                                     bias=sd[key + ".bias"], omap=tail_cmap, ospan=tail_span))
+        r1 = View(b.buf(S * S * tail_span), 0, tail_span, S, S, c8 + 3, tail_span, tail_cmap)
+        b.conv("layers.10.layers.0.0", res_pc("layers.10.layers.0.0"), cat, r1, pad=1, flags=nat.F_RELU_PRE,
+               tag=TAG_TAIL_RES)
+        r2 = View(b.buf(S * S * tail_span), 0, tail_span, S, S, c8 + 3, tail_span, tail_cmap)
+        b.conv("layers.10.layers.1.0", res_pc("layers.10.layers.1.0"), r1, r2, pad=1,
+               flags=nat.F_RELU_PRE | nat.F_RESIDUAL, res=cat, tag=TAG_TAIL_RES)
+        pc = self._conv("layers.11.0", lambda: pack_conv(self.pack, conv_weight(sd, "layers.11.0"), tail_cmap, tail_span,
+                                                         bias=sd["layers.11.0.bias"]))
+        b.conv("layers.11.0", pc, r2, out_buf, flags=nat.F_OUT_RGB8, f=(Y_RANGE[0], Y_RANGE[1], 0, 0), Co=3)
+        ops, bufs = b.finish()
+        return ops, bufs, in_buf, out_buf, b.names

@@ -1,0 +1,235 @@
+"""Weight packing and execution-plan emission for libhavc_mi355.so (host side, numpy only).
+
+Offline-converter half of the drop-in: takes a reference state dict (fastai/basic_train.py:264-286
+semantics: `{'model': sd}` or a bare dict), resolves spectral / weight norm with the STORED u, v
+(SURVEY.md App. B), folds conv->BN where no activation sits between them, and lays every conv out as
+the fp16 [Npad][tap][cin/8][8] matrix the implicit-GEMM kernel streams (csrc/conv_igemm.hip).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _native as nat
+
+EPS = 1e-5
+TAG_TAIL_RES = 1          # the 259->259 (303->303) 3x3 res-block convs: the dominant kernel
+TAG_FIRST_FREE = 16
+
+
+def pad_to(n, m):
+    return (n + m - 1) // m * m
+
+
+def to_np(sd):
+    """Accept torch tensors or numpy arrays; return {name: float32/64 ndarray}."""
+    if isinstance(sd, dict) and "model" in sd and isinstance(sd["model"], dict):
+        sd = sd["model"]                                    # Learner.load accepts {'model','opt'}
+    out = {}
+    for k, v in sd.items():
+        if hasattr(v, "detach"):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    return out
+
+
+def fold_spectral(sd, p):
+    """W = weight_orig / (u . (W_mat v)) — eval-mode spectral_norm, stored u/v, no power iteration."""
+    w = sd[p + ".weight_orig"].astype(np.float32)
+    wm = w.reshape(w.shape[0], -1)
+    sigma = np.dot(sd[p + ".weight_u"].astype(np.float32), wm @ sd[p + ".weight_v"].astype(np.float32))
+    return w / np.float32(sigma)
+
+
+def fold_weightnorm(sd, p):
+    v = sd[p + ".weight_v"].astype(np.float32)
+    g = sd[p + ".weight_g"].astype(np.float32)
+    n = np.sqrt((v.reshape(v.shape[0], -1) ** 2).sum(1)).reshape(-1, *([1] * (v.ndim - 1)))
+    return g * v / n
+
+
+def conv_weight(sd, p):
+    if p + ".weight_orig" in sd:
+        return fold_spectral(sd, p)
+    if p + ".weight_g" in sd:
+        return fold_weightnorm(sd, p)
+    return sd[p + ".weight"].astype(np.float32)
+
+
+def bn_scale_shift(sd, p):
+    s = sd[p + ".weight"].astype(np.float32) / np.sqrt(sd[p + ".running_var"].astype(np.float32) + np.float32(EPS))
+    return s, sd[p + ".bias"].astype(np.float32) - sd[p + ".running_mean"].astype(np.float32) * s
+
+
+class WeightPack:
+    """Append-only device blob; every tensor 256-byte aligned."""
+
+    def __init__(self):
+        self.parts, self.size = [], 0
+
+    def add(self, arr):
+        b = np.ascontiguousarray(arr).tobytes()
+        off = self.size
+        pad = (-len(b)) % 256
+        self.parts.append(b + b"\0" * pad)
+        self.size += len(b) + pad
+        return off
+
+    def blob(self):
+        return b"".join(self.parts)
+
+
+@dataclass
+class View:
+    """A logical C-channel NHWC tensor living in buffer `buf` at channel offset `coff`."""
+    buf: int
+    coff: int
+    cpitch: int
+    H: int
+    W: int
+    C: int                       # logical channels
+    span: int                    # stored channels (multiple of 8) starting at coff
+    cmap: np.ndarray = None      # position (relative to coff) of each logical channel
+
+    def __post_init__(self):
+        if self.cmap is None:
+            self.cmap = np.arange(self.C)
+
+
+@dataclass
+class PackedConv:
+    w_off: int
+    bias_off: int
+    scale_off: int
+    shift_off: int
+    Kc: int
+    Npad: int
+    Ci: int
+    Cout: int
+    Cin: int
+    kh: int
+    kw: int
+
+
+def pack_conv(pack, W, cmap, Ci, bias=None, scale=None, shift=None, pixshuf=False, omap=None, ospan=None):
+    """W [Cout, Cin, KH, KW] fp32 -> fp16 [Npad][KH*KW][Ci/8][8] (+ fp32 bias/scale/shift [Npad]).
+    cmap: position of every logical input channel inside the Ci-wide input span;
+    omap/ospan: position of every logical output channel inside the ospan-wide output span."""
+    Cout, Cin, KH, KW = W.shape
+    assert len(cmap) == Cin and Ci % 8 == 0
+    if omap is None:
+        omap, ospan = np.arange(Cout), Cout
+    Npad = pad_to(ospan, 16)
+    Wt = np.zeros((Npad, KH, KW, Ci), np.float32)
+    tmp = np.zeros((Cout, KH, KW, Ci), np.float32)
+    tmp[:, :, :, cmap] = W.transpose(0, 2, 3, 1)
+    Wt[omap] = tmp
+
+    def vec(v):
+        if v is None:
+            return None
+        o = np.zeros(Npad, np.float32)
+        o[omap] = v
+        return o
+    bias, scale, shift = vec(bias), vec(scale), vec(shift)
+    if pixshuf:
+        assert Cout % 16 == 0 and Npad == Cout
+        cps = Cout // 4
+        # packed row q*cps + c  <-  original row c*4 + q   (PixelShuffle(2): q = dy*2 + dx)
+        perm = (np.arange(cps)[None, :] * 4 + np.arange(4)[:, None]).reshape(-1)
+        Wt = Wt[perm]
+        bias = None if bias is None else bias[perm]
+        scale = None if scale is None else scale[perm]
+        shift = None if shift is None else shift[perm]
+    K = KH * KW * Ci // 8
+    Kc = pad_to(K, 4)
+    flat = np.zeros((Npad, Kc * 8), np.float16)
+    flat[:, :K * 8] = Wt.reshape(Npad, -1).astype(np.float16)
+    return PackedConv(pack.add(flat), -1 if bias is None else pack.add(bias), -1 if scale is None else pack.add(scale),
+                      -1 if shift is None else pack.add(shift), Kc, Npad, Ci, Cout, Cin, KH, KW)
+
+
+class PlanBuilder:
+    def __init__(self):
+        self.ops, self.bufs, self.names = [], [], []
+
+    def buf(self, elems_per_frame, elem_bytes=2, zero_init=False):
+        self.bufs.append((int(elems_per_frame), elem_bytes, 1 if zero_init else 0))
+        return len(self.bufs) - 1
+
+    def tensor(self, H, W, C, zero_init=True):
+        """fresh buffer holding one logical tensor; zero_init keeps pad channels 0 forever."""
+        span = pad_to(C, 8)
+        return View(self.buf(H * W * span, 2, zero_init and span != C), 0, span, H, W, C, span)
+
+    def _op(self, name, tag=None, **kw):
+        op = np.zeros((), dtype=nat.OP_DTYPE)
+        op["src2"] = -1
+        for f in ("w_off", "bias_off", "scale_off", "shift_off"):
+            op[f] = -1
+        for k, v in kw.items():
+            op[k] = v
+        if tag is None:
+            tag = TAG_FIRST_FREE + len(self.names)
+        op["tag"] = tag
+        self.names.append(name)
+        self.ops.append(op)
+        return len(self.ops) - 1
+
+    def conv(self, name, pc, x, y, stride=1, pad=0, dil=1, flags=0, res=None, tag=None, f=(0, 0, 0, 0), Co=None,
+             aux0=0):
+        """y may be a View (fp16 NHWC / pixel-shuffled target) or a raw buffer id (RGB8 / transposed)."""
+        assert x.span == pc.Ci, (name, x.span, pc.Ci)
+        Ho = (x.H + 2 * pad - dil * (pc.kh - 1) - 1) // stride + 1
+        Wo = (x.W + 2 * pad - dil * (pc.kw - 1) - 1) // stride + 1
+        kw = dict(type=nat.OP_CONV, flags=flags, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, Hi=x.H, Wi=x.W,
+                  Ci=pc.Ci, Ho=Ho, Wo=Wo, kh=pc.kh, kw=pc.kw, stride=stride, pad=pad, dil=dil, Kc=pc.Kc,
+                  Npad=pc.Npad, w_off=pc.w_off, bias_off=pc.bias_off, scale_off=pc.scale_off, shift_off=pc.shift_off,
+                  f0=f[0], f1=f[1], f2=f[2], f3=f[3], aux0=aux0, flops=2 * Ho * Wo * pc.Cout * pc.Cin * pc.kh * pc.kw)
+        if isinstance(y, View):
+            kw.update(dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch)
+            if flags & nat.F_OUT_PIXSHUF:
+                assert y.H == 2 * Ho and y.W == 2 * Wo and pc.Cout == 4 * y.C and y.C % 4 == 0, name
+                kw["Co"] = y.C
+            else:
+                assert y.H == Ho and y.W == Wo and y.C == pc.Cout, (name, y.H, Ho, y.C, pc.Cout)
+                kw["Co"] = y.span
+        else:
+            kw.update(dst=y, Co=Co)
+        if res is not None:
+            assert flags & nat.F_RESIDUAL
+            kw.update(src2=res.buf, res_coff=res.coff, res_cpitch=res.cpitch)
+        return self._op(name, tag, **kw)
+
+    def maxpool(self, name, x, y):
+        return self._op(name, type=nat.OP_MAXPOOL, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf,
+                        dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.span, Ho=y.H, Wo=y.W, Co=y.span)
+
+    def blur_resize(self, name, x, y):
+        assert x.span == y.span
+        return self._op(name, type=nat.OP_BLUR_RESIZE, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf,
+                        dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.span, Ho=y.H, Wo=y.W, Co=y.span)
+
+    def affine(self, name, x, y, scale_off, shift_off, relu):
+        assert x.span == y.span and x.H == y.H
+        return self._op(name, type=nat.OP_AFFINE, flags=nat.F_RELU_POST if relu else 0, src=x.buf, src_coff=x.coff,
+                        src_cpitch=x.cpitch, dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W,
+                        Ci=x.span, Ho=y.H, Wo=y.W, Co=y.span, scale_off=scale_off, shift_off=shift_off)
+
+    def attention(self, name, x, qk, d, vT_buf, npitch, y, gamma):
+        N = x.H * x.W
+        return self._op(name, type=nat.OP_ATTENTION, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf,
+                        dst_coff=y.coff, dst_cpitch=y.cpitch, src2=qk.buf, res_coff=qk.coff, res_cpitch=qk.cpitch,
+                        Hi=x.H, Wi=x.W, Ci=x.C, Ho=x.H, Wo=x.W, Co=x.C, aux0=d, aux1=vT_buf, Kc=npitch, f0=gamma,
+                        flops=2 * N * N * d + 2 * N * N * x.C)
+
+    def prep_rgb8(self, name, in_buf, S, y0, y1=None):
+        kw = dict(type=nat.OP_PREP_RGB8, src=in_buf, dst=y0.buf, dst_coff=y0.coff, dst_cpitch=y0.cpitch, Hi=S, Wi=S,
+                  Ci=8, Ho=S, Wo=S, Co=8)
+        if y1 is not None:
+            kw.update(src2=y1.buf, res_coff=y1.coff, res_cpitch=y1.cpitch)
+        return self._op(name, **kw)
+
+    def finish(self):
+        ops = np.array(self.ops, dtype=nat.OP_DTYPE)
+        bufs = np.array(self.bufs, dtype=nat.BUF_DTYPE)
+        return ops, bufs

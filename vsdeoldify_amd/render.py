@@ -1,0 +1,149 @@
+"""Host-side mirror of the reference's DeOldify adapters, backed by libhavc_mi355.so.
+
+  ModelImageRender        <- vsdeoldify/deoldify/visualize.py:41-137
+  (ColorizerFilter flow)  <- vsdeoldify/deoldify/filters.py:23-124
+Same constructor / method names, argument meaning and error behaviour; images are PIL RGB in, PIL RGB
+out (new object, input untouched).  Weights are read from
+`package_dir/models/Colorize{Video,Stable,Artistic}_gen.pth` exactly like gen_inference_wide/deep
+(deoldify/generators.py:12-21,85-95) unless `state_dicts` are injected (tests / bench: seeded
+synthetic weights).  There is no CPU path: construction raises if the HIP library or GPU is missing.
+"""
+import logging
+import os
+
+import numpy as np
+
+from . import _native as nat
+from .deoldify_net import DeoldifyGenerator
+
+WEIGHTS = {"video": ("ColorizeVideo_gen", "wide"), "stable": ("ColorizeStable_gen", "wide"),
+           "artistic": ("ColorizeArtistic_gen", "deep")}
+RENDER_BASE = 16                      # ColorizerFilter.render_base, deoldify/filters.py:79
+
+_contexts = {}
+
+
+def get_context(device_index=0):
+    """One havc context per GPU (process-wide), like device.set(DeviceId(n)) (deoldify/_device.py:21-30)."""
+    if device_index == 99:
+        raise nat.NativeLibraryError("device_index=99 (CPU) is not supported by vsdeoldify_amd: MI355X only")
+    if device_index not in _contexts:
+        _contexts[device_index] = nat.Context(device_index)
+    return _contexts[device_index]
+
+
+def _load_pth(path):
+    import torch  # plumbing only: deserialise the checkpoint (fastai/basic_train.py:270-283)
+    state = torch.load(path, map_location="cpu", weights_only=False)
+    return state["model"] if isinstance(state, dict) and set(state.keys()) == {"model", "opt"} else state
+
+
+class GeneratorRuntime:
+    """Packed weights on one GPU + a cache of nets keyed by (render size, max_batch)."""
+
+    def __init__(self, ctx, state_dict, arch):
+        self.ctx, self.arch = ctx, arch
+        self.gen = DeoldifyGenerator(state_dict, arch)
+        self.weights = nat.Weights(ctx, self.gen.blob)
+        self.nets = {}
+
+    def net(self, S, max_batch=1):
+        key = (S, max_batch)
+        if key not in self.nets:
+            ops, bufs, i, o, names = self.gen.plan(S)
+            n = nat.Net(self.ctx, self.weights, ops, bufs, i, o, S, max_batch)
+            n.names = names
+            self.nets[key] = n
+        return self.nets[key]
+
+    def close(self):
+        for n in self.nets.values():
+            n.close()
+        self.nets.clear()
+        self.weights.close()
+
+
+class ModelImageRender:
+    """Drop-in for vsdeoldify.deoldify.visualize.ModelImageRender."""
+
+    def __init__(self, package_dir=None, modelname="video", render_factor=24, video_weight=0, device_index=0,
+                 state_dicts=None, max_batch=1):
+        self.package_dir = package_dir
+        self._modelname = modelname
+        self._video_weight = video_weight
+        self._render_factor = render_factor
+        self._max_batch = max_batch
+        self.ctx = get_context(device_index)
+        second = None if modelname == "video" else ("stable" if modelname == "stable" else "artistic")
+        self._video = self._runtime("video", state_dicts)
+        self._second = self._runtime(second, state_dicts) if second else None
+
+    def _runtime(self, which, state_dicts):
+        name, arch = WEIGHTS[which]
+        if state_dicts is not None and which in state_dicts:
+            sd = state_dicts[which]
+        else:
+            path = os.path.join(str(self.package_dir), "models", name + ".pth")      # Learner.load path
+            if not os.path.isfile(path) or os.path.getsize(path) == 0:
+                raise FileNotFoundError(f"DeOldify weights not found: {path}")
+            sd = _load_pth(path)
+        return GeneratorRuntime(self.ctx, sd, arch)
+
+    # -- raw batched entry (frames already S x S, uint8 [n,S,S,3]) ------------------------------
+    def render_square_batch(self, frames, post_process=True):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, S = frames.shape[0], frames.shape[1]
+        assert frames.shape[1:] == (S, S, 3) and S == self._render_factor * RENDER_BASE
+        v = self._video.net(S, self._max_batch)
+        s = self._second.net(S, self._max_batch) if self._second else None
+        out = np.empty_like(frames)
+        nat.check(self.ctx.lib.havc_deoldify_frames(self.ctx.h, v.h, s.h if s else None, float(self._video_weight),
+                                                    1 if post_process else 0, nat.as_ptr(frames), nat.as_ptr(out), n),
+                  self.ctx.h)
+        return out
+
+    def get_transformed_image(self, img_orig, post_process=True):
+        """PIL RGB in -> PIL RGB out, same size (visualize.py:118-137).  Frames already at the render size
+        (the HAVC_colorizer flow, __init__.py:2502-2506) run entirely on the GPU; other sizes use Pillow's own
+        BILINEAR stretch on the host exactly where the reference does (filters.py:37-41,70-73)."""
+        from PIL import Image
+        S = self._render_factor * RENDER_BASE
+        img_orig = img_orig.convert("RGB") if img_orig.mode != "RGB" else img_orig
+        try:
+            if img_orig.size == (S, S):
+                out = self.render_square_batch(np.asarray(img_orig)[None], post_process)[0]
+                return Image.fromarray(out)
+            sq = np.asarray(img_orig.resize((S, S), resample=Image.BILINEAR))
+            raw_v, raw_s = self._raw_colors(sq)
+            outs = []
+            for raw in (raw_v, raw_s):
+                if raw is None:
+                    continue
+                col = np.asarray(Image.fromarray(raw).resize(img_orig.size, resample=Image.BILINEAR))
+                if post_process:
+                    from .imfilters import chroma_post_process_np
+                    col = chroma_post_process_np(self.ctx, col, np.asarray(img_orig))
+                outs.append(col)
+            if len(outs) == 1:
+                return Image.fromarray(outs[0])
+            from .imfilters import blend_np
+            return Image.fromarray(blend_np(self.ctx, outs[1], outs[0], self._video_weight))
+        except nat.HavcOutOfMemory:
+            # deoldify/filters.py:55-63: OOM -> warn and return the (squared, gray) model image
+            logging.warning("Warning: render_factor was set too high, and out of memory error resulted. "
+                            "Returning original image.")
+            return img_orig.resize((S, S), resample=Image.BILINEAR).convert("LA").convert("RGB")
+
+    def _raw_colors(self, sq):
+        S = sq.shape[0]
+        outs = []
+        for rt in (self._video, self._second):
+            if rt is None:
+                outs.append(None)
+                continue
+            n = rt.net(S, self._max_batch)
+            o = np.empty_like(sq[None])
+            nat.check(self.ctx.lib.havc_deoldify_frames(self.ctx.h, n.h, None, 0.0, 0, nat.as_ptr(np.ascontiguousarray(sq[None])),
+                                                        nat.as_ptr(o), 1), self.ctx.h)
+            outs.append(o[0])
+        return outs

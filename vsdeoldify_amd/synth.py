@@ -1,0 +1,165 @@
+"""Seeded synthetic DeOldify state dicts (no real weights exist in the sandbox: SURVEY.md §0.3).
+
+`state_dict_spec(arch)` enumerates the reference's state-dict entries (name -> shape) for the wide
+(resnet101, nf_factor 2) and deep (resnet34, nf_factor 1.5) generators; `synth_state_dict` fills them
+with a counter-based PRNG keyed by (seed, crc32(name)) so that every consumer (tests, bench, golden
+generation) sees identical weights.  Scales are chosen so activations stay O(1) through ~130 layers
+and the pre-sigmoid output is not saturated; spectral / weight-norm parameters are generated so that
+the eval-mode fold is NON-trivial (sigma != 1, g != |v|) yet yields a He-scaled effective weight;
+attention gamma != 0 (the reference's init 0 would hide attention bugs).
+"""
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+RESNET = {"wide": ("bottleneck", [3, 4, 23, 3]), "deep": ("basic", [3, 4, 6, 3])}
+
+
+def _bn(spec, p, c):
+    for k in ("weight", "bias", "running_mean", "running_var"):
+        spec[f"{p}.{k}"] = (c,)
+    spec[f"{p}.num_batches_tracked"] = ()
+
+
+def _spectral(spec, p, shape, bias=False):
+    if bias:
+        spec[p + ".bias"] = (shape[0],)
+    spec[p + ".weight_orig"] = tuple(shape)
+    spec[p + ".weight_u"] = (shape[0],)
+    spec[p + ".weight_v"] = (int(np.prod(shape[1:])),)
+
+
+def state_dict_spec(arch):
+    """name -> shape, in the reference's state_dict() order (checked by tests/golden/spec_*.json)."""
+    kind, nblk = RESNET[arch]
+    deep = arch == "deep"
+    spec = OrderedDict()
+    e = "layers.0"
+    spec[e + ".0.weight"] = (64, 3, 7, 7)
+    _bn(spec, e + ".1", 64)
+    inpl, exp = 64, (4 if kind == "bottleneck" else 1)
+    enc_c = [64]
+    for li, n in enumerate(nblk):
+        planes = 64 * 2 ** li
+        for bi in range(n):
+            q = f"{e}.{4 + li}.{bi}"
+            stride = 2 if (li > 0 and bi == 0) else 1
+            if kind == "bottleneck":
+                spec[q + ".conv1.weight"] = (planes, inpl, 1, 1)
+                _bn(spec, q + ".bn1", planes)
+                spec[q + ".conv2.weight"] = (planes, planes, 3, 3)
+                _bn(spec, q + ".bn2", planes)
+                spec[q + ".conv3.weight"] = (planes * 4, planes, 1, 1)
+                _bn(spec, q + ".bn3", planes * 4)
+            else:
+                spec[q + ".conv1.weight"] = (planes, inpl, 3, 3)
+                _bn(spec, q + ".bn1", planes)
+                spec[q + ".conv2.weight"] = (planes, planes, 3, 3)
+                _bn(spec, q + ".bn2", planes)
+            if bi == 0 and (stride != 1 or inpl != planes * exp):
+                spec[q + ".downsample.0.weight"] = (planes * exp, inpl, 1, 1)
+                _bn(spec, q + ".downsample.1", planes * exp)
+            inpl = planes * exp
+        enc_c.append(inpl)
+    ni = inpl                                        # 2048 / 512
+    _bn(spec, "layers.1", ni)
+    _spectral(spec, "layers.3.0.0", (ni * 2, ni, 3, 3)); _bn(spec, "layers.3.0.2", ni * 2)
+    _spectral(spec, "layers.3.1.0", (ni, ni * 2, 3, 3)); _bn(spec, "layers.3.1.2", ni)
+    skips = [enc_c[3], enc_c[2], enc_c[1], enc_c[0]]     # children 6,5,4,2
+    x_c = ni
+    for i, sc in enumerate(skips):
+        p = f"layers.{4 + i}"
+        final = i == 3
+        if deep:
+            up_out = x_c // 2
+            cat = up_out + sc
+            nf = int((cat if not final else cat // 2) * 1.5)
+        else:
+            n_out = 1024 if not final else 512           # nf = 512 * nf_factor(2)
+            up_out = nf = n_out // 2
+            cat = up_out + sc
+        _spectral(spec, p + ".shuf.conv.0", (up_out * 4, x_c, 1, 1)); _bn(spec, p + ".shuf.conv.1", up_out * 4)
+        _bn(spec, p + ".bn", sc)
+        convs = [("conv1", cat, nf), ("conv2", nf, nf)] if deep else [("conv", cat, nf)]
+        for name, ci, co in convs:
+            _spectral(spec, f"{p}.{name}.0", (co, ci, 3, 3)); _bn(spec, f"{p}.{name}.2", co)
+        if i == 1:                                       # sa = (i == len(sfs_idxs) - 3)
+            a = f"{p}.{convs[-1][0]}.3"
+            spec[a + ".gamma"] = (1,)
+            for nm, co in (("query", nf // 8), ("key", nf // 8), ("value", nf)):
+                _spectral(spec, f"{a}.{nm}", (co, nf, 1))
+        x_c = nf
+    spec["layers.8.conv.0.bias"] = (x_c * 4,)
+    spec["layers.8.conv.0.weight_g"] = (x_c * 4, 1, 1, 1)
+    spec["layers.8.conv.0.weight_v"] = (x_c * 4, x_c, 1, 1)
+    c = x_c + 3
+    _spectral(spec, "layers.10.layers.0.0", (c, c, 3, 3), bias=True)
+    _spectral(spec, "layers.10.layers.1.0", (c, c, 3, 3), bias=True)
+    _spectral(spec, "layers.11.0", (3, c, 1, 1), bias=True)
+    return spec
+
+
+def _rng(seed, name):
+    return np.random.default_rng([int(seed), zlib.crc32(name.encode())])
+
+
+def synth_state_dict(arch, seed=0):
+    spec = state_dict_spec(arch)
+    sd = OrderedDict()
+    for name, shape in spec.items():
+        r = _rng(seed, name)
+        leaf = name.rsplit(".", 1)[1]
+        if leaf == "num_batches_tracked":
+            sd[name] = np.array(1000, np.int64)
+        elif leaf == "gamma":
+            sd[name] = np.array([0.5], np.float32)
+        elif leaf == "weight" and len(shape) == 4:                       # encoder conv, He
+            fan_in = shape[1] * shape[2] * shape[3]
+            sd[name] = (r.standard_normal(shape) * np.sqrt(2.0 / fan_in)).astype(np.float32)
+        elif leaf in ("weight_orig", "weight_v") and len(shape) >= 3:    # spectral / weight-norm direction
+            fan_in = int(np.prod(shape[1:]))
+            final = name.startswith("layers.11.")
+            gain = (0.1 if arch == "deep" else 0.25) if final else np.sqrt(2.0)
+            wt = (r.standard_normal(shape) * gain / np.sqrt(fan_in)).astype(np.float32)
+            if final:                                   # zero-mean rows: the all-positive input offset cancels
+                wt -= wt.mean(axis=1, keepdims=True)
+            if leaf == "weight_orig":
+                sigma0 = np.float32(r.uniform(0.5, 2.0))
+                sd[name] = wt * sigma0
+                p = name[: -len(".weight_orig")]
+                v = _rng(seed, p + ".weight_v").standard_normal(fan_in).astype(np.float32)
+                v /= np.linalg.norm(v)
+                t = sd[name].reshape(shape[0], -1) @ v
+                sd[p + ".weight_v"] = v
+                sd[p + ".weight_u"] = (t * (sigma0 / np.dot(t, t))).astype(np.float32)   # u.(W v) = sigma0
+            else:                                                        # weight-norm: v = W_t * r_c, g = |W_t|
+                rc = r.uniform(0.5, 2.0, size=(shape[0],) + (1,) * (len(shape) - 1)).astype(np.float32)
+                sd[name] = wt * rc
+                p = name[: -len(".weight_v")]
+                sd[p + ".weight_g"] = np.sqrt((wt.reshape(shape[0], -1) ** 2).sum(1)).reshape(
+                    (shape[0],) + (1,) * (len(shape) - 1)).astype(np.float32)
+        elif leaf in ("weight_u", "weight_v", "weight_g"):
+            if name not in sd:
+                sd[name] = None                                          # filled by the matching weight_orig/_v
+        elif leaf == "bias" and (name[:-5] + ".running_mean") not in spec:   # conv bias
+            sd[name] = (r.standard_normal(shape) * 0.05).astype(np.float32)
+        else:                                                            # BatchNorm parameters
+            p = name.rsplit(".", 1)[0]
+            post_relu = p.endswith(".2") and not p.startswith("layers.0.")   # decoder conv -> ReLU -> BN
+            last_in_block = p.startswith("layers.0.") and (p.endswith(".bn3") or
+                                                            (arch == "deep" and p.endswith(".bn2")))
+            if leaf == "weight":
+                g = r.uniform(0.8, 1.2, shape)
+                sd[name] = (g * (0.15 if last_in_block else 1.0)).astype(np.float32)
+            elif leaf == "bias":
+                sd[name] = (r.standard_normal(shape) * 0.1).astype(np.float32)
+            elif leaf == "running_mean":
+                sd[name] = (r.standard_normal(shape) * 0.1 + (0.5 if post_relu else 0.0)).astype(np.float32)
+            elif leaf == "running_var":
+                sd[name] = (r.uniform(0.7, 1.3, shape) * (0.5 if post_relu else 1.0)).astype(np.float32)
+            else:
+                raise KeyError(name)
+    out = OrderedDict((k, sd[k]) for k in spec)          # reference order
+    assert all(v is not None for v in out.values())
+    return out
