@@ -72,3 +72,16 @@ def chroma_stabilizer(img_stable, img_new, alpha=0.15, weight=1.0):
     out[..., 2] = clip(yuv2[..., 2], v_dn, v_up)
     rgb = cvcolor.yuv2rgb_u8(out)
     return imaging.pil_blend(img_stable, rgb, weight) if weight < 1.0 else rgb
+
+
+def colorize_frame_fullsize(sds, modelname, frame_u8, render_factor, video_weight=0.5):
+    """HAVC_colorizer(method=0) per-frame flow on one full-size frame (vsdeoldify/__init__.py:2502-2523):
+    Spline64 squash to S x S -> ModelImageRender -> Spline64 back -> chroma_post_process vs the source
+    (vs_recover_clip_luma, vsslib/vsfilters.py:863-899).  The resampler is the harness stand-in (resample.py)."""
+    from . import resample
+    S = render_factor * 16
+    h, w, _ = frame_u8.shape
+    sq = frame_u8 if (w, h) == (S, S) else resample.resize_rgb8(frame_u8, S, S)
+    col = model_image_render(sds, modelname, sq, render_factor, video_weight, True)
+    up = col if (w, h) == (S, S) else resample.resize_rgb8(col, w, h)
+    return post_process(up, frame_u8)

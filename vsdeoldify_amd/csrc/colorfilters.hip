@@ -26,9 +26,15 @@ __device__ __forceinline__ void yuv2rgb(int y, int u, int v, int& r, int& g, int
     r = sat8(y + descale14(v * 18678));
 }
 
-// ---- PIL Image.blend(a, b, w): (UINT8)((int)a + w * ((int)b - (int)a)), float32, no FMA contraction ----
+// ---- PIL Image.blend(a, b, w): (UINT8)((int)a + w * ((int)b - (int)a)) in float32 with the product
+// ROUNDED before the add (Pillow's x86-64 build has no FMA).  HIP's __fmul_rn/__fadd_rn are plain operators
+// and hipcc contracts a + w*d into v_fma_f32 by default, so contraction is switched off explicitly here
+// (and the whole file is built with -ffp-contract=off). ----
 __device__ __forceinline__ uint8_t blend1(uint8_t a, uint8_t b, float w) {
-    return (uint8_t)(int)__fadd_rn((float)(int)a, __fmul_rn(w, (float)((int)b - (int)a)));
+#pragma clang fp contract(off)
+    const float prod = w * (float)((int)b - (int)a);
+    const float sum = (float)(int)a + prod;
+    return (uint8_t)(int)sum;
 }
 
 __global__ void blend_u8_kernel(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, float w,
