@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
     ap.add_argument("--clip-frames", type=int, default=16, help="distinct synthetic frames resident per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=32, help="threads for the CPU-oracle baseline leg")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,7 +153,7 @@ def main():
         got = np.empty((1, HEIGHT, WIDTH, 3), np.uint8)
         step(0)
         ctx.dev_download(got, off(d_dst, 0))
-        base, parity = cpu_baseline_and_parity(sds, frames[0], got[0], os.cpu_count() or 1)
+        base, parity = cpu_baseline_and_parity(sds, frames[0], got[0], min(os.cpu_count() or 1, args.cpu_threads))
         out["cpu_baseline"] = base
         out["parity"] = parity
     if dist is not None:

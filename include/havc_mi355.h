@@ -155,7 +155,7 @@ int havc_chroma_stabilizer(havc_ctx* ctx, const uint8_t* img_stable, const uint8
 /* ---- device-resident clip pipeline (bench + multi-GPU shard path) -----------------
  * One call colours n_frames 1080p-class frames that are ALREADY in HBM:
  *   d_src [n][h][w][3] u8 gray-as-RGB  -> Spline64 squash to S x S (harness stand-in for zimg,
- *   vsdeoldify/__init__.py:2504) -> havc_deoldify (video [+second], blend, YUV merge) -> Spline64 back to
+ *   vsdeoldify/__init__.py:2504) -> DeOldify passes (video [+second], blend, YUV merge) -> Spline64 back to
  *   w x h (__init__.py:3547) -> chroma_post_process with the source luma (vsfilters.py:863-899) -> d_dst.
  * Frames are processed in batches of the nets' max_batch. */
 int havc_colorize_clip(havc_ctx* ctx, havc_net* video, havc_net* second, float video_weight, const uint8_t* d_src,

@@ -1,0 +1,152 @@
+"""CPU (-m "not gpu"): host-side logic — C ABI surface, struct layout, weight folding/packing, plan emission,
+frame sharding and the world_size-2 timing protocol on gloo."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests.conftest import ROOT
+from vsdeoldify_amd import _native as nat
+from vsdeoldify_amd import plan as P
+from vsdeoldify_amd.sharded import gather_order, shard_frames
+from vsdeoldify_amd.synth import synth_state_dict
+
+HEADER = os.path.join(ROOT, "include", "havc_mi355.h")
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = nat.load()
+    declared = set(re.findall(r"\b(havc_[a-z0-9_]+)\s*\(", open(HEADER).read()))
+    bound = {n for n, _, _ in nat.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.havc_version().decode().startswith("havc_mi355")
+
+
+def test_no_device_fails_loudly():
+    lib = nat.load()
+    if lib.havc_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    with pytest.raises(nat.NativeLibraryError):
+        nat.Context(0)
+    from vsdeoldify_amd.render import ModelImageRender
+    with pytest.raises(nat.NativeLibraryError):            # no CPU fallback, device_index=99 refused as well
+        ModelImageRender(None, "video", 2, 0.0, device_index=99, state_dicts={})
+
+
+def test_op_struct_layout_matches_c(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "havc_mi355.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+                   "sizeof(havc_op),offsetof(havc_op,w_off),offsetof(havc_op,f0),offsetof(havc_op,flops),offsetof(havc_op,tag),"
+                   "sizeof(havc_buf));return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    d = nat.OP_DTYPE
+    assert got == [d.itemsize, d.fields["w_off"][1], d.fields["f0"][1], d.fields["flops"][1], d.fields["tag"][1],
+                   nat.BUF_DTYPE.itemsize]
+
+
+def test_norm_folds_match_oracle():
+    from oracle import unet as ou
+    sd = synth_state_dict("deep", 4)
+    tsd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+    for p in ("layers.3.0.0", "layers.10.layers.0.0", "layers.11.0"):
+        assert np.abs(P.fold_spectral(sd, p) - ou.fold_spectral(tsd, p).numpy()).max() < 1e-6
+        assert abs(float(np.dot(sd[p + ".weight_u"], sd[p + ".weight_orig"].reshape(len(sd[p + ".weight_u"]), -1) @ sd[p + ".weight_v"])) - 1) > 1e-2, \
+            "synthetic sigma must not be 1 (the fold would be untested)"
+    assert np.abs(P.fold_weightnorm(sd, "layers.8.conv.0") - ou.fold_weightnorm(tsd, "layers.8.conv.0").numpy()).max() < 1e-6
+
+
+def test_pack_conv_layout():
+    r = np.random.default_rng(0)
+    W = r.standard_normal((5, 11, 3, 3)).astype(np.float32)
+    cmap = np.concatenate([np.arange(6), 8 + np.arange(5)])            # two concatenated segments 6 | 5 in a 16-wide span
+    pack = P.WeightPack()
+    pc = P.pack_conv(pack, W, cmap, 16, bias=np.arange(5, dtype=np.float32))
+    blob = pack.blob()
+    assert pc.Npad == 16 and pc.Kc == 20 and pc.Ci == 16            # K = 9 taps * 2 chunks = 18 -> padded to 20
+    flat = np.frombuffer(blob, np.float16, pc.Npad * pc.Kc * 8, pc.w_off).reshape(16, 20 * 8)
+    Wt = flat[:, :9 * 16].reshape(16, 3, 3, 16).astype(np.float32)
+    assert np.allclose(Wt[:5][..., cmap], W.transpose(0, 2, 3, 1), atol=2e-3)
+    assert (Wt[5:] == 0).all() and (flat[:, 9 * 16:] == 0).all() and (Wt[:5][..., [6, 7, 13, 14, 15]] == 0).all()
+    bias = np.frombuffer(blob, np.float32, 16, pc.bias_off)
+    assert (bias[:5] == np.arange(5)).all() and (bias[5:] == 0).all()
+    # pixel-shuffle row order: packed row q*cps + c <- original row c*4 + q
+    W2 = r.standard_normal((32, 8, 1, 1)).astype(np.float32)
+    pc2 = P.pack_conv(pack, W2, np.arange(8), 8, pixshuf=True)
+    f2 = np.frombuffer(pack.blob(), np.float16, 32 * 4 * 8, pc2.w_off).reshape(32, 32)[:, :8].astype(np.float32)
+    for q in range(4):
+        for c in range(8):
+            assert np.allclose(f2[q * 8 + c], W2[c * 4 + q, :, 0, 0], atol=2e-3)
+
+
+@pytest.mark.parametrize("arch,gflop", [("wide", {256: 282.49, 384: 639.00, 512: 1144.46, 560: 1379.66}),
+                                        ("deep", {560: 1915.05})])
+def test_plan_flops_match_survey(arch, gflop):
+    """the plan's algorithmic FLOPs per pass reproduce SURVEY.md §8a-T1 (conv + attention bmm, 2*MAC)."""
+    from vsdeoldify_amd.deoldify_net import DeoldifyGenerator
+    gen = DeoldifyGenerator(synth_state_dict(arch, 0), arch)
+    for S, want in gflop.items():
+        ops, bufs, i, o, names = gen.plan(S)
+        assert abs(ops["flops"].sum() / 1e9 - want) < 0.01, (S, ops["flops"].sum() / 1e9)
+        assert len(names) == len(ops) and bufs["elem_bytes"][i] == 1 and bufs["elem_bytes"][o] == 1
+        for op in ops:                                            # every buffer id / weight offset in range
+            assert -1 <= op["src2"] < len(bufs) and 0 <= op["src"] < len(bufs) and 0 <= op["dst"] < len(bufs)
+            for f in ("w_off", "bias_off", "scale_off", "shift_off"):
+                assert op[f] == -1 or (0 <= op[f] < len(gen.blob) and op[f] % 16 == 0)
+    # odd render size (S/16 odd) keeps the 35 vs 36 mismatch the nearest resize has to absorb
+    ops = gen.plan(560)[0]
+    blur = [op for op in ops if op["type"] == nat.OP_BLUR_RESIZE]
+    assert any(op["Hi"] == 36 and op["Ho"] == 35 for op in blur)
+
+
+def test_shard_frames_partition():
+    for n, g in ((64, 8), (10, 4), (3, 8), (0, 2)):
+        shards = [shard_frames(n, r, g) for r in range(g)]
+        assert sorted(sum(shards, [])) == list(range(n))
+        order = gather_order(n, g)
+        assert all(shards[r][i] == k for k, (r, i) in enumerate(order))
+    with pytest.raises(ValueError):
+        shard_frames(4, 2, 2)
+
+
+WORKER = r"""
+import os, sys, time
+sys.path.insert(0, {root!r})
+import torch
+from vsdeoldify_amd.sharded import env_rank, init_dist, shard_frames, timed_steps
+rank, local, world = env_rank()
+dist = init_dist("gloo", local)
+mine = shard_frames(12, rank, world)
+done = []
+def step(i):
+    time.sleep(0.01 * (rank + 1))           # rank 1 is slower: MAX over ranks must report ITS time
+    done.append(mine[i % len(mine)])
+el = timed_steps(step, 4, 1, lambda: None, dist)
+t = torch.tensor([float(len(done))]); dist.all_reduce(t)
+if rank == 0:
+    print("RESULT", el, t.item())
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_timing_protocol_gloo(tmp_path):
+    """N>1 path on CPU: 2 processes, gloo, barrier-bracketed timing, MAX over ranks, disjoint shards."""
+    script = tmp_path / "w.py"
+    script.write_text(WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    line = [l for l in outs[0][0].splitlines() if l.startswith("RESULT")][0].split()
+    elapsed, total = float(line[1]), float(line[2])
+    assert total == 10.0                       # (1 warm-up + 4 timed) x 2 ranks
+    assert 0.075 <= elapsed < 1.0              # >= 4 x 20 ms of the slow rank (max over ranks), not rank 0's 40 ms

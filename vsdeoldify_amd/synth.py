@@ -104,7 +104,18 @@ def _rng(seed, name):
     return np.random.default_rng([int(seed), zlib.crc32(name.encode())])
 
 
+_CACHE = {}
+
+
 def synth_state_dict(arch, seed=0):
+    """Deterministic in (arch, seed); cached per process (callers must treat the arrays as read-only)."""
+    key = (arch, int(seed))
+    if key not in _CACHE:
+        _CACHE[key] = _synth_state_dict(arch, int(seed))
+    return _CACHE[key]
+
+
+def _synth_state_dict(arch, seed=0):
     spec = state_dict_spec(arch)
     sd = OrderedDict()
     for name, shape in spec.items():
