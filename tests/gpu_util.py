@@ -14,9 +14,10 @@ def nhwc_pad(x_nchw, span=None):
     return out
 
 
-def run_plan(ctx, pack, b, uploads, downloads, batch):
+def run_plan(ctx, pack, b, uploads, downloads, batch, cfg=0):
     """uploads: {buf: ndarray}; downloads: {buf: (shape, dtype)} -> {buf: ndarray}."""
     ops, bufs = b.finish()
+    ops["reserved"] = cfg
     w = nat.Weights(ctx, pack.blob() or b"\0" * 256)
     net = nat.Net(ctx, w, ops, bufs, 0, 0, 0, batch)
     try:
@@ -29,7 +30,7 @@ def run_plan(ctx, pack, b, uploads, downloads, batch):
         w.close()
 
 
-def conv_op(ctx, x, W, bias=None, scale=None, shift=None, stride=1, pad=0, dil=1, flags=0, res=None, pixshuf=False):
+def conv_op(ctx, x, W, bias=None, scale=None, shift=None, stride=1, pad=0, dil=1, flags=0, res=None, pixshuf=False, cfg=0):
     """x [B,Cin,H,W] float, W [Cout,Cin,kh,kw] -> fp16 NHWC output (float32 NCHW returned) via OP_CONV."""
     B, Cin, H, Wd = x.shape
     pack, b = WeightPack(), PlanBuilder()
@@ -50,5 +51,5 @@ def conv_op(ctx, x, W, bias=None, scale=None, shift=None, stride=1, pad=0, dil=1
         ups[rv.buf] = nhwc_pad(res)
         flags |= nat.F_RESIDUAL
     b.conv("t", pc, xv, yv, stride=stride, pad=pad, dil=dil, flags=flags, res=rv)
-    out = run_plan(ctx, pack, b, ups, {yv.buf: ((B, yv.H, yv.W, yv.span), np.float16)}, B)[yv.buf]
+    out = run_plan(ctx, pack, b, ups, {yv.buf: ((B, yv.H, yv.W, yv.span), np.float16)}, B, cfg)[yv.buf]
     return out.astype(np.float32)[..., :yv.C].transpose(0, 3, 1, 2), out

@@ -71,8 +71,8 @@ def test_pack_conv_layout():
     pack = P.WeightPack()
     pc = P.pack_conv(pack, W, cmap, 16, bias=np.arange(5, dtype=np.float32))
     blob = pack.blob()
-    assert pc.Npad == 16 and pc.Kc == 20 and pc.Ci == 16            # K = 9 taps * 2 chunks = 18 -> padded to 20
-    flat = np.frombuffer(blob, np.float16, pc.Npad * pc.Kc * 8, pc.w_off).reshape(16, 20 * 8)
+    assert pc.Npad == 16 and pc.Kc == 24 and pc.Ci == 16            # K = 9 taps * 2 chunks = 18 -> padded to 24
+    flat = np.frombuffer(blob, np.float16, pc.Npad * pc.Kc * 8, pc.w_off).reshape(16, 24 * 8)
     Wt = flat[:, :9 * 16].reshape(16, 3, 3, 16).astype(np.float32)
     assert np.allclose(Wt[:5][..., cmap], W.transpose(0, 2, 3, 1), atol=2e-3)
     assert (Wt[5:] == 0).all() and (flat[:, 9 * 16:] == 0).all() and (Wt[:5][..., [6, 7, 13, 14, 15]] == 0).all()
@@ -81,7 +81,7 @@ def test_pack_conv_layout():
     # pixel-shuffle row order: packed row q*cps + c <- original row c*4 + q
     W2 = r.standard_normal((32, 8, 1, 1)).astype(np.float32)
     pc2 = P.pack_conv(pack, W2, np.arange(8), 8, pixshuf=True)
-    f2 = np.frombuffer(pack.blob(), np.float16, 32 * 4 * 8, pc2.w_off).reshape(32, 32)[:, :8].astype(np.float32)
+    f2 = np.frombuffer(pack.blob(), np.float16, 32 * 8 * 8, pc2.w_off).reshape(32, 64)[:, :8].astype(np.float32)
     for q in range(4):
         for c in range(8):
             assert np.allclose(f2[q * 8 + c], W2[c * 4 + q, :, 0, 0], atol=2e-3)

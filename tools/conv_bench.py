@@ -1,0 +1,70 @@
+"""Micro-benchmark of the implicit-GEMM conv kernel on the hot shapes.  Usage (GPU box):
+   python tools/conv_bench.py [batch] [reps] [shape-filter]
+Each shape is a 1-op plan run through the C ABI; time = HIP events around the op (havc_net_profile)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from vsdeoldify_amd import _native as nat
+from vsdeoldify_amd.plan import PlanBuilder, WeightPack, pack_conv
+from vsdeoldify_amd.render import get_context
+
+SHAPES = {  # name: (Cin, Cout, k, stride, pad, H, W, flags)
+    "tail259": (259, 259, 3, 1, 1, 560, 560, nat.F_RELU_PRE),
+    "tail256": (256, 256, 3, 1, 1, 560, 560, nat.F_RELU_PRE),
+    "l7conv": (320, 256, 3, 1, 1, 280, 280, nat.F_RELU_PRE | nat.F_AFFINE),
+    "l6conv": (768, 512, 3, 1, 1, 140, 140, nat.F_RELU_PRE | nat.F_AFFINE),
+    "l5conv": (1024, 512, 3, 1, 1, 70, 70, nat.F_RELU_PRE | nat.F_AFFINE),
+    "l4conv": (1536, 512, 3, 1, 1, 35, 35, nat.F_RELU_PRE | nat.F_AFFINE),
+    "mid0": (2048, 4096, 3, 1, 1, 18, 18, nat.F_RELU_PRE | nat.F_AFFINE),
+    "mid1": (4096, 2048, 3, 1, 1, 18, 18, nat.F_RELU_PRE | nat.F_AFFINE),
+    "l8ps": (256, 1024, 1, 1, 0, 280, 280, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),
+    "l7ps": (512, 1024, 1, 1, 0, 140, 140, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),
+    "enc3x3_35": (256, 256, 3, 1, 1, 35, 35, nat.F_RELU_PRE),
+    "enc1x1_35": (1024, 256, 1, 1, 0, 35, 35, nat.F_RELU_PRE),
+    "enc3x3_140": (64, 64, 3, 1, 1, 140, 140, nat.F_RELU_PRE),
+}
+
+
+def bench(ctx, name, batch, reps, cfg=0):
+    Cin, Cout, k, s, p, H, W, flags = SHAPES[name]
+    r = np.random.default_rng(0)
+    pack, b = WeightPack(), PlanBuilder()
+    x = b.tensor(H, W, Cin)
+    Wt = (r.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    kw = dict(bias=r.standard_normal(Cout).astype(np.float32))
+    if flags & nat.F_AFFINE:
+        kw.update(scale=np.ones(Cout, np.float32), shift=np.zeros(Cout, np.float32))
+    pc = pack_conv(pack, Wt, x.cmap, x.span, pixshuf=bool(flags & nat.F_OUT_PIXSHUF), **kw)
+    Ho = (H + 2 * p - k) // s + 1
+    y = b.tensor(2 * Ho, 2 * Ho, Cout // 4) if flags & nat.F_OUT_PIXSHUF else b.tensor(Ho, Ho, Cout)
+    b.conv(name, pc, x, y, stride=s, pad=p, flags=flags)
+    ops, bufs = b.finish()
+    ops["reserved"] = cfg
+    w = nat.Weights(ctx, pack.blob())
+    net = nat.Net(ctx, w, ops, bufs, 0, 0, 0, batch)
+    xin = (r.standard_normal((batch, H, W, x.span)) * 0.5).astype(np.float16)
+    xin[..., Cin:] = 0
+    net.upload(x.buf, xin)
+    for _ in range(2):
+        net.profile(batch)
+    ms = float(np.median([net.profile(batch)[0] for _ in range(reps)]))
+    fl = float(ops["flops"][0]) * batch
+    net.close(); w.close()
+    return ms, fl / ms / 1e9
+
+
+if __name__ == "__main__":
+    batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    filt = sys.argv[3] if len(sys.argv) > 3 else ""
+    cfgs = [int(c) for c in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
+    ctx = get_context(0)
+    for name in SHAPES:
+        if filt and filt not in name:
+            continue
+        for cfg in cfgs:
+            try:
+                ms, tf = bench(ctx, name, batch, reps, cfg)
+                print(f"{name:12s} cfg={cfg} batch={batch}: {ms:8.3f} ms  {tf:8.1f} TFLOP/s", flush=True)
+            except Exception as e:
+                print(f"{name:12s} cfg={cfg}: {type(e).__name__}: {e}", flush=True)

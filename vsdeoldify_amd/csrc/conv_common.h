@@ -1,0 +1,89 @@
+// Shared device helpers of the LDS-DMA convolution kernels (conv_igemm_glds.hip, conv_igemm_pipe.hip).
+#pragma once
+#include "kernels.h"
+#include "../../include/havc_mi355.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+// 16 bytes of zeros: LDS-DMA lanes that fall on padding / M tail / K tail fetch these (no per-lane zero fill in DMA)
+static __device__ __attribute__((aligned(16))) unsigned int havc_zero_page[4] = {0, 0, 0, 0};
+
+__device__ __forceinline__ int swz2(int row) { return (4 - ((row >> 2) & 3)) & 3; }
+
+__device__ __forceinline__ void glds16(const void* g, half_t* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// one 16x16 accumulator fragment -> fused epilogue -> store.  lane owns pixel m, channels n..n+3.
+__device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v acc, int m, int n, int HoWo) {
+    if (m >= p.M || n >= p.Npad) return;
+    const bool leaky = p.flags & HAVC_F_LEAKY;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r];
+    if (p.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    }
+    if (p.flags & HAVC_F_OUT_RGB8) {
+        if (n == 0) {
+            uint8_t* y = reinterpret_cast<uint8_t*>(p.y) + (int64_t)m * 3;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float s = 1.f / (1.f + __expf(-v[r]));
+                s = s * (p.f1 - p.f0) + p.f0;
+                s = s * p.istd[r] + p.mean[r];
+                s = fminf(fmaxf(s, 0.f), 1.f);
+                y[r] = (uint8_t)(int)(s * 255.f);
+            }
+        }
+        return;
+    }
+    if (p.flags & HAVC_F_RELU_PRE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : (leaky ? v[r] * p.f2 : 0.f);
+    }
+    if (p.flags & HAVC_F_AFFINE) {
+        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
+        const float4 sh = *reinterpret_cast<const float4*>(p.shift + n);
+        v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
+        v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+    }
+    if (p.flags & HAVC_F_OUT_PIXSHUF) {
+        const int q = n / p.Co, c = n - q * p.Co;
+        if (q >= 4) return;
+        const int b = m / HoWo, rem = m - b * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int64_t pix = (int64_t)(b * 2 * p.Ho + 2 * ho + (q >> 1)) * (2 * p.Wo) + 2 * wo + (q & 1);
+        half4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+        *reinterpret_cast<half4*>(reinterpret_cast<half_t*>(p.y) + pix * p.y_cpitch + p.y_coff + c) = o;
+        return;
+    }
+    if (n >= p.Co) return;
+    if (p.flags & HAVC_F_RESIDUAL) {
+        const half4 rv = *reinterpret_cast<const half4*>(p.res + (int64_t)m * p.res_cpitch + p.res_coff + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+    }
+    if (p.flags & HAVC_F_RELU_POST) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : (leaky ? v[r] * p.f2 : 0.f);
+    }
+    half_t* y = reinterpret_cast<half_t*>(p.y);
+    if (p.flags & HAVC_F_OUT_TRANSPOSED) {
+        const int b = m / HoWo;
+        const int64_t base = (int64_t)b * p.Co * p.pix_pitch + (m - b * HoWo);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) y[base + (int64_t)(n + r) * p.pix_pitch] = (half_t)v[r];
+    } else {
+        half4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
+        *reinterpret_cast<half4*>(y + (int64_t)m * p.y_cpitch + p.y_coff + n) = o;
+    }
+}
+

@@ -266,7 +266,9 @@ const char* conv_config_name(const ConvArgs& a) {
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {
-    switch (pick_config(a)) {
+    if (a.cfg >= 60) return launch_conv_pipe(a, a.cfg, s);
+    if (a.cfg >= 16) return launch_conv_glds(a, a.cfg, s);
+    switch (a.cfg > 0 ? a.cfg - 1 : pick_config(a)) {
         case CFG_128x128: return launch_cfg<128, 128, 2, 2>(a, s);
         case CFG_128x64: return launch_cfg<128, 64, 2, 2>(a, s);
         case CFG_64x64: return launch_cfg<64, 64, 2, 2>(a, s);

@@ -199,6 +199,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             a.flags = op.flags;
             a.pix_pitch = op.aux0;
             a.f0 = op.f0; a.f1 = op.f1; a.f2 = op.f2;
+            a.cfg = op.reserved;
             const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
             for (int i = 0; i < 3; ++i) { a.mean[i] = mean[i]; a.istd[i] = stdv[i]; }
             if (!a.w || (op.Kc & 3) || a.C8 <= 0) return fail(c, HAVC_E_INVALID, "conv op: bad weights / Kc / Ci");

@@ -25,10 +25,13 @@ struct ConvArgs {
     int pix_pitch;         // transposed store: elements per channel row
     float f0, f1, f2;      // sigmoid range lo/hi, leaky slope
     float mean[3], istd[3];
+    int cfg;               // 0 = heuristic; otherwise forced tile configuration (tools/conv_bench.py A/B runs)
 };
 
 // returns hipError_t as int
 int launch_conv(const ConvArgs& a, hipStream_t s);
+int launch_conv_glds(const ConvArgs& a, int cfg, hipStream_t s);
+int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s);
 const char* conv_config_name(const ConvArgs& a);
 
 int launch_maxpool3x3s2(const half_t* x, half_t* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int x_cpitch,

@@ -141,7 +141,7 @@ def pack_conv(pack, W, cmap, Ci, bias=None, scale=None, shift=None, pixshuf=Fals
         scale = None if scale is None else scale[perm]
         shift = None if shift is None else shift[perm]
     K = KH * KW * Ci // 8
-    Kc = pad_to(K, 4)
+    Kc = pad_to(K, 8)          # 64-deep K-steps (two 32-deep sub-tiles) in the ring kernels
     flat = np.zeros((Npad, Kc * 8), np.float16)
     flat[:, :K * 8] = Wt.reshape(Npad, -1).astype(np.float16)
     return PackedConv(pack.add(flat), -1 if bias is None else pack.add(bias), -1 if scale is None else pack.add(scale),
