@@ -44,12 +44,13 @@ def conv_op(ctx, x, W, bias=None, scale=None, shift=None, stride=1, pad=0, dil=1
         yv = b.tensor(2 * Ho, 2 * Wo, W.shape[0] // 4)
     else:
         yv = b.tensor(Ho, Wo, W.shape[0])
-    ups = {xv.buf: nhwc_pad(x)}
+    ups = {xv.buf: nhwc_pad(x, xv.cpitch)}
     rv = None
     if res is not None:
         rv = b.tensor(Ho, Wo, W.shape[0])
-        ups[rv.buf] = nhwc_pad(res)
+        ups[rv.buf] = nhwc_pad(res, rv.cpitch)
         flags |= nat.F_RESIDUAL
     b.conv("t", pc, xv, yv, stride=stride, pad=pad, dil=dil, flags=flags, res=rv)
-    out = run_plan(ctx, pack, b, ups, {yv.buf: ((B, yv.H, yv.W, yv.span), np.float16)}, B, cfg)[yv.buf]
+    out = run_plan(ctx, pack, b, ups, {yv.buf: ((B, yv.H, yv.W, yv.cpitch), np.float16)}, B, cfg)[yv.buf]
+    out = out[..., :yv.span]
     return out.astype(np.float32)[..., :yv.C].transpose(0, 3, 1, 2), out

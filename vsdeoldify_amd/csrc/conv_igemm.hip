@@ -53,48 +53,38 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     const int HoWo = p.Ho * p.Wo;
     const int j = tid & 3;
     // ---- per-thread im2col row state -----------------------------------------------------------
-    int a_pix[A_IT], a_hi0[A_IT], a_wi0[A_IT];
-    bool a_ok[A_IT];
+    int64_t a_base[A_IT];
+    int a_hi0[A_IT], a_wi0[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
         const int row = (tid >> 2) + it * 64;
         const int m = m0 + row;
-        a_ok[it] = m < p.M;
-        const int mm = a_ok[it] ? m : 0;
+        const bool okm = m < p.M;
+        const int mm = okm ? m : 0;
         const int b = mm / HoWo;
         const int rem = mm - b * HoWo;
         const int ho = rem / p.Wo;
         const int wo = rem - ho * p.Wo;
-        a_hi0[it] = ho * p.stride - p.pad;
-        a_wi0[it] = wo * p.stride - p.pad;
-        a_pix[it] = b * p.Hi * p.Wi;
-    }
-    int kc8 = j, kkh = 0, kkw = 0;  // this thread's current (cin chunk, tap)
-    while (kc8 >= p.C8) {
-        kc8 -= p.C8;
-        if (++kkw == p.kw) { kkw = 0; ++kkh; }
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        a_hi0[it] = okm ? hi0 : -(1 << 20);          // rows past M never pass the bounds test
+        a_wi0[it] = wi0;
+        a_base[it] = ((int64_t)(b * p.Hi * p.Wi) + (int64_t)hi0 * p.Wi + wi0) * p.x_cpitch + p.x_coff;
     }
 
     uint4 a_reg[A_IT], b_reg[B_IT];
     const int KT = p.Kc >> 2;
 
     auto load_tiles = [&](int kt) {
+        const int2 e = p.ktab[kt * 4 + j];               // this lane's K chunk: (tap displacement, byte offset)
+        const int dh = (short)(e.y & 0xffff), dw = e.y >> 16;
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int hi = a_hi0[it] + kkh * p.dil;
-            const int wi = a_wi0[it] + kkw * p.dil;
-            const bool ok = a_ok[it] && kkh < p.kh && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+            const int hi = a_hi0[it] + dh;
+            const int wi = a_wi0[it] + dw;
+            const bool ok = (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
             uint4 v = make_uint4(0, 0, 0, 0);
-            if (ok) {
-                const int64_t off = (int64_t)(a_pix[it] + hi * p.Wi + wi) * p.x_cpitch + p.x_coff + kc8 * 8;
-                v = *reinterpret_cast<const uint4*>(p.x + off);
-            }
+            if (ok) v = *reinterpret_cast<const uint4*>(p.x + (a_base[it] + (e.x >> 1)));
             a_reg[it] = v;
-        }
-        kc8 += 4;
-        while (kc8 >= p.C8) {
-            kc8 -= p.C8;
-            if (++kkw == p.kw) { kkw = 0; ++kkh; }
         }
 #pragma unroll
         for (int it = 0; it < B_IT; ++it) {
@@ -260,14 +250,31 @@ static int pick_config(const ConvArgs& a) {
     return CFG_64x64;
 }
 
+bool conv_pipe_supported(const ConvArgs& a, int extra);
+
+// 0 = register-staged kernels below; 60 / 61 = software-pipelined 256x256 kernel (conv_igemm_pipe.hip)
+static int pick_pipe(const ConvArgs& a) {
+    if (a.flags & HAVC_F_OUT_RGB8) return 0;
+    const int extra = (a.Npad % 256 == 16) ? 1 : 0;
+    if (a.Npad < 256 || (a.Npad % 256 != 0 && !extra)) return 0;
+    if (!conv_pipe_supported(a, extra)) return 0;
+    const int64_t blocks = (int64_t)((a.M + 255) / 256) * ((a.Npad - 16 * extra) / 256);
+    if (blocks < 160) return 0;                       // too few 256x256 tiles to fill 256 CUs: smaller tiles win
+    return 60 + extra;
+}
+
 const char* conv_config_name(const ConvArgs& a) {
+    if (pick_pipe(a)) return pick_pipe(a) == 61 ? "pipe256x272" : "pipe256x256";
     static const char* names[] = {"128x128", "128x64", "64x64", "128x272", "128x304", "128x16", "64x128"};
     return names[pick_config(a)];
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {
     if (a.cfg >= 60) return launch_conv_pipe(a, a.cfg, s);
-    if (a.cfg >= 16) return launch_conv_glds(a, a.cfg, s);
+    if (a.cfg == 0) {
+        const int pc = pick_pipe(a);
+        if (pc) return launch_conv_pipe(a, pc, s);
+    }
     switch (a.cfg > 0 ? a.cfg - 1 : pick_config(a)) {
         case CFG_128x128: return launch_cfg<128, 128, 2, 2>(a, s);
         case CFG_128x64: return launch_cfg<128, 64, 2, 2>(a, s);

@@ -1,44 +1,54 @@
-// Implicit-GEMM convolution, software-pipelined main loop (the kernel the big decoder convs run on).
+// Implicit-GEMM convolution, software-pipelined main loop: the kernel the big decoder convs run on.
 //
-// Why: PMC + ablation of the ring kernel (profiles/r1_conv_ablation.txt) showed MFMA time (0.72 ms) and
-// everything else (im2col address generation + LDS-DMA issue 0.47 ms, fragment reads 0.17 ms, barrier 0.22 ms,
-// epilogue) adding up with ZERO overlap: a wave issues in order, and the compiler clustered all address VALU and
-// ds_reads ahead of the 32-MFMA block, so the matrix pipe idled 60 % of the time (MfmaUtil 38 %).
+// History in profiles/r1_conv_ablation.txt.  What the measurements forced:
+//  * a wave issues in order: address VALU / ds_read / LDS-DMA issue must be INTERLEAVED with the MFMAs in program
+//    order or they add to the matrix time instead of hiding under it (ring kernels: MfmaUtil 38 %, zero overlap);
+//  * LDS-DMA moves 64-byte row segments at 3.65 TB/s chip-wide but 128-byte segments at 8.5 TB/s, and a row pitch that
+//    is not a multiple of 128 B halves it again  =>  K-step 64 with ONE 128-byte line per tile row per stage, channel
+//    pitch of every activation buffer a multiple of 64 (plan.py), K ordered so a stage never straddles a tap.
 //
-// Structure: 256 x 256 block tile (L1/TA traffic per flop halves vs 128^2: the vector-memory path is 64 B/clk/CU),
-// 8 waves as 2(M) x 4(N), wave tile 128 x 64, K-step 64 = two 32-deep sub-tiles, 2-stage LDS double buffer
-// (128 KiB), ONE barrier per 64-deep step.  The body of a stage is 16 "steps" of 4 MFMAs; between the MFMA groups
-// each step carries one slice of the next stage's work, pinned in place with sched_barrier:
-//   * ds_read of the A fragment two steps ahead (3-deep register ring; B fragments of the next sub-tile
-//     are prefetched in the second half of a sub-tile),
-//   * one 1-KiB LDS-DMA piece of the NEXT stage (branch-free im2col address: per-lane incremental k-state,
-//     out-of-image / K-tail lanes read a zero page),
-// so address VALU, LDS latency and DMA issue all sit in the shadow of the matrix pipe.
-// EXTRA = 1: 16 extra output columns (the 259-channel tail, Npad = 256 + 16) as 2 more MFMAs per wave per sub-tile.
+// Structure: 256 x 256 block tile, 8 waves as 2 (M) x 4 (N), wave tile 128 x 64, K-step 64, 2-stage LDS double buffer
+// (2 x 64 KiB), ONE barrier per stage.  A stage is 16 steps of 4 MFMAs (v_mfma_f32_16x16x32_f16); each step also
+// carries, pinned with sched_barrier: the ds_read of the pixel fragment two steps ahead (3-deep register ring), a weight
+// fragment of the second K half, and one 1-KiB LDS-DMA piece (8 rows x 128 B) of the NEXT stage.
+// LDS-DMA = buffer_load_dwordx4 ... lds through buffer descriptors: lanes on padding / M tail / K tail / N tail use an
+// out-of-range offset and the hardware writes zeros (no zero page, no 64-bit pointer math, no branches).
+// The im2col geometry comes from a host-built per-chunk table (ConvArgs::ktab), so stride, dilation, any channel count
+// and split K orderings need no per-lane state machine.
+// LDS rows are 128 B = 8 chunks; chunk c of row r sits at position c ^ ((r >> 1) & 7): conflict-free for the
+// ds_read_b128 lane groups when 16 consecutive rows read chunk (ks*4 + lane>>4).  DMA writes are lane-linear, so the
+// involution is applied to the SOURCE chunk each DMA lane fetches.
+// EXTRA = 1: 16 extra output columns (the 259-channel tail: Npad = 256 + 16) as 2 more MFMAs per wave per K half.
 #include "conv_common.h"
 #include <type_traits>
 
 namespace {
 
-constexpr int BM = 256, BN = 256, NW = 8;   // 8 waves as 2 (M) x 4 (N)
-constexpr int FM = 8, FN = 4;            // 16-row / 16-col fragments per wave
-constexpr int KSUB = 2;
+constexpr int BM = 256, BN = 256, NW = 8;     // 8 waves as 2 (M) x 4 (N)
+constexpr int FM = 8, FN = 4;                 // 16-pixel / 16-channel fragments per wave
+constexpr unsigned OOB = 0xF0000000u;         // voffset beyond every descriptor range -> DMA writes zeros
 
 template <int EXTRA>
 struct Geo {
-    static constexpr int BNX = BN + 16 * EXTRA;
-    static constexpr int SUB = (BM + BNX) * 32;      // halfs per 32-deep sub-tile
-    static constexpr int STAGE = SUB * KSUB;
-    static constexpr int LDS_BYTES = 2 * STAGE * 2;
+    static constexpr int ROWS = BM + BN + 16 * EXTRA;
+    static constexpr int STAGE_BYTES = ROWS * 128;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
 };
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voff, soff, 0, 0);
+}
 
 }  // namespace
 
-// ABL (profiling only, wrong results): 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no MFMA, 5 = no epilogue stores
+// ABL (profiling only, wrong results): 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no MFMA, 5 = no epilogue
+// (Tried and dropped: staggering the DMA slots of the two waves sharing a SIMD -- 3-12 % slower, profiles/r1_conv_ablation.txt.)
 template <int EXTRA, int ABL = 0>
 __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
     using G = Geo<EXTRA>;
-    extern __shared__ __attribute__((aligned(16))) half_t smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -56,20 +66,21 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
     const int m0 = (pid / NT) * BM;
     const int n0 = (pid % NT) * BN;
     const bool has_extra = EXTRA && (n0 + BN + 16 == p.Npad);
-
     const int HoWo = p.Ho * p.Wo;
-    // ---- DMA lane role (see conv_igemm_glds.hip): piece row lane>>2, LDS position lane&3, source chunk j ----
-    const int prow = lane >> 2;
-    const int j = (lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3);
-    const half_t* zero = reinterpret_cast<const half_t*>(havc_zero_page);
 
-    // A rows owned by this lane: pieces `wave` and `wave + 8` of the 16 A pieces
-    const half_t* a_ptr[2];
-    int64_t a_zoff[2];                               // (zero page - a_ptr) in halfs: select an OFFSET, not a pointer,
-    int a_hi0[2], a_wi0[2];                          // so the bounds test compiles to v_cndmask instead of a branch
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.w), 0, p.w_bytes, 0x00020000);
+
+    // ---- DMA lane role: row lane>>3 of an 8-row piece, LDS position lane&7, source chunk c = pos ^ f(row) ----
+    // wave w owns pieces w, w+8, w+16, w+24 (same parity => same f) of both the pixel and the weight tile.
+    const int r8 = lane >> 3;
+    const int c = (lane & 7) ^ ((((wave & 1) << 2) + (r8 >> 1)) & 7);
+
+    unsigned a_base[4];      // byte offset of (pixel row, tap 0, channel 0) in the input buffer (wraps when hi0/wi0 < 0)
+    int a_hw0[4];            // hi0 | wi0 << 16 (signed 16-bit each)
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int row = (wave + it * NW) * 16 + prow;
+    for (int it = 0; it < 4; ++it) {
+        const int row = (wave + it * NW) * 8 + r8;
         const int m = m0 + row;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
@@ -77,55 +88,35 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
         const int rem = mm - b * HoWo;
         const int ho = rem / p.Wo;
         const int wo = rem - ho * p.Wo;
-        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
-        a_hi0[it] = ok ? hi0 : -(1 << 20);          // an out-of-range row never passes the bounds test
-        a_wi0[it] = wi0;
-        a_ptr[it] = p.x + ((int64_t)(b * p.Hi * p.Wi) + (int64_t)hi0 * p.Wi + wi0) * p.x_cpitch + p.x_coff;
-        a_zoff[it] = ((intptr_t)zero - (intptr_t)a_ptr[it]) / 2;
+        const int hi0 = ok ? ho * p.stride - p.pad : -16384, wi0 = wo * p.stride - p.pad;
+        a_hw0[it] = (hi0 & 0xffff) | (wi0 << 16);
+        a_base[it] = (unsigned)((((int64_t)(b * p.Hi + hi0) * p.Wi + wi0) * p.x_cpitch + p.x_coff) * 2);
     }
-    // B rows: pieces `wave`, `wave + 8` (+ the extra piece 16 on wave 7)
-    const half_t* b_ptr[2];
-    int b_stepv[2];                                   // halfs per sub-tile along K (4 chunks); 0 for rows >= Npad (zero page)
+    unsigned b_voff[4];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int n = n0 + (wave + it * NW) * 16 + prow;
-        b_ptr[it] = (n < p.Npad) ? p.w + ((int64_t)n * p.Kc + j) * 8 : zero;
-        b_stepv[it] = (n < p.Npad) ? 32 : 0;
+    for (int it = 0; it < 4; ++it) {
+        const int n = n0 + (wave + it * NW) * 8 + r8;
+        b_voff[it] = n < p.Npad ? (unsigned)((n * p.Kc + c) * 16) : OOB;
     }
-    const int b_step = 32;
-    const half_t* bx_ptr = p.w + ((int64_t)(n0 + BN + prow) * p.Kc + j) * 8;
-    const bool extra_wave = has_extra && wave == NW - 1;
+    // extra 16 weight rows = pieces 32, 33 -> waves 6, 7
+    const unsigned x_voff = (unsigned)(((n0 + BN + (wave & 1) * 8 + r8) * p.Kc + c) * 16);
+    const bool extra_wave = has_extra && wave >= 6;
 
-    // ---- branch-free incremental k-state of this lane's chunk (requires C8 >= 4) ----
-    int kc8 = j, dh = 0, dw = 0;
-    int koff = j * 8;
-    const int stepw = p.dil * p.x_cpitch - p.C8 * 8;
-    const int steph = p.dil * p.Wi * p.x_cpitch - p.kw * p.dil * p.x_cpitch;
-    const int dw_end = p.kw * p.dil, dh_end = p.kh * p.dil;
-    auto k_advance = [&]() {
-        kc8 += 4;
-        koff += 32;
-        const bool pw = kc8 >= p.C8;
-        kc8 -= pw ? p.C8 : 0;
-        koff += pw ? stepw : 0;
-        dw += pw ? p.dil : 0;
-        const bool qh = dw == dw_end;                  // only possible right after a wrap
-        dw = qh ? 0 : dw;
-        dh += qh ? p.dil : 0;
-        koff += qh ? steph : 0;
-    };
-    auto a_src = [&](int it) -> const half_t* {
-        const int hi = a_hi0[it] + dh, wi = a_wi0[it] + dw;
-        const bool ok = (dh < dh_end) & ((unsigned)hi < (unsigned)p.Hi) & ((unsigned)wi < (unsigned)p.Wi);
-        return a_ptr[it] + (ok ? (int64_t)koff : a_zoff[it]);
+    const int KT = p.Kc >> 3;
+    const int2* kt_lane = p.ktab + c;                  // this lane's chunk of every stage: kt_lane[kt * 8]
+
+    auto a_voff = [&](int it, int2 e) -> unsigned {
+        const int hi = (short)(a_hw0[it] & 0xffff) + (short)(e.y & 0xffff);
+        const int wi = (a_hw0[it] >> 16) + (e.y >> 16);
+        const bool ok = ((unsigned)hi < (unsigned)p.Hi) & ((unsigned)wi < (unsigned)p.Wi);
+        return ok ? a_base[it] + (unsigned)e.x : OOB;
     };
 
-    const int KT = p.Kc >> 3;                         // 64-deep stages
-
-    // ---- fragment read addresses: per-lane constant + immediates ----
-    const int a_lds = ((wm * 128 + lr) * 4 + (lg ^ ((4 - ((lr >> 2) & 3)) & 3))) * 8;     // halfs, A frag 0
-    const int b_lds = BM * 32 + ((wn * 64 + lr) * 4 + (lg ^ ((4 - ((lr >> 2) & 3)) & 3))) * 8;
-    const int x_lds = BM * 32 + ((BN + lr) * 4 + (lg ^ ((4 - ((lr >> 2) & 3)) & 3))) * 8;
+    // ---- fragment read addresses (bytes): per-lane constants + immediates; the second K half is base ^ 64 ----
+    const int fsw = (lr >> 1) & 7;
+    const int a_l0 = (wm * 128 + lr) * 128 + ((lg ^ fsw) << 4), a_l1 = a_l0 ^ 64;
+    const int b_l0 = BM * 128 + (wn * 64 + lr) * 128 + ((lg ^ fsw) << 4), b_l1 = b_l0 ^ 64;
+    const int x_l0 = (BM + BN + lr) * 128 + ((lg ^ fsw) << 4), x_l1 = x_l0 ^ 64;
 
     float4v acc[FN][FM];
     float4v accx[2];
@@ -135,80 +126,69 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
         for (int mi = 0; mi < FM; ++mi) acc[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
     accx[0] = accx[1] = float4v{0.f, 0.f, 0.f, 0.f};
 
-    // issue the DMA pieces of one sub-tile (prologue form, not interleaved)
-    auto issue_sub = [&](half_t* sub) {
-        glds16(a_src(0), sub + wave * 512);
-        glds16(a_src(1), sub + (wave + NW) * 512);
-        k_advance();
-        glds16(b_ptr[0], sub + BM * 32 + wave * 512);
-        glds16(b_ptr[1], sub + BM * 32 + (wave + NW) * 512);
-        if (EXTRA && extra_wave) glds16(bx_ptr, sub + BM * 32 + 16 * 512);
-        b_ptr[0] += b_stepv[0]; b_ptr[1] += b_stepv[1]; bx_ptr += b_step;
-    };
-    issue_sub(smem);
-    issue_sub(smem + G::SUB);
+    // ---- prologue: stage 0 ----
+    int2 e_nx = kt_lane[0];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) dma16(rx, smem + (wave + it * NW) * 1024, a_voff(it, e_nx), 0);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) dma16(rw, smem + BM * 128 + (wave + it * NW) * 1024, b_voff[it], 0);
+    if (EXTRA && extra_wave) dma16(rw, smem + (BM + BN) * 128 + (wave & 1) * 1024, x_voff, 0);
+    e_nx = kt_lane[(KT > 1 ? 1 : 0) * 8];
 
-    // one 64-deep stage; MORE (compile time) = the next stage exists and its DMA is issued from inside this one.
-    // Straight-line: no branch inside a stage except the per-wave extra-column MFMA.
-    auto stage = [&](const half_t* cur, half_t* nxt, auto more_tag) {
+    // one 64-deep stage; MORE (compile time): the next stage exists and its DMA is issued from inside this one
+    auto stage = [&](int kt, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value && ABL != 1;
+        constexpr int GRP = 0;
+        const char* cur = smem + (kt & 1) * G::STAGE_BYTES;
+        char* nxt = smem + ((kt & 1) ^ 1) * G::STAGE_BYTES;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
-        half8 bf[2][FN];                               // B fragments of sub-tile 0 / 1
-        half8 xb[2];                                   // extra-column B fragment
-        half8 af[3];                                   // A fragment ring
+        half8 bf[2][FN];                               // weight fragments, K half 0 / 1
+        half8 xb[2];                                   // extra-column weight fragment
+        half8 af[3];                                   // pixel fragment ring
 #pragma unroll
-        for (int ni = 0; ni < FN; ++ni) bf[0][ni] = *reinterpret_cast<const half8*>(cur + b_lds + ni * 16 * 32);
-        if (EXTRA) xb[0] = *reinterpret_cast<const half8*>(cur + x_lds);
-        af[0] = *reinterpret_cast<const half8*>(cur + a_lds);
-        af[1] = *reinterpret_cast<const half8*>(cur + a_lds + 16 * 32);
+        for (int ni = 0; ni < FN; ++ni) bf[0][ni] = *reinterpret_cast<const half8*>(cur + b_l0 + ni * 2048);
+        if (EXTRA) xb[0] = *reinterpret_cast<const half8*>(cur + x_l0);
+        af[0] = *reinterpret_cast<const half8*>(cur + a_l0);
+        af[1] = *reinterpret_cast<const half8*>(cur + a_l0 + 2048);
+        int2 e_n2 = e_nx;
 
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {                 // 16 steps of 4 (+extra) MFMAs
-            const int h = s >> 3, mi = s & 7;
-            // (1) prefetch the A fragment two steps ahead (within this stage)
-            if (s + 2 < 16 && ABL != 2) {
+        for (int s = 0; s < 16; ++s) {                 // step s: K half s>>3, pixel fragment s&7
+            const int ks = s >> 3, mi = s & 7;
+            if (s + 2 < 16 && ABL != 2) {              // (1) pixel fragment two steps ahead
                 const int s2 = s + 2;
-                af[s2 % 3] = *reinterpret_cast<const half8*>(cur + (s2 >> 3) * G::SUB + a_lds + (s2 & 7) * 16 * 32);
+                af[s2 % 3] = *reinterpret_cast<const half8*>(cur + ((s2 >> 3) ? a_l1 : a_l0) + (s2 & 7) * 2048);
             }
-            // (2) prefetch sub-tile 1's B fragments during steps 4..7
-            if (s >= 4 && s < 8 && ABL != 2) bf[1][s - 4] = *reinterpret_cast<const half8*>(cur + G::SUB + b_lds + (s - 4) * 16 * 32);
-            if (EXTRA && s == 3) xb[1] = *reinterpret_cast<const half8*>(cur + G::SUB + x_lds);
-            // (3) one DMA piece of the next stage per step (steps 0..4 -> its sub-tile 0, steps 8..12 -> sub-tile 1)
-            if (MORE) {
-                const int hs = s >> 3, ps = s & 7;
-                half_t* sub = nxt + hs * G::SUB;
-                if (ps == 0) glds16(a_src(0), sub + wave * 512);
-                if (ps == 1) { glds16(a_src(1), sub + (wave + NW) * 512); k_advance(); }
-                if (ps == 2) glds16(b_ptr[0], sub + BM * 32 + wave * 512);
-                if (ps == 3) {
-                    glds16(b_ptr[1], sub + BM * 32 + (wave + NW) * 512);
-                    b_ptr[0] += b_stepv[0]; b_ptr[1] += b_stepv[1];
+            if (s >= 4 && s < 8 && ABL != 2)           // (2) weight fragments of the second K half
+                bf[1][s - 4] = *reinterpret_cast<const half8*>(cur + b_l1 + (s - 4) * 2048);
+            if (EXTRA && s == 3) xb[1] = *reinterpret_cast<const half8*>(cur + x_l1);
+            if (MORE) {                                // (3) one DMA piece of the next stage
+                const int sa = GRP ? s - 8 : s, sb = GRP ? s - 12 : s - 4;     // pixel / weight piece index at this step
+                if (sa >= 0 && sa < 4) dma16(rx, nxt + (wave + sa * NW) * 1024, a_voff(sa, e_nx), 0);
+                if (sb >= 0 && sb < 4) dma16(rw, nxt + BM * 128 + (wave + sb * NW) * 1024, b_voff[sb], (unsigned)(kt + 1) * 128u);
+                if (EXTRA && s == (GRP ? 7 : 8)) {
+                    if (extra_wave) dma16(rw, nxt + (BM + BN) * 128 + (wave & 1) * 1024, x_voff, (unsigned)(kt + 1) * 128u);
                 }
-                if (EXTRA && ps == 4) {
-                    if (extra_wave) glds16(bx_ptr, sub + BM * 32 + 16 * 512);
-                    bx_ptr += b_step;
-                }
+                if (s == (GRP ? 6 : 9)) e_n2 = kt_lane[(kt + 2 < KT ? kt + 2 : KT - 1) * 8];   // K table entry, stage after next
             }
-            // (4) the MFMAs of this step
-            const half8 a = af[ABL == 2 ? s % 2 : s % 3];
+            const half8 a = af[ABL == 2 ? s % 2 : s % 3];                     // (4) the MFMAs of this step
 #pragma unroll
             for (int ni = 0; ni < FN; ++ni) {
-                if (ABL == 4) asm volatile("" :: "v"(bf[ABL == 2 ? 0 : h][ni]), "v"(a));
-                else acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ABL == 2 ? 0 : h][ni], a, acc[ni][mi], 0, 0, 0);
+                if (ABL == 4) asm volatile("" ::"v"(bf[ABL == 2 ? 0 : ks][ni]), "v"(a));
+                else acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ABL == 2 ? 0 : ks][ni], a, acc[ni][mi], 0, 0, 0);
             }
-            if (EXTRA && has_extra) {
-                // extra column fragment x row fragment mi: owned by N-wave (mi >> 1)  (2 per wave)
-                if (wn == (mi >> 1)) accx[mi & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[h], a, accx[mi & 1], 0, 0, 0);
+            if (EXTRA && has_extra) {                  // extra column fragment x pixel fragment mi: N-wave mi >> 1
+                if (wn == (mi >> 1)) accx[mi & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], a, accx[mi & 1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        e_nx = e_n2;
     };
     int kt = 0;
-    for (; kt + 1 < KT; ++kt)
-        stage(smem + (kt & 1) * G::STAGE, smem + ((kt & 1) ^ 1) * G::STAGE, std::true_type{});
-    stage(smem + (kt & 1) * G::STAGE, smem + ((kt & 1) ^ 1) * G::STAGE, std::false_type{});
+    for (; kt + 1 < KT; ++kt) stage(kt, std::true_type{});
+    stage(kt, std::false_type{});
 
     // ---- epilogue ----
     if (ABL == 5) {
@@ -220,11 +200,86 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
         if (t == 123.456f) reinterpret_cast<half_t*>(p.y)[0] = (half_t)t;
         return;
     }
+    // Main 256 columns: transpose through LDS so every lane stores 16 B and 8 lanes cover one 128-byte line of a pixel
+    // (the direct fragment layout gives 8-byte stores in 32-byte runs: 0.29 ms of a 1.6 ms launch, fully exposed at one
+    // block per CU).  Phase 1: bias -> ReLU -> affine in registers, fp16, ds_write_b64 into a wave-private
+    // [8 fragments][16 pixels][128 B] image (16-byte slots XOR-swizzled by pixel).  Phase 2: ds_read_b128, residual +
+    // ReLU, global store.  TRANSPOSED / RGB8 / odd pixel-shuffle widths keep the per-fragment path.
+    const bool lds_epi = !(p.flags & (HAVC_F_OUT_TRANSPOSED | HAVC_F_OUT_RGB8)) &&
+                         (!(p.flags & HAVC_F_OUT_PIXSHUF) || (p.Co & 63) == 0);
+    if (!lds_epi) {
 #pragma unroll
-    for (int mi = 0; mi < FM; ++mi) {
-        const int m = m0 + wm * 128 + mi * 16 + lr;
+        for (int mi = 0; mi < FM; ++mi) {
+            const int m = m0 + wm * 128 + mi * 16 + lr;
 #pragma unroll
-        for (int ni = 0; ni < FN; ++ni) epilogue_frag(p, acc[ni][mi], m, n0 + wn * 64 + ni * 16 + lg * 4, HoWo);
+            for (int ni = 0; ni < FN; ++ni) epilogue_frag(p, acc[ni][mi], m, n0 + wn * 64 + ni * 16 + lg * 4, HoWo);
+        }
+    } else {
+        __syncthreads();                                   // every wave is done reading the last stage
+        char* img = smem + wave * 16384;
+        const bool leaky = p.flags & HAVC_F_LEAKY;
+        const int nw0 = n0 + wn * 64;                      // first channel of this wave's 64-channel slice
+#pragma unroll
+        for (int ni = 0; ni < FN; ++ni) {
+            const int n = nw0 + ni * 16 + lg * 4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bv;
+            const bool n_ok = n < p.Npad;
+            if (p.bias && n_ok) bv = *reinterpret_cast<const float4*>(p.bias + n);
+            if ((p.flags & HAVC_F_AFFINE) && n_ok) {
+                sc = *reinterpret_cast<const float4*>(p.scale + n);
+                sh = *reinterpret_cast<const float4*>(p.shift + n);
+            }
+            const float bb[4] = {bv.x, bv.y, bv.z, bv.w}, ss[4] = {sc.x, sc.y, sc.z, sc.w}, hh[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+            for (int mi = 0; mi < FM; ++mi) {
+                half4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[ni][mi][r] + bb[r];
+                    if (p.flags & HAVC_F_RELU_PRE) v = v > 0.f ? v : (leaky ? v * p.f2 : 0.f);
+                    if (p.flags & HAVC_F_AFFINE) v = v * ss[r] + hh[r];
+                    o[r] = (half_t)v;
+                }
+                const int slot = (ni * 2 + (lg >> 1)) ^ (lr & 7);
+                *reinterpret_cast<half4*>(img + mi * 2048 + lr * 128 + slot * 16 + (lg & 1) * 8) = o;
+            }
+        }
+        // phase 2: lane -> (pixel row lane>>3 (+8), 16-byte channel slot lane&7)
+        const int ch = lane & 7;
+        const int n = nw0 + ch * 8;
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+#pragma unroll
+            for (int hp = 0; hp < 2; ++hp) {
+                const int px = (lane >> 3) + hp * 8;
+                const int m = m0 + wm * 128 + mi * 16 + px;
+                const half8 v = *reinterpret_cast<const half8*>(img + mi * 2048 + px * 128 + ((ch ^ (px & 7)) << 4));
+                if (m >= p.M) continue;
+                half_t* y = reinterpret_cast<half_t*>(p.y);
+                int64_t off;
+                if (p.flags & HAVC_F_OUT_PIXSHUF) {
+                    const int q = n / p.Co, cc = n - q * p.Co;
+                    if (q >= 4) continue;
+                    const int b = m / HoWo, rem = m - b * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+                    off = ((int64_t)(b * 2 * p.Ho + 2 * ho + (q >> 1)) * (2 * p.Wo) + 2 * wo + (q & 1)) * p.y_cpitch + p.y_coff + cc;
+                } else {
+                    if (n >= p.Co) continue;
+                    off = (int64_t)m * p.y_cpitch + p.y_coff + n;
+                }
+                half8 o = v;
+                if (p.flags & (HAVC_F_RESIDUAL | HAVC_F_RELU_POST)) {
+                    half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (p.flags & HAVC_F_RESIDUAL) rv = *reinterpret_cast<const half8*>(p.res + (int64_t)m * p.res_cpitch + p.res_coff + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float f = (float)v[e] + (float)rv[e];
+                        if (p.flags & HAVC_F_RELU_POST) f = f > 0.f ? f : (leaky ? f * p.f2 : 0.f);
+                        o[e] = (half_t)f;
+                    }
+                }
+                *reinterpret_cast<half8*>(y + off) = o;
+            }
+        }
     }
     if (EXTRA && has_extra) {
 #pragma unroll
@@ -237,7 +292,7 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
 
 template <int EXTRA, int ABL = 0>
 static int launch_pipe(const ConvArgs& a, hipStream_t s) {
-    if ((a.Kc & 7) || a.C8 < 4) return (int)hipErrorInvalidValue;
+    if ((a.Kc & 7) || !a.ktab || a.x_bytes == 0 || a.x_bytes >= OOB || a.w_bytes >= OOB) return (int)hipErrorInvalidValue;
     const int MT = (a.M + BM - 1) / BM, NT = (a.Npad - 16 * EXTRA + BN - 1) / BN;
     constexpr int LDS = Geo<EXTRA>::LDS_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
@@ -248,6 +303,10 @@ static int launch_pipe(const ConvArgs& a, hipStream_t s) {
     }
     hipLaunchKernelGGL((conv_pipe_kernel<EXTRA, ABL>), dim3(MT * NT), dim3(512), LDS, s, a);
     return (int)hipGetLastError();
+}
+
+bool conv_pipe_supported(const ConvArgs& a, int extra) {
+    return !(a.Kc & 7) && a.ktab && a.x_bytes != 0 && a.x_bytes < OOB && a.w_bytes < OOB && (!extra || (a.Npad - 16) % BN == 0);
 }
 
 int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {

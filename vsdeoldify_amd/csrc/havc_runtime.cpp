@@ -56,6 +56,8 @@ struct havc_net {
     std::vector<havc_buf> bufdesc;
     std::vector<void*> bufs;
     int in_buf, out_buf, S, max_batch;
+    int2* d_ktab = nullptr;               // all conv K tables, one allocation
+    std::vector<int64_t> ktab_off;        // per op: element offset into d_ktab, -1 for non-conv ops
     const void* in_override = nullptr;
     void* out_override = nullptr;
     double flops_per_frame = 0;
@@ -200,9 +202,17 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             a.pix_pitch = op.aux0;
             a.f0 = op.f0; a.f1 = op.f1; a.f2 = op.f2;
             a.cfg = op.reserved;
+            {
+                const int oi = (int)(&op - n->ops.data());
+                a.ktab = n->ktab_off[oi] >= 0 ? n->d_ktab + n->ktab_off[oi] : nullptr;
+                const uint64_t xb = (uint64_t)n->bufdesc[op.src].elems_per_frame * n->bufdesc[op.src].elem_bytes * n->max_batch + 256;
+                a.x_bytes = xb < 0xF0000000ull ? (unsigned)xb : 0u;          // 0: descriptor path unavailable
+                const uint64_t wb = (uint64_t)op.Npad * op.Kc * 16;
+                a.w_bytes = wb < 0xF0000000ull ? (unsigned)wb : 0xFFFFFFFFu;
+            }
             const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
             for (int i = 0; i < 3; ++i) { a.mean[i] = mean[i]; a.istd[i] = stdv[i]; }
-            if (!a.w || (op.Kc & 3) || a.C8 <= 0) return fail(c, HAVC_E_INVALID, "conv op: bad weights / Kc / Ci");
+            if (!a.w || (op.Kc & 7) || a.C8 <= 0 || !a.ktab) return fail(c, HAVC_E_INVALID, "conv op: bad weights / Kc / Ci");
             if ((op.flags & HAVC_F_AFFINE) && (!a.scale || !a.shift)) return fail(c, HAVC_E_INVALID, "conv op: AFFINE without scale/shift");
             e = launch_conv(a, s);
             break;
@@ -425,6 +435,53 @@ int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops,
     n->bufs.assign(n_bufs, nullptr);
     n->in_buf = in_buf; n->out_buf = out_buf; n->S = S; n->max_batch = max_batch;
     for (int i = 0; i < n_ops; ++i) n->flops_per_frame += (double)ops[i].flops;
+    // ---- per-conv K tables: chunk kidx -> (byte offset from the tap-0 pixel, tap displacement) -----------------
+    // K order (must match plan.py pack_conv): main segment = chunks [0, C8a) of every tap, then chunks [C8a, C8), each
+    // segment padded to a multiple of 8 chunks.  A main segment with C8a % 8 == 0 is CHANNEL-GROUP MAJOR (group of 8
+    // chunks, then tap): the 9 taps of one 128-byte line group are consecutive stages -> re-reads hit L1/L2.
+    {
+        std::vector<int2> host;
+        n->ktab_off.assign(n_ops, -1);
+        for (int i = 0; i < n_ops; ++i) {
+            const havc_op& o = ops[i];
+            if (o.type != HAVC_OP_CONV) continue;
+            n->ktab_off[i] = (int64_t)host.size();
+            const int C8 = o.Ci / 8, C8a = (o.aux1 > 0 && o.aux1 < C8) ? o.aux1 : C8;
+            const size_t start = host.size();
+            auto emit = [&](int kh, int kw, int c) {
+                int2 e;
+                e.x = ((kh * o.dil * o.Wi + kw * o.dil) * o.src_cpitch + c * 8) * 2;
+                e.y = ((kh * o.dil) & 0xffff) | ((kw * o.dil) << 16);
+                host.push_back(e);
+            };
+            auto emit_seg = [&](int c_lo, int c_hi) {
+                if (c_hi <= c_lo) return;
+                if (c_lo == 0 && c_hi % 8 == 0) {
+                    for (int g = 0; g < c_hi / 8; ++g)
+                        for (int kh = 0; kh < o.kh; ++kh)
+                            for (int kw = 0; kw < o.kw; ++kw)
+                                for (int c = 0; c < 8; ++c) emit(kh, kw, g * 8 + c);
+                } else {
+                    for (int kh = 0; kh < o.kh; ++kh)
+                        for (int kw = 0; kw < o.kw; ++kw)
+                            for (int c = c_lo; c < c_hi; ++c) emit(kh, kw, c);
+                }
+                while ((host.size() - start) % 8) host.push_back(int2{0, HAVC_KTAB_PAD_DH});
+            };
+            emit_seg(0, C8a);
+            emit_seg(C8a, C8);
+            if ((int)(host.size() - start) != o.Kc) {
+                delete n;
+                return fail(c, HAVC_E_INVALID, "net_create: conv op Kc does not match its K layout (Ci, kh, kw, aux1)");
+            }
+        }
+        if (!host.empty()) {
+            hipError_t e = hipMalloc((void**)&n->d_ktab, host.size() * sizeof(int2));
+            if (e == hipSuccess) e = hipMemcpy(n->d_ktab, host.data(), host.size() * sizeof(int2), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { delete n; return hip_fail(c, e, "K table upload"); }
+            c->stats.bytes_resident += (int64_t)(host.size() * sizeof(int2));
+        }
+    }
     for (int i = 0; i < n_bufs; ++i) {
         // +256 B tail so a predicated-off 16-byte vector address is never formed past the allocation
         size_t nb = (size_t)bufs[i].elems_per_frame * bufs[i].elem_bytes * max_batch + 256;
@@ -445,6 +502,7 @@ void havc_net_free(havc_net* n) {
     if (!n) return;
     std::lock_guard<std::mutex> lk(n->ctx->mu);
     (void)hipStreamSynchronize(n->ctx->stream);
+    if (n->d_ktab) (void)hipFree(n->d_ktab);
     for (size_t i = 0; i < n->bufs.size(); ++i) {
         if (n->bufs[i]) (void)hipFree(n->bufs[i]);
         n->ctx->stats.bytes_resident -= (int64_t)((size_t)n->bufdesc[i].elems_per_frame * n->bufdesc[i].elem_bytes * n->max_batch + 256);

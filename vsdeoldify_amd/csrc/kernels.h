@@ -26,11 +26,15 @@ struct ConvArgs {
     float f0, f1, f2;      // sigmoid range lo/hi, leaky slope
     float mean[3], istd[3];
     int cfg;               // 0 = heuristic; otherwise forced tile configuration (tools/conv_bench.py A/B runs)
+    const int2* ktab;      // [Kc] per 16-byte K chunk: .x = byte offset of (tap, cin chunk) from the tap-0 pixel,
+                           //      .y = dh | dw << 16 (input-pixel displacement of the tap; pad entries: dh = 0x7fff)
+    unsigned x_bytes;      // size of the input allocation (buffer descriptor range; OOB lanes read zeros)
+    unsigned w_bytes;      // Npad * Kc * 16
 };
+#define HAVC_KTAB_PAD_DH 0x7fff
 
 // returns hipError_t as int
 int launch_conv(const ConvArgs& a, hipStream_t s);
-int launch_conv_glds(const ConvArgs& a, int cfg, hipStream_t s);
 int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s);
 const char* conv_config_name(const ConvArgs& a);
 

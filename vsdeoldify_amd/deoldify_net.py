@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _native as nat
 from .plan import (TAG_TAIL_RES, PlanBuilder, View, WeightPack, bn_scale_shift, conv_weight, fold_spectral, pack_conv,
-                   pad_to, to_np)
+                   pad_to, pitch_for, to_np)
 
 RESNET = {"wide": ("bottleneck", [3, 4, 23, 3]), "deep": ("basic", [3, 4, 6, 3])}
 Y_RANGE = (-3.0, 3.0)          # SigmoidRange(*y_range), deoldify/generators.py:33,111
@@ -93,10 +93,11 @@ class DeoldifyGenerator:
         c8 = sd["layers.8.conv.0.weight_v"].shape[0] // 4          # channels after the last pixel shuffle
         c8s = pad_to(c8, 8)
         tail_span = c8s + 8
-        tail_buf = b.buf(S * S * tail_span, 2, zero_init=c8s != c8)
+        tail_pitch = pitch_for(tail_span)                          # 264 -> 320: 128-byte aligned pixel rows
+        tail_buf = b.buf(S * S * tail_pitch, 2, zero_init=c8s != c8)
         tail_cmap = np.concatenate([np.arange(c8), c8s + np.arange(3)])
         x0 = b.tensor(S, S, 3, zero_init=False)
-        b.prep_rgb8("prep", in_buf, S, x0, View(tail_buf, c8s, tail_span, S, S, 3, 8))
+        b.prep_rgb8("prep", in_buf, S, x0, View(tail_buf, c8s, tail_pitch, S, S, 3, 8))
 
         # ---- encoder: torchvision resnet children()[:-2] ----
         e = "layers.0"
@@ -159,12 +160,13 @@ class DeoldifyGenerator:
             b.conv(p + ".shuf", pc, x, ps, flags=nat.F_RELU_PRE | nat.F_OUT_PIXSHUF)
             ups, sks = pad_to(up_c, 8), pad_to(skip.C, 8)
             cat_span = ups + sks
-            cat_buf = b.buf(skip.H * skip.W * cat_span, 2, zero_init=(ups != up_c or sks != skip.C))
+            cat_pitch = pitch_for(cat_span)
+            cat_buf = b.buf(skip.H * skip.W * cat_pitch, 2, zero_init=(ups != up_c or sks != skip.C))
             # blur (+ nearest resize when the shuffled size != skip size, e.g. 36 -> 35 at rf=35)
-            b.blur_resize(p + ".blur", ps, View(cat_buf, 0, cat_span, skip.H, skip.W, up_c, ups))
+            b.blur_resize(p + ".blur", ps, View(cat_buf, 0, cat_pitch, skip.H, skip.W, up_c, ups))
             so, sho = self._vecs(p + ".bn", lambda p=p: bn_scale_shift(sd, p + ".bn"))
-            b.affine(p + ".bn", skip, View(cat_buf, ups, cat_span, skip.H, skip.W, skip.C, sks), so, sho, relu=True)
-            cat = View(cat_buf, 0, cat_span, skip.H, skip.W, up_c + skip.C, cat_span,
+            b.affine(p + ".bn", skip, View(cat_buf, ups, cat_pitch, skip.H, skip.W, skip.C, sks), so, sho, relu=True)
+            cat = View(cat_buf, 0, cat_pitch, skip.H, skip.W, up_c + skip.C, cat_span,
                        np.concatenate([np.arange(up_c), ups + np.arange(skip.C)]))
             if deep:
                 x = self._dec_conv(b, p + ".conv1", cat)
@@ -182,17 +184,17 @@ class DeoldifyGenerator:
         ps8 = b.tensor(2 * x.H, 2 * x.W, c8)
         assert ps8.H == S
         b.conv("layers.8", pc, x, ps8, flags=nat.F_RELU_PRE | nat.F_OUT_PIXSHUF)
-        b.blur_resize("layers.8.blur", ps8, View(tail_buf, 0, tail_span, S, S, c8, c8s))
-        cat = View(tail_buf, 0, tail_span, S, S, c8 + 3, tail_span, tail_cmap)
+        b.blur_resize("layers.8.blur", ps8, View(tail_buf, 0, tail_pitch, S, S, c8, c8s))
+        cat = View(tail_buf, 0, tail_pitch, S, S, c8 + 3, tail_span, tail_cmap)
 
         # ---- layers.10 res_block: 2 x (spectral conv3x3 + bias -> ReLU), + input; layers.11/12 ----
         def res_pc(key):
             return self._conv(key, lambda: pack_conv(self.pack, conv_weight(sd, key), tail_cmap, tail_span,
                                                      bias=sd[key + ".bias"], omap=tail_cmap, ospan=tail_span))
-        r1 = View(b.buf(S * S * tail_span), 0, tail_span, S, S, c8 + 3, tail_span, tail_cmap)
+        r1 = View(b.buf(S * S * tail_pitch), 0, tail_pitch, S, S, c8 + 3, tail_span, tail_cmap)
         b.conv("layers.10.layers.0.0", res_pc("layers.10.layers.0.0"), cat, r1, pad=1, flags=nat.F_RELU_PRE,
                tag=TAG_TAIL_RES)
-        r2 = View(b.buf(S * S * tail_span), 0, tail_span, S, S, c8 + 3, tail_span, tail_cmap)
+        r2 = View(b.buf(S * S * tail_pitch), 0, tail_pitch, S, S, c8 + 3, tail_span, tail_cmap)
         b.conv("layers.10.layers.1.0", res_pc("layers.10.layers.1.0"), r1, r2, pad=1,
                flags=nat.F_RELU_PRE | nat.F_RESIDUAL, res=cat, tag=TAG_TAIL_RES)
         pc = self._conv("layers.11.0", lambda: pack_conv(self.pack, conv_weight(sd, "layers.11.0"), tail_cmap, tail_span,

@@ -108,6 +108,13 @@ class PackedConv:
     Cin: int
     kh: int
     kw: int
+    C8a: int = 0                 # chunks per tap in the main K segment (== Ci/8 when K is not split)
+
+
+def pitch_for(span):
+    """channel pitch of a buffer holding `span` stored channels: 128-byte aligned rows (multiple of 64 channels) for
+    everything wider than 64 channels — LDS-DMA line fetches halve in speed on unaligned pitches (dma_bench)."""
+    return span if span <= 64 else pad_to(span, 64)
 
 
 def pack_conv(pack, W, cmap, Ci, bias=None, scale=None, shift=None, pixshuf=False, omap=None, ospan=None):
@@ -140,12 +147,28 @@ def pack_conv(pack, W, cmap, Ci, bias=None, scale=None, shift=None, pixshuf=Fals
         bias = None if bias is None else bias[perm]
         scale = None if scale is None else scale[perm]
         shift = None if shift is None else shift[perm]
-    K = KH * KW * Ci // 8
-    Kc = pad_to(K, 8)          # 64-deep K-steps (two 32-deep sub-tiles) in the ring kernels
-    flat = np.zeros((Npad, Kc * 8), np.float16)
-    flat[:, :K * 8] = Wt.reshape(Npad, -1).astype(np.float16)
+    # K order (must match havc_net_create's K table).  Main segment = chunks [0, C8a) of every tap, remainder segment =
+    # chunks [C8a, C8); each segment padded to a multiple of 8 chunks (259 = 256 + 3: 32 chunks x 9 taps, then 9 single
+    # chunks of x0).  When C8a is a multiple of 8 the main segment is ordered CHANNEL-GROUP MAJOR: for every group of 8
+    # chunks (64 channels = one 128-byte line per pixel), all taps in turn.  A 64-deep stage of the pipelined kernel is
+    # then one line of one tap, and the 9 taps of a group re-read the same lines back to back (L1/L2 hits) instead of
+    # cycling through the whole 512-byte pixel between re-uses (tap-major order overflowed the 4 MiB L2 of an XCD).
+    C8 = Ci // 8
+    C8a = C8 - C8 % 8 if (C8 % 8 != 0 and C8 >= 16) else C8
+    W5 = Wt.reshape(Npad, KH * KW, C8, 8)
+    segs = []
+    for lo, hi in ((0, C8a), (C8a, C8)):
+        if hi > lo:
+            seg = W5[:, :, lo:hi, :]
+            if lo == 0 and C8a % 8 == 0:
+                seg = seg.reshape(Npad, KH * KW, C8a // 8, 64).transpose(0, 2, 1, 3)      # [n][group][tap][64]
+            seg = seg.reshape(Npad, -1)
+            padk = (-seg.shape[1]) % 64
+            segs.append(np.pad(seg, ((0, 0), (0, padk))))
+    flat = np.concatenate(segs, axis=1).astype(np.float16)
+    Kc = flat.shape[1] // 8
     return PackedConv(pack.add(flat), -1 if bias is None else pack.add(bias), -1 if scale is None else pack.add(scale),
-                      -1 if shift is None else pack.add(shift), Kc, Npad, Ci, Cout, Cin, KH, KW)
+                      -1 if shift is None else pack.add(shift), Kc, Npad, Ci, Cout, Cin, KH, KW, C8a)
 
 
 class PlanBuilder:
@@ -159,7 +182,8 @@ class PlanBuilder:
     def tensor(self, H, W, C, zero_init=True):
         """fresh buffer holding one logical tensor; zero_init keeps pad channels 0 forever."""
         span = pad_to(C, 8)
-        return View(self.buf(H * W * span, 2, zero_init and span != C), 0, span, H, W, C, span)
+        pitch = pitch_for(span)
+        return View(self.buf(H * W * pitch, 2, zero_init and span != C), 0, pitch, H, W, C, span)
 
     def _op(self, name, tag=None, **kw):
         op = np.zeros((), dtype=nat.OP_DTYPE)
@@ -184,7 +208,8 @@ class PlanBuilder:
         kw = dict(type=nat.OP_CONV, flags=flags, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, Hi=x.H, Wi=x.W,
                   Ci=pc.Ci, Ho=Ho, Wo=Wo, kh=pc.kh, kw=pc.kw, stride=stride, pad=pad, dil=dil, Kc=pc.Kc,
                   Npad=pc.Npad, w_off=pc.w_off, bias_off=pc.bias_off, scale_off=pc.scale_off, shift_off=pc.shift_off,
-                  f0=f[0], f1=f[1], f2=f[2], f3=f[3], aux0=aux0, flops=2 * Ho * Wo * pc.Cout * pc.Cin * pc.kh * pc.kw)
+                  f0=f[0], f1=f[1], f2=f[2], f3=f[3], aux0=aux0, aux1=pc.C8a,
+                  flops=2 * Ho * Wo * pc.Cout * pc.Cin * pc.kh * pc.kw)
         if isinstance(y, View):
             kw.update(dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch)
             if flags & nat.F_OUT_PIXSHUF:
