@@ -56,7 +56,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
     ap.add_argument("--clip-frames", type=int, default=16, help="distinct synthetic frames resident per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads for the CPU-oracle baseline leg")

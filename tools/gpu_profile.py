@@ -26,6 +26,18 @@ for i in order[:40]:
     o = ops[i]
     print(f"{net.names[i]:40s} {ms[i]:8.3f} {100*ms[i]/ms.sum():6.1f} {fl[i]/1e9:9.2f} {fl[i]/ms[i]/1e9 if ms[i]>0 else 0:8.1f}  "
           f"t{o['type']} {o['Ci']}->{o['Npad']} k{o['kh']} s{o['stride']} {o['Hi']}x{o['Wi']}->{o['Ho']}x{o['Wo']}")
+# group totals
+import collections
+grp = collections.OrderedDict()
+def gname(n):
+    if n.startswith("layers.0."): return "encoder (" + (".".join(n.split(".")[:3]) if n.split(".")[2] in "4567" else "stem") + ")"
+    if n.startswith("layers.10") or n.startswith("layers.11"): return "tail convs"
+    return ".".join(n.split(".")[:2])
+for i in range(len(ms)):
+    g = gname(net.names[i]); a = grp.setdefault(g, [0.0, 0.0, 0]); a[0] += ms[i]; a[1] += fl[i]; a[2] += 1
+print("--- groups ---")
+for g, (t, f, n) in grp.items():
+    print(f"{g:28s} {n:3d} ops {t:8.3f} ms {100*t/ms.sum():5.1f}%  {f/1e9:9.1f} GF  {f/t/1e9 if t else 0:7.1f} TF/s")
 # whole-pass wall time without per-op events
 d_in = ctx.dev_alloc(batch * S * S * 3); d_out = ctx.dev_alloc(batch * S * S * 3)
 ctx.dev_upload(d_in, np.random.default_rng(0).integers(0, 256, (batch, S, S, 3), dtype=np.uint8))

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -27,6 +28,11 @@ struct ResizeTable {
 struct havc_ctx {
     int dev = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;        // the second generator of a stable/artistic render runs here, concurrently
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_main_done = nullptr;
+    bool wait_main_before_tail = false;   // set while the second generator is being enqueued on stream2
+    hipStream_t cur = nullptr;            // stream the plan executor launches on (stream or stream2)
+    bool two_streams = true;              // HAVC_TWO_STREAMS=0 serialises the two generators (A/B measurements)
     std::mutex mu;
     std::string err;
     havc_stats stats{};
@@ -56,6 +62,7 @@ struct havc_net {
     std::vector<havc_buf> bufdesc;
     std::vector<void*> bufs;
     int in_buf, out_buf, S, max_batch;
+    int tail_first = -1;                  // index of the first op tagged 1 (exclusive tail), -1 if none
     int2* d_ktab = nullptr;               // all conv K tables, one allocation
     std::vector<int64_t> ktab_off;        // per op: element offset into d_ktab, -1 for non-conv ops
     const void* in_override = nullptr;
@@ -166,7 +173,7 @@ inline const T* wptr(havc_net* n, int64_t off) {
 
 int run_op(havc_net* n, const havc_op& op, int batch) {
     havc_ctx* c = n->ctx;
-    hipStream_t s = c->stream;
+    hipStream_t s = c->cur ? c->cur : c->stream;
     int e = 0;
     const bool timed = (op.tag == c->timed_tag && c->timed_tag >= 0 && op.type == HAVC_OP_CONV);
     std::pair<hipEvent_t, hipEvent_t> evp{nullptr, nullptr};
@@ -214,7 +221,28 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             for (int i = 0; i < 3; ++i) { a.mean[i] = mean[i]; a.istd[i] = stdv[i]; }
             if (!a.w || (op.Kc & 7) || a.C8 <= 0 || !a.ktab) return fail(c, HAVC_E_INVALID, "conv op: bad weights / Kc / Ci");
             if ((op.flags & HAVC_F_AFFINE) && (!a.scale || !a.shift)) return fail(c, HAVC_E_INVALID, "conv op: AFFINE without scale/shift");
-            e = launch_conv(a, s);
+            {
+                // frames per launch: keep every operand within the 32-bit range of a buffer descriptor (and of the
+                // kernels' int pixel indices); big batches of the 560x560 tail run as several launches.
+                const uint64_t lim = 0xE0000000ull;
+                const uint64_t xf = (uint64_t)n->bufdesc[op.src].elems_per_frame * n->bufdesc[op.src].elem_bytes;
+                const uint64_t yf = (uint64_t)n->bufdesc[op.dst].elems_per_frame * n->bufdesc[op.dst].elem_bytes;
+                const uint64_t rf = a.res ? (uint64_t)n->bufdesc[op.src2].elems_per_frame * n->bufdesc[op.src2].elem_bytes : 0;
+                int chunk = batch;
+                const uint64_t big = std::max(xf, std::max(yf, rf));
+                if (big * (uint64_t)batch > lim) chunk = (int)std::max<uint64_t>(1, lim / big);
+                const char* x0 = (const char*)a.x; const char* r0 = (const char*)a.res; char* y0 = (char*)a.y;
+                for (int f0 = 0; f0 < batch && e == 0; f0 += chunk) {
+                    const int nb = std::min(chunk, batch - f0);
+                    a.x = (const half_t*)(x0 + (uint64_t)f0 * xf);
+                    a.y = y0 + (uint64_t)f0 * yf;
+                    if (r0) a.res = (const half_t*)(r0 + (uint64_t)f0 * rf);
+                    a.M = nb * op.Ho * op.Wo;
+                    a.x_bytes = (unsigned)std::min<uint64_t>(xf * (uint64_t)nb + 256, 0xEFFFFFFFull);
+                    e = launch_conv(a, s);
+                    if (f0 > 0) c->stats.launches += 1;
+                }
+            }
             break;
         }
         case HAVC_OP_MAXPOOL:
@@ -259,16 +287,22 @@ int run_ops_locked(havc_net* n, int first, int count, int batch) {
     if (batch < 1 || batch > n->max_batch) return fail(n->ctx, HAVC_E_INVALID, "batch out of range");
     if (first < 0 || count < 0 || first + count > (int)n->ops.size()) return fail(n->ctx, HAVC_E_INVALID, "op range");
     for (int i = first; i < first + count; ++i) {
+        // the GPU-filling tail (tag 1 = the 560x560 res-block convs onward) of the second generator runs after the first
+        // generator has finished: only the under-filled encoder / bottleneck phases of the two networks overlap.
+        if (n->ctx->wait_main_before_tail && i == n->tail_first)
+            HIP_TRY(n->ctx, hipStreamWaitEvent(n->ctx->cur, n->ctx->ev_main_done, 0));
         int rc = run_op(n, n->ops[i], batch);
         if (rc) return rc;
     }
     return HAVC_OK;
 }
 
-int net_run_rgb8_locked(havc_net* n, const uint8_t* d_in, uint8_t* d_out, int batch) {
+int net_run_rgb8_locked(havc_net* n, const uint8_t* d_in, uint8_t* d_out, int batch, hipStream_t on = nullptr) {
     n->in_override = d_in;
     n->out_override = d_out;
+    n->ctx->cur = on;
     int rc = run_ops_locked(n, 0, (int)n->ops.size(), batch);
+    n->ctx->cur = nullptr;
     n->in_override = nullptr;
     n->out_override = nullptr;
     if (rc == HAVC_OK) {
@@ -316,6 +350,28 @@ int deoldify_tail(havc_ctx* c, const uint8_t* d_in, uint8_t* d_v, uint8_t* d_s, 
     return HAVC_OK;
 }
 
+// video generator on the main stream, second (stable / artistic) generator concurrently on stream2: the encoder and
+// bottleneck layers fill well under 256 CUs at small batch, the other network's kernels take the idle CUs.
+int run_generators(havc_ctx* c, havc_net* video, havc_net* second, const uint8_t* d_in, uint8_t* d_v, uint8_t* d_s, int b) {
+    int rc;
+    if (!second) return net_run_rgb8_locked(video, d_in, d_v, b);
+    if (!c->two_streams) {
+        if ((rc = net_run_rgb8_locked(video, d_in, d_v, b))) return rc;
+        return net_run_rgb8_locked(second, d_in, d_s, b);
+    }
+    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    if ((rc = net_run_rgb8_locked(video, d_in, d_v, b))) return rc;          // enqueue order matters: the event the
+    HIP_TRY(c, hipEventRecord(c->ev_main_done, c->stream));                   // second generator waits on is recorded first
+    c->wait_main_before_tail = true;
+    rc = net_run_rgb8_locked(second, d_in, d_s, b, c->stream2);
+    c->wait_main_before_tail = false;
+    if (rc) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    return HAVC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -340,7 +396,12 @@ int havc_create(havc_ctx** out, int device_id) {
         return fail(nullptr, HAVC_E_NODEVICE, std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
     havc_ctx* c = new havc_ctx();
     c->dev = device_id;
+    if (const char* e = getenv("HAVC_TWO_STREAMS")) c->two_streams = atoi(e) != 0;
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_main_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
         return fail(nullptr, HAVC_E_HIP, "failed to create stream/events");
@@ -359,6 +420,11 @@ void havc_destroy(havc_ctx* c) {
     for (auto& p : c->tag_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     (void)hipEventDestroy(c->ev0);
     (void)hipEventDestroy(c->ev1);
+    (void)hipStreamSynchronize(c->stream2);
+    (void)hipEventDestroy(c->ev_fork);
+    (void)hipEventDestroy(c->ev_join);
+    (void)hipEventDestroy(c->ev_main_done);
+    (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -435,6 +501,8 @@ int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops,
     n->bufs.assign(n_bufs, nullptr);
     n->in_buf = in_buf; n->out_buf = out_buf; n->S = S; n->max_batch = max_batch;
     for (int i = 0; i < n_ops; ++i) n->flops_per_frame += (double)ops[i].flops;
+    for (int i = 0; i < n_ops; ++i)
+        if (ops[i].tag == 1) { n->tail_first = i; break; }
     // ---- per-conv K tables: chunk kidx -> (byte offset from the tap-0 pixel, tap displacement) -----------------
     // K order (must match plan.py pack_conv): main segment = chunks [0, C8a) of every tap, then chunks [C8a, C8), each
     // segment padded to a multiple of 8 chunks.  A main segment with C8a % 8 == 0 is CHANNEL-GROUP MAJOR (group of 8
@@ -599,8 +667,7 @@ int havc_deoldify_frames(havc_ctx* c, havc_net* video, havc_net* second, float v
     for (int f0 = 0; f0 < n_frames; f0 += maxb) {
         const int b = std::min(maxb, n_frames - f0);
         HIP_TRY(c, hipMemcpyAsync(d_in, rgb_in + (size_t)f0 * fb, fb * b, hipMemcpyHostToDevice, c->stream));
-        if ((rc = net_run_rgb8_locked(video, d_in, d_v, b))) return rc;
-        if (second && (rc = net_run_rgb8_locked(second, d_in, d_s, b))) return rc;
+        if ((rc = run_generators(c, video, second, d_in, d_v, d_s, b))) return rc;
         if ((rc = deoldify_tail(c, d_in, d_v, second ? d_s : nullptr, video_weight, post_process, d_out, npix1 * b))) return rc;
         HIP_TRY(c, hipMemcpyAsync(rgb_out + (size_t)f0 * fb, d_out, fb * b, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -686,8 +753,7 @@ int havc_colorize_clip(havc_ctx* c, havc_net* video, havc_net* second, float vid
         if (width == S && height == S) {
             HIP_TRY(c, hipMemcpyAsync(d_sq, src, fb * b, hipMemcpyDeviceToDevice, c->stream));
         } else if ((rc = resize_rgb8(c, src, width, height, d_sq, S, S, b, nullptr))) return rc;
-        if ((rc = net_run_rgb8_locked(video, d_sq, d_v, b))) return rc;
-        if (second && (rc = net_run_rgb8_locked(second, d_sq, d_s, b))) return rc;
+        if ((rc = run_generators(c, video, second, d_sq, d_v, d_s, b))) return rc;
         if ((rc = deoldify_tail(c, d_sq, d_v, second ? d_s : nullptr, video_weight, 1, d_col, npix1 * b))) return rc;
         // Spline64 back to full size fused with vs_recover_clip_luma (chroma_post_process vs the source frame)
         if ((rc = resize_rgb8(c, d_col, S, S, d_dst + (size_t)f0 * fbig, width, height, b, src))) return rc;
