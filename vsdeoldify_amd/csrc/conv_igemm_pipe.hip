@@ -244,9 +244,22 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
                 *reinterpret_cast<half4*>(img + mi * 2048 + lr * 128 + slot * 16 + (lg & 1) * 8) = o;
             }
         }
-        // phase 2: lane -> (pixel row lane>>3 (+8), 16-byte channel slot lane&7)
+        // phase 2: lane -> (pixel row lane>>3 (+8), 16-byte channel slot lane&7).  All residual vectors are requested
+        // up front (the accumulators are dead by now) so their latency overlaps instead of serialising 16 load->store pairs.
         const int ch = lane & 7;
         const int n = nw0 + ch * 8;
+        const bool do_res = (p.flags & HAVC_F_RESIDUAL) && !(p.flags & HAVC_F_OUT_PIXSHUF) && n < p.Co;
+        half8 rres[FM][2];
+        if (p.flags & HAVC_F_RESIDUAL) {
+#pragma unroll
+            for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+                for (int hp = 0; hp < 2; ++hp) {
+                    const int m = m0 + wm * 128 + mi * 16 + (lane >> 3) + hp * 8;
+                    rres[mi][hp] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (do_res && m < p.M) rres[mi][hp] = *reinterpret_cast<const half8*>(p.res + (int64_t)m * p.res_cpitch + p.res_coff + n);
+                }
+        }
 #pragma unroll
         for (int mi = 0; mi < FM; ++mi) {
 #pragma unroll
@@ -268,11 +281,10 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
                 }
                 half8 o = v;
                 if (p.flags & (HAVC_F_RESIDUAL | HAVC_F_RELU_POST)) {
-                    half8 rv = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                    if (p.flags & HAVC_F_RESIDUAL) rv = *reinterpret_cast<const half8*>(p.res + (int64_t)m * p.res_cpitch + p.res_coff + n);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
-                        float f = (float)v[e] + (float)rv[e];
+                        float f = (float)v[e];
+                        if (p.flags & HAVC_F_RESIDUAL) f += (float)rres[mi][hp][e];
                         if (p.flags & HAVC_F_RELU_POST) f = f > 0.f ? f : (leaky ? f * p.f2 : 0.f);
                         o[e] = (half_t)f;
                     }

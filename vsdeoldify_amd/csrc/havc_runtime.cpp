@@ -30,7 +30,6 @@ struct havc_ctx {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // the second generator of a stable/artistic render runs here, concurrently
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_main_done = nullptr;
-    bool wait_main_before_tail = false;   // set while the second generator is being enqueued on stream2
     hipStream_t cur = nullptr;            // stream the plan executor launches on (stream or stream2)
     bool two_streams = true;              // HAVC_TWO_STREAMS=0 serialises the two generators (A/B measurements)
     std::mutex mu;
@@ -287,10 +286,6 @@ int run_ops_locked(havc_net* n, int first, int count, int batch) {
     if (batch < 1 || batch > n->max_batch) return fail(n->ctx, HAVC_E_INVALID, "batch out of range");
     if (first < 0 || count < 0 || first + count > (int)n->ops.size()) return fail(n->ctx, HAVC_E_INVALID, "op range");
     for (int i = first; i < first + count; ++i) {
-        // the GPU-filling tail (tag 1 = the 560x560 res-block convs onward) of the second generator runs after the first
-        // generator has finished: only the under-filled encoder / bottleneck phases of the two networks overlap.
-        if (n->ctx->wait_main_before_tail && i == n->tail_first)
-            HIP_TRY(n->ctx, hipStreamWaitEvent(n->ctx->cur, n->ctx->ev_main_done, 0));
         int rc = run_op(n, n->ops[i], batch);
         if (rc) return rc;
     }
@@ -350,25 +345,38 @@ int deoldify_tail(havc_ctx* c, const uint8_t* d_in, uint8_t* d_v, uint8_t* d_s, 
     return HAVC_OK;
 }
 
-// video generator on the main stream, second (stable / artistic) generator concurrently on stream2: the encoder and
-// bottleneck layers fill well under 256 CUs at small batch, the other network's kernels take the idle CUs.
+// Two generators per frame (video + stable/artistic).  Their encoder / bottleneck / decoder-block phases fill well under
+// 256 CUs at small batch, so those phases of the two networks run CONCURRENTLY on two streams; the GPU-filling tails
+// (ops from the first one tagged 1 = the 560x560 res-block convs onward) then run one after the other, each alone:
+//   stream : A.small ------------\  wait(B.small) -> A.tail -> record(A.done) ............ wait(B.done)
+//   stream2: wait(fork) B.small --/--------------------------- wait(A.done) -> B.tail -> record(B.done)
 int run_generators(havc_ctx* c, havc_net* video, havc_net* second, const uint8_t* d_in, uint8_t* d_v, uint8_t* d_s, int b) {
     int rc;
     if (!second) return net_run_rgb8_locked(video, d_in, d_v, b);
-    if (!c->two_streams) {
+    const int ta = video->tail_first, tb = second->tail_first;
+    if (!c->two_streams || ta < 0 || tb < 0) {
         if ((rc = net_run_rgb8_locked(video, d_in, d_v, b))) return rc;
         return net_run_rgb8_locked(second, d_in, d_s, b);
     }
+    auto part = [&](havc_net* n, const uint8_t* in, uint8_t* out, int first, int count, hipStream_t on) {
+        n->in_override = in; n->out_override = out; c->cur = on;
+        int r = run_ops_locked(n, first, count, b);
+        n->in_override = nullptr; n->out_override = nullptr; c->cur = nullptr;
+        return r;
+    };
     HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
     HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    if ((rc = net_run_rgb8_locked(video, d_in, d_v, b))) return rc;          // enqueue order matters: the event the
-    HIP_TRY(c, hipEventRecord(c->ev_main_done, c->stream));                   // second generator waits on is recorded first
-    c->wait_main_before_tail = true;
-    rc = net_run_rgb8_locked(second, d_in, d_s, b, c->stream2);
-    c->wait_main_before_tail = false;
-    if (rc) return rc;
-    HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+    if ((rc = part(video, d_in, d_v, 0, ta, nullptr))) return rc;
+    if ((rc = part(second, d_in, d_s, 0, tb, c->stream2))) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));                        // B.small done
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    if ((rc = part(video, d_in, d_v, ta, (int)video->ops.size() - ta, nullptr))) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_main_done, c->stream));                    // A.tail done
+    HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_main_done, 0));
+    if ((rc = part(second, d_in, d_s, tb, (int)second->ops.size() - tb, c->stream2))) return rc;
+    HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));                        // B.tail done
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    c->stats.total_flops += (video->flops_per_frame + second->flops_per_frame) * b;
     return HAVC_OK;
 }
 
