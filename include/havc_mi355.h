@@ -50,6 +50,11 @@ enum havc_op_type {
     HAVC_OP_ATTENTION = 5,   /* fastai SelfAttention, flash form: out = gamma * softmax_i(f_i.g_j) h + x   */
     HAVC_OP_PREP_RGB8 = 6,   /* u8 RGB -> PIL 'L' gray x3 -> /255 -> imagenet normalise -> fp16 C8         */
     HAVC_OP_COPY_CH = 7,     /* copy channel slice src@coff -> dst@coff (dense MergeLayer, layers.9)       */
+    HAVC_OP_SUBSAMPLE2 = 8,  /* y[h][w] = x[2h][2w]  (siggraph17 `conv[:, :, ::2, ::2]`)                    */
+    HAVC_OP_PROJ2 = 9,       /* per pixel C -> 2 projection in fp32: flags&1: softmax over C first (eccv16
+                                model_out), flags&2: + bias then tanh (siggraph17 model_out); x f0; fp32 out */
+    HAVC_OP_BILINEAR2 = 10,  /* 2-channel fp32 map, bilinear align_corners=False (nn.Upsample x4), x f0      */
+    HAVC_OP_PREP_LAB_L = 11, /* u8 RGB -> CIELAB L (skimage rgb2lab, fp64) -> (L-50)/100 -> fp16 C8 ch 0      */
 };
 
 /* conv epilogue flags: v = acc + bias; RELU_PRE; v = v*scale+shift; v += residual; RELU_POST */
@@ -80,7 +85,10 @@ typedef struct havc_op {
     float f0, f1, f2, f3;
     int64_t flops;                       /* algorithmic FLOPs per frame of this op (2*MAC), for stats       */
     int32_t tag;                         /* builder's label (index into its name table), for profiling      */
-    int32_t reserved;
+    int32_t reserved;                    /* forced conv tile configuration (0 = heuristic)                  */
+    int32_t pad_w_delta;                 /* pad along W = pad + pad_w_delta (ConvTranspose parity sub-convs) */
+    int32_t out_step, out_oy, out_ox;    /* out_step 2: output pixel (2*ho + out_oy, 2*wo + out_ox) of a 2Ho x 2Wo
+                                            image (ConvTranspose2d(k4,s2,p1) = 4 parity convs with dil = -1) */
 } havc_op;
 
 typedef struct havc_buf {
@@ -141,6 +149,15 @@ int havc_net_profile(havc_net* net, int batch, float* ms_per_op, int n_ops);
  * rgb_in/rgb_out: host u8 interleaved RGB, n frames of S*S*3 bytes, tightly packed. */
 int havc_deoldify_frames(havc_ctx* ctx, havc_net* video, havc_net* second, float video_weight, int post_process,
                          const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames);
+
+/* havc_zhang_frames replaces ModelColorization.colorize_frame (colorization/__init__.py:76-95) with
+ * preprocess_img / postprocess_tens (colorization/colorizers/util.py:25-55): PIL BICUBIC squash to 256x256, skimage
+ * rgb2lab L of the original and of the squashed frame, eccv16 / siggraph17 forward at 256x256 (the plan of `net`),
+ * bilinear ab -> frame size, lab2rgb, uint8(clip(x*255)).  rgb_in/rgb_out: host u8 interleaved RGB, n frames of w*h*3. */
+int havc_zhang_frames(havc_ctx* ctx, havc_net* net, const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames, int width,
+                      int height);
+/* Pillow Image.resize (BILINEAR = 2, BICUBIC = 3), 8 bits per channel, bit-exact (libImaging/Resample.c) */
+int havc_pil_resize(havc_ctx* ctx, const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int resample);
 
 /* ---- per-pixel filters on host buffers (vsslib/imfilters.py); u8 interleaved RGB, w*h pixels ---- */
 /* Image.blend(a, b, w): trunc(a + w*(b-a)) in fp32 — image_weighted_merge, imfilters.py:113-124 */

@@ -42,15 +42,15 @@ def test_no_device_fails_loudly():
 
 def test_op_struct_layout_matches_c(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "havc_mi355.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "havc_mi355.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
                    "sizeof(havc_op),offsetof(havc_op,w_off),offsetof(havc_op,f0),offsetof(havc_op,flops),offsetof(havc_op,tag),"
-                   "sizeof(havc_buf));return 0;}\n")
+                   "offsetof(havc_op,out_ox),sizeof(havc_buf));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     d = nat.OP_DTYPE
     assert got == [d.itemsize, d.fields["w_off"][1], d.fields["f0"][1], d.fields["flops"][1], d.fields["tag"][1],
-                   nat.BUF_DTYPE.itemsize]
+                   d.fields["out_ox"][1], nat.BUF_DTYPE.itemsize]
 
 
 def test_norm_folds_match_oracle():

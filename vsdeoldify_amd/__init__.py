@@ -13,6 +13,9 @@ def __getattr__(name):
     if name == "ModelImageRender":
         from .render import ModelImageRender
         return ModelImageRender
+    if name == "ModelColorization":
+        from .colorization import ModelColorization
+        return ModelColorization
     if name in ("image_weighted_merge", "chroma_post_process", "chroma_stabilizer"):
         from . import imfilters
         return getattr(imfilters, name)

@@ -16,6 +16,7 @@ HAVC_OK, HAVC_E_INVALID, HAVC_E_OOM, HAVC_E_HIP, HAVC_E_NODEVICE = 0, -1, -2, -3
 
 # op types / flags (mirror include/havc_mi355.h)
 OP_CONV, OP_MAXPOOL, OP_BLUR_RESIZE, OP_AFFINE, OP_ATTENTION, OP_PREP_RGB8, OP_COPY_CH = 1, 2, 3, 4, 5, 6, 7
+OP_SUBSAMPLE2, OP_PROJ2, OP_BILINEAR2, OP_PREP_LAB_L = 8, 9, 10, 11
 F_RELU_PRE, F_AFFINE, F_RESIDUAL, F_RELU_POST = 0x1, 0x2, 0x4, 0x8
 F_OUT_PIXSHUF, F_OUT_TRANSPOSED, F_OUT_RGB8, F_LEAKY = 0x10, 0x20, 0x40, 0x80
 
@@ -34,6 +35,7 @@ OP_DTYPE = np.dtype([
     ("w_off", "<i8"), ("bias_off", "<i8"), ("scale_off", "<i8"), ("shift_off", "<i8"),
     ("f0", "<f4"), ("f1", "<f4"), ("f2", "<f4"), ("f3", "<f4"),
     ("flops", "<i8"), ("tag", "<i4"), ("reserved", "<i4"),
+    ("pad_w_delta", "<i4"), ("out_step", "<i4"), ("out_oy", "<i4"), ("out_ox", "<i4"),
 ], align=True)
 BUF_DTYPE = np.dtype([("elems_per_frame", "<i8"), ("elem_bytes", "<i4"), ("zero_init", "<i4")], align=True)
 
@@ -74,6 +76,8 @@ SYMBOLS = [
     ("havc_net_run_ops", _I, [_P, _I, _I, _I]),
     ("havc_net_profile", _I, [_P, _I, _P, _I]),
     ("havc_deoldify_frames", _I, [_P, _P, _P, _F, _I, _P, _P, _I]),
+    ("havc_zhang_frames", _I, [_P, _P, _P, _P, _I, _I, _I]),
+    ("havc_pil_resize", _I, [_P, _P, _I, _I, _P, _I, _I, _I]),
     ("havc_blend", _I, [_P, _P, _P, _F, _P, _I, _I]),
     ("havc_chroma_post_process", _I, [_P, _P, _P, _P, _I, _I]),
     ("havc_chroma_stabilizer", _I, [_P, _P, _P, _D, _D, _P, _I, _I]),

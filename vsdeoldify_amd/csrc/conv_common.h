@@ -17,6 +17,13 @@ __device__ __forceinline__ void glds16(const void* g, half_t* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// output pixel index of GEMM row m (identity unless the conv scatters with an output step: ConvTranspose parity convs)
+__device__ __forceinline__ int64_t out_pixel(const ConvArgs& p, int m, int HoWo) {
+    if (p.oss == 1) return m;
+    const int b = m / HoWo, rem = m - b * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    return ((int64_t)(b * p.Ho * p.oss + ho * p.oss + p.ooy)) * (p.Wo * p.oss) + wo * p.oss + p.oox;
+}
+
 // one 16x16 accumulator fragment -> fused epilogue -> store.  lane owns pixel m, channels n..n+3.
 __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v acc, int m, int n, int HoWo) {
     if (m >= p.M || n >= p.Npad) return;
@@ -64,8 +71,9 @@ __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v a
         return;
     }
     if (n >= p.Co) return;
+    const int64_t mo = out_pixel(p, m, HoWo);
     if (p.flags & HAVC_F_RESIDUAL) {
-        const half4 rv = *reinterpret_cast<const half4*>(p.res + (int64_t)m * p.res_cpitch + p.res_coff + n);
+        const half4 rv = *reinterpret_cast<const half4*>(p.res + mo * p.res_cpitch + p.res_coff + n);
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
     }
@@ -83,7 +91,7 @@ __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v a
         half4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-        *reinterpret_cast<half4*>(y + (int64_t)m * p.y_cpitch + p.y_coff + n) = o;
+        *reinterpret_cast<half4*>(y + mo * p.y_cpitch + p.y_coff + n) = o;
     }
 }
 

@@ -11,18 +11,9 @@
 // chunk (zero for padding / M tail / K tail).  LDS tiles are [row][4 chunks] with the chunk index
 // XOR-swizzled by g(row>>2) so that ds_read_b128 fragment reads and ds_write_b128 staging writes are
 // bank-conflict free for the b128 lane groups of MI355X_MICROARCH.md §LDS.
-#include "kernels.h"
-#include "../../include/havc_mi355.h"
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float float4v __attribute__((ext_vector_type(4)));
+#include "conv_common.h"
 
 __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
-
-__device__ __forceinline__ float act(float v, bool leaky, float slope) {
-    return v > 0.f ? v : (leaky ? v * slope : 0.f);
-}
 
 template <int BM, int BN, int WM, int WN>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
@@ -65,7 +56,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
         const int rem = mm - b * HoWo;
         const int ho = rem / p.Wo;
         const int wo = rem - ho * p.Wo;
-        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+        const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad_w;
         a_hi0[it] = okm ? hi0 : -(1 << 20);          // rows past M never pass the bounds test
         a_wi0[it] = wi0;
         a_base[it] = ((int64_t)(b * p.Hi * p.Wi) + (int64_t)hi0 * p.Wi + wi0) * p.x_cpitch + p.x_coff;
@@ -145,87 +136,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
         __syncthreads();
     }
 
-    // ---- fused epilogue ------------------------------------------------------------------------
-    const bool leaky = p.flags & HAVC_F_LEAKY;
+    // ---- fused epilogue (conv_common.h) ----
 #pragma unroll
     for (int mi = 0; mi < FM; ++mi) {
         const int m = m0 + wm * (BM / WM) + mi * 16 + lr;
-        if (m >= p.M) continue;
-        int64_t out_base = 0;
-        if (p.flags & HAVC_F_OUT_PIXSHUF) {
-            const int b = m / HoWo;
-            const int rem = m - b * HoWo;
-            const int ho = rem / p.Wo;
-            const int wo = rem - ho * p.Wo;
-            out_base = ((int64_t)(b * 2 * p.Ho + 2 * ho) * (2 * p.Wo) + 2 * wo);  // pixel index of (dy=0,dx=0)
-        } else if (p.flags & HAVC_F_OUT_TRANSPOSED) {
-            const int b = m / HoWo;
-            out_base = (int64_t)b * p.Co * p.pix_pitch + (m - b * HoWo);
-        }
 #pragma unroll
-        for (int ni = 0; ni < FN; ++ni) {
-            const int n = n0 + wn * (BN / WN) + ni * 16 + lg * 4;
-            if (n >= p.Npad) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r];
-            if (p.bias) {
-                const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-                v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
-            }
-            if (p.flags & HAVC_F_OUT_RGB8) {
-                if (n == 0) {
-                    uint8_t* y = reinterpret_cast<uint8_t*>(p.y) + (int64_t)m * 3;
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        float s = 1.f / (1.f + __expf(-v[r]));
-                        s = s * (p.f1 - p.f0) + p.f0;
-                        s = s * p.istd[r] + p.mean[r];   // here istd[] carries std (denormalise)
-                        s = fminf(fmaxf(s, 0.f), 1.f);
-                        y[r] = (uint8_t)(int)(s * 255.f);
-                    }
-                }
-                continue;
-            }
-            if (p.flags & HAVC_F_RELU_PRE) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = act(v[r], leaky, p.f2);
-            }
-            if (p.flags & HAVC_F_AFFINE) {
-                const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
-                const float4 sh = *reinterpret_cast<const float4*>(p.shift + n);
-                v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
-                v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
-            }
-            if (n >= p.Co && !(p.flags & HAVC_F_OUT_PIXSHUF)) continue;
-            if (p.flags & HAVC_F_RESIDUAL) {
-                const half4 rv = *reinterpret_cast<const half4*>(p.res + (int64_t)m * p.res_cpitch + p.res_coff + n);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-            }
-            if (p.flags & HAVC_F_RELU_POST) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = act(v[r], leaky, p.f2);
-            }
-            half_t* y = reinterpret_cast<half_t*>(p.y);
-            if (p.flags & HAVC_F_OUT_TRANSPOSED) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) y[out_base + (int64_t)(n + r) * p.pix_pitch] = (half_t)v[r];
-            } else {
-                half4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (half_t)v[r];
-                int64_t off;
-                if (p.flags & HAVC_F_OUT_PIXSHUF) {
-                    const int q = n / p.Co, c = n - q * p.Co;  // Co = channels per sub-pixel
-                    if (q >= 4) continue;
-                    off = (out_base + (int64_t)(q >> 1) * (2 * p.Wo) + (q & 1)) * p.y_cpitch + p.y_coff + c;
-                } else {
-                    off = (int64_t)m * p.y_cpitch + p.y_coff + n;
-                }
-                *reinterpret_cast<half4*>(y + off) = o;
-            }
-        }
+        for (int ni = 0; ni < FN; ++ni) epilogue_frag(p, acc[ni][mi], m, n0 + wn * (BN / WN) + ni * 16 + lg * 4, HoWo);
     }
 }
 

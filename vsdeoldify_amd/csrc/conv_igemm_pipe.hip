@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
         const int rem = mm - b * HoWo;
         const int ho = rem / p.Wo;
         const int wo = rem - ho * p.Wo;
-        const int hi0 = ok ? ho * p.stride - p.pad : -16384, wi0 = wo * p.stride - p.pad;
+        const int hi0 = ok ? ho * p.stride - p.pad : -16384, wi0 = wo * p.stride - p.pad_w;
         a_hw0[it] = (hi0 & 0xffff) | (wi0 << 16);
         a_base[it] = (unsigned)((((int64_t)(b * p.Hi + hi0) * p.Wi + wi0) * p.x_cpitch + p.x_coff) * 2);
     }
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
                 for (int hp = 0; hp < 2; ++hp) {
                     const int m = m0 + wm * 128 + mi * 16 + (lane >> 3) + hp * 8;
                     rres[mi][hp] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                    if (do_res && m < p.M) rres[mi][hp] = *reinterpret_cast<const half8*>(p.res + (int64_t)m * p.res_cpitch + p.res_coff + n);
+                    if (do_res && m < p.M) rres[mi][hp] = *reinterpret_cast<const half8*>(p.res + out_pixel(p, m, HoWo) * p.res_cpitch + p.res_coff + n);
                 }
         }
 #pragma unroll
@@ -277,7 +277,7 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
                     off = ((int64_t)(b * 2 * p.Ho + 2 * ho + (q >> 1)) * (2 * p.Wo) + 2 * wo + (q & 1)) * p.y_cpitch + p.y_coff + cc;
                 } else {
                     if (n >= p.Co) continue;
-                    off = (int64_t)m * p.y_cpitch + p.y_coff + n;
+                    off = out_pixel(p, m, HoWo) * p.y_cpitch + p.y_coff + n;
                 }
                 half8 o = v;
                 if (p.flags & (HAVC_F_RESIDUAL | HAVC_F_RELU_POST)) {

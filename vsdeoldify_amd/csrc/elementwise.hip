@@ -147,3 +147,113 @@ int launch_prep_rgb8(const uint8_t* rgb, half_t* y0, int y0_cpitch, int y0_coff,
                        y1_cpitch, y1_coff, npix);
     return (int)hipGetLastError();
 }
+
+// ---- siggraph17 `x[:, :, ::2, ::2]` (colorizers/siggraph17.py:135-137) ----
+__global__ void subsample2_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int B, int Ho, int Wo, int Hi, int Wi,
+                                  int C8, int x_cpitch, int x_coff, int y_cpitch, int y_coff) {
+    const int64_t total = (int64_t)B * Ho * Wo * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        int64_t pix = i / C8;
+        const int wo = (int)(pix % Wo);
+        pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        *reinterpret_cast<half8*>(y + ((int64_t)(b * Ho + ho) * Wo + wo) * y_cpitch + y_coff + c8 * 8) =
+            *reinterpret_cast<const half8*>(x + ((int64_t)(b * Hi + 2 * ho) * Wi + 2 * wo) * x_cpitch + x_coff + c8 * 8);
+    }
+}
+
+int launch_subsample2(const half_t* x, half_t* y, int B, int Ho, int Wo, int Hi, int Wi, int C, int x_cpitch, int x_coff,
+                      int y_cpitch, int y_coff, hipStream_t s) {
+    const int C8 = C / 8;
+    hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for((int64_t)B * Ho * Wo * C8)), dim3(256), 0, s, x, y, B, Ho, Wo, Hi, Wi, C8,
+                       x_cpitch, x_coff, y_cpitch, y_coff);
+    return (int)hipGetLastError();
+}
+
+// ---- per-pixel C -> 2 projection in fp32: one wave per pixel, lanes stride the channels, wavefront-shuffle reductions.
+// mode & 1: softmax over the C logits first (eccv16: model_out(softmax(conv8_3)), eccv16.py:95);
+// mode & 2: + bias, tanh (siggraph17 model_out, siggraph17.py:113-114).  Result x mul, fp32 [npix][2].
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+__global__ void proj2_kernel(const half_t* __restrict__ x, int x_cpitch, int x_coff, int C, const float* __restrict__ w,
+                             const float* __restrict__ bias, int mode, float mul, float* __restrict__ out, int64_t npix) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t pix = wave; pix < npix; pix += nwaves) {
+        const half_t* xp = x + pix * x_cpitch + x_coff;
+        float v[8];
+        int n = 0;
+        float mx = -3.0e38f;
+        for (int c = lane; c < C; c += 64) { v[n] = (float)xp[c]; mx = fmaxf(mx, v[n]); ++n; }
+        float den = 1.f;
+        if (mode & 1) {
+            mx = wave_max(mx);
+            float s = 0.f;
+            n = 0;
+            for (int c = lane; c < C; c += 64) { v[n] = __expf(v[n] - mx); s += v[n]; ++n; }
+            den = wave_sum(s);
+        }
+        float a0 = 0.f, a1 = 0.f;
+        n = 0;
+        for (int c = lane; c < C; c += 64) { a0 += v[n] * w[c]; a1 += v[n] * w[C + c]; ++n; }
+        a0 = wave_sum(a0) / den;
+        a1 = wave_sum(a1) / den;
+        if (mode & 2) { a0 = tanhf(a0 + bias[0]); a1 = tanhf(a1 + bias[1]); }
+        if (lane == 0) { out[pix * 2] = a0 * mul; out[pix * 2 + 1] = a1 * mul; }
+    }
+}
+
+int launch_proj2(const half_t* x, int x_cpitch, int x_coff, int C, const float* w, const float* bias, int mode, float mul,
+                 float* out, int64_t npix, hipStream_t s) {
+    if (C > 512) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(proj2_kernel, dim3(grid_for(npix * 64)), dim3(256), 0, s, x, x_cpitch, x_coff, C, w, bias, mode, mul, out, npix);
+    return (int)hipGetLastError();
+}
+
+// ---- bilinear resize of a 2-channel fp32 map, PyTorch align_corners=False semantics (nn.Upsample(scale_factor=4,
+// mode='bilinear'), eccv16.py:85; F.interpolate(ab, size, 'bilinear'), util.py:50) ----
+__device__ __forceinline__ void bilin_src(int dst, float scale, int in, int& i0, int& i1, float& l) {
+    float src = ((float)dst + 0.5f) * scale - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i0 = i0 > in - 1 ? in - 1 : i0;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l = src - (float)i0;
+}
+
+__global__ void bilinear2_kernel(const float2* __restrict__ x, float2* __restrict__ y, int B, int Hi, int Wi, int Ho, int Wo,
+                                 float sh, float sw, float mul) {
+    const int64_t total = (int64_t)B * Ho * Wo;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int wo = (int)(i % Wo), ho = (int)((i / Wo) % Ho), b = (int)(i / ((int64_t)Wo * Ho));
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilin_src(ho, sh, Hi, y0, y1, ly);
+        bilin_src(wo, sw, Wi, x0, x1, lx);
+        const float2* base = x + (int64_t)b * Hi * Wi;
+        const float2 p00 = base[y0 * Wi + x0], p01 = base[y0 * Wi + x1], p10 = base[y1 * Wi + x0], p11 = base[y1 * Wi + x1];
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        float2 o;
+        o.x = (hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x)) * mul;
+        o.y = (hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y)) * mul;
+        y[i] = o;
+    }
+}
+
+int launch_bilinear2(const float* x, float* y, int B, int Hi, int Wi, int Ho, int Wo, float mul, hipStream_t s) {
+    hipLaunchKernelGGL(bilinear2_kernel, dim3(grid_for((int64_t)B * Ho * Wo)), dim3(256), 0, s, (const float2*)x, (float2*)y, B, Hi, Wi,
+                       Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, mul);
+    return (int)hipGetLastError();
+}

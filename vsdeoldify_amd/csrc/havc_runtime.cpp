@@ -159,6 +159,68 @@ int resize_rgb8(havc_ctx* c, const uint8_t* d_src, int sw, int sh, uint8_t* d_ds
     return HAVC_OK;
 }
 
+// ---- Pillow ImagingResample coefficient tables (libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc) ----
+struct PilTable { int ksize = 0; int* d_bounds = nullptr; int* d_kk = nullptr; };
+
+double pil_filter(int resample, double x) {
+    if (x < 0.0) x = -x;
+    if (resample == 2) return x < 1.0 ? 1.0 - x : 0.0;                       // BILINEAR
+    const double a = -0.5;                                                    // BICUBIC
+    if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+    if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+    return 0.0;
+}
+
+int build_pil_table(havc_ctx* c, int in_size, int out_size, int resample, PilTable* tb) {
+    const double fsupport = resample == 2 ? 1.0 : 2.0;
+    const double scale = (double)in_size / (double)out_size;
+    double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = fsupport * filterscale;
+    const int ksize = (int)std::ceil(support) * 2 + 1;
+    std::vector<int> bounds(out_size * 2), kk((size_t)out_size * ksize, 0);
+    std::vector<double> w(ksize);
+    const double ss = 1.0 / filterscale;
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = (xx + 0.5) * scale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        double ww = 0.0;
+        for (int x = 0; x < xmax; ++x) { w[x] = pil_filter(resample, (x + xmin - center + 0.5) * ss); ww += w[x]; }
+        for (int x = 0; x < xmax; ++x) {
+            const double v = ww != 0.0 ? w[x] / ww : w[x];
+            kk[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (double)(1 << 22)) : (int)(0.5 + v * (double)(1 << 22));
+        }
+        bounds[xx * 2] = xmin; bounds[xx * 2 + 1] = xmax;
+    }
+    tb->ksize = ksize;
+    HIP_TRY(c, hipMalloc((void**)&tb->d_bounds, bounds.size() * sizeof(int)));
+    HIP_TRY(c, hipMalloc((void**)&tb->d_kk, kk.size() * sizeof(int)));
+    HIP_TRY(c, hipMemcpy(tb->d_bounds, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(tb->d_kk, kk.data(), kk.size() * sizeof(int), hipMemcpyHostToDevice));
+    return HAVC_OK;
+}
+
+void free_pil_table(PilTable& t) { if (t.d_bounds) (void)hipFree(t.d_bounds); if (t.d_kk) (void)hipFree(t.d_kk); t = PilTable{}; }
+
+// Image.resize on device buffers; tmp must hold n*sh*dw*3 bytes
+int pil_resize_dev(havc_ctx* c, const uint8_t* d_src, int sw, int sh, uint8_t* d_tmp, uint8_t* d_dst, int dw, int dh, int n, int resample) {
+    PilTable th, tv;
+    int rc = HAVC_OK;
+    if (sw != dw && (rc = build_pil_table(c, sw, dw, resample, &th))) return rc;
+    if (sh != dh && (rc = build_pil_table(c, sh, dh, resample, &tv))) { free_pil_table(th); return rc; }
+    int e = launch_pil_resize_passes(d_src, sw, sh, d_tmp, d_dst, dw, dh, n, th.d_bounds, th.d_kk, th.ksize, tv.d_bounds, tv.d_kk,
+                                     tv.ksize, c->stream);
+    c->stats.launches += 2;
+    hipError_t se = hipStreamSynchronize(c->stream);       // tables are freed right away (tiny, rebuilt per call)
+    free_pil_table(th); free_pil_table(tv);
+    if (e) return hip_fail(c, (hipError_t)e, "pil resize");
+    if (se != hipSuccess) return hip_fail(c, se, "pil resize sync");
+    return HAVC_OK;
+}
+
 inline void* bufptr(havc_net* n, int id) {
     if (id == n->in_buf && n->in_override) return const_cast<void*>(n->in_override);
     if (id == n->out_buf && n->out_override) return n->out_override;
@@ -202,6 +264,8 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             a.Hi = op.Hi; a.Wi = op.Wi; a.C8 = op.Ci / 8;
             a.Ho = op.Ho; a.Wo = op.Wo; a.Co = op.Co;
             a.kh = op.kh; a.kw = op.kw; a.stride = op.stride; a.pad = op.pad; a.dil = op.dil;
+            a.pad_w = op.pad + op.pad_w_delta;
+            a.oss = op.out_step == 2 ? 2 : 1; a.ooy = op.out_oy; a.oox = op.out_ox;
             a.Kc = op.Kc; a.Npad = op.Npad;
             a.M = batch * op.Ho * op.Wo;
             a.flags = op.flags;
@@ -272,6 +336,21 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             e = launch_prep_rgb8((const uint8_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
                                  op.src2 >= 0 ? (half_t*)bufptr(n, op.src2) : nullptr, op.res_cpitch, op.res_coff,
                                  (int64_t)batch * op.Hi * op.Wi, s);
+            break;
+        case HAVC_OP_SUBSAMPLE2:
+            e = launch_subsample2((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), batch, op.Ho, op.Wo, op.Hi, op.Wi, op.Ci,
+                                  op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff, s);
+            break;
+        case HAVC_OP_PROJ2:
+            e = launch_proj2((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, op.Ci, wptr<float>(n, op.w_off),
+                             wptr<float>(n, op.bias_off), op.flags, op.f0, (float*)bufptr(n, op.dst), (int64_t)batch * op.Hi * op.Wi, s);
+            break;
+        case HAVC_OP_BILINEAR2:
+            e = launch_bilinear2((const float*)bufptr(n, op.src), (float*)bufptr(n, op.dst), batch, op.Hi, op.Wi, op.Ho, op.Wo, op.f0, s);
+            break;
+        case HAVC_OP_PREP_LAB_L:
+            e = launch_prep_lab_l((const uint8_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
+                                  (int64_t)batch * op.Hi * op.Wi, s);
             break;
         default:
             return fail(c, HAVC_E_INVALID, "unknown op type");
@@ -527,7 +606,7 @@ int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops,
             auto emit = [&](int kh, int kw, int c) {
                 int2 e;
                 e.x = ((kh * o.dil * o.Wi + kw * o.dil) * o.src_cpitch + c * 8) * 2;
-                e.y = ((kh * o.dil) & 0xffff) | ((kw * o.dil) << 16);
+                e.y = (int)(((unsigned)(kh * o.dil) & 0xffffu) | ((unsigned)(kw * o.dil) << 16));
                 host.push_back(e);
             };
             auto emit_seg = [&](int c_lo, int c_hi) {
@@ -701,6 +780,52 @@ static int host_filter_epilogue(havc_ctx* c, uint8_t* out, const uint8_t* dout, 
     HIP_TRY(c, hipMemcpyAsync(out, dout, nbytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return HAVC_OK;
+}
+
+int havc_pil_resize(havc_ctx* c, const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int resample) {
+    if (!c || !src || !dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0 || (resample != 2 && resample != 3))
+        return fail(c, HAVC_E_INVALID, "pil_resize: bad args (resample must be 2 = BILINEAR or 3 = BICUBIC)");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    int rc;
+    const size_t sb = (size_t)sw * sh * 3, tb = (size_t)sh * dw * 3, db = (size_t)dw * dh * 3;
+    if ((rc = ensure_scratch(c, 0, sb)) || (rc = ensure_scratch(c, 1, tb)) || (rc = ensure_scratch(c, 2, db))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->scratch[0], src, sb, hipMemcpyHostToDevice, c->stream));
+    if ((rc = pil_resize_dev(c, (uint8_t*)c->scratch[0], sw, sh, (uint8_t*)c->scratch[1], (uint8_t*)c->scratch[2], dw, dh, 1, resample))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(dst, c->scratch[2], db, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HAVC_OK;
+}
+
+int havc_zhang_frames(havc_ctx* c, havc_net* net, const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames, int width, int height) {
+    if (!c || !net || !rgb_in || !rgb_out || n_frames < 0 || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "zhang_frames: bad args");
+    if (net->ctx != c || net->bufdesc[net->out_buf].elem_bytes != 4) return fail(c, HAVC_E_INVALID, "zhang_frames: not a Zhang net of this ctx");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const int S = net->S, maxb = net->max_batch;
+    const size_t fb = (size_t)width * height * 3, sq = (size_t)S * S * 3;
+    int rc;
+    if ((rc = ensure_scratch(c, 0, fb * maxb)) || (rc = ensure_scratch(c, 1, (size_t)height * S * 3 * maxb)) ||
+        (rc = ensure_scratch(c, 2, sq * maxb)) || (rc = ensure_scratch(c, 3, fb * maxb))) return rc;
+    uint8_t *d_in = (uint8_t*)c->scratch[0], *d_tmp = (uint8_t*)c->scratch[1], *d_sq = (uint8_t*)c->scratch[2], *d_out = (uint8_t*)c->scratch[3];
+    Timer t(c);
+    for (int f0 = 0; f0 < n_frames; f0 += maxb) {
+        const int b = std::min(maxb, n_frames - f0);
+        HIP_TRY(c, hipMemcpyAsync(d_in, rgb_in + (size_t)f0 * fb, fb * b, hipMemcpyHostToDevice, c->stream));
+        if ((rc = pil_resize_dev(c, d_in, width, height, d_tmp, d_sq, S, S, b, 3))) return rc;                  // PIL BICUBIC -> 256x256
+        net->in_override = d_sq;
+        rc = run_ops_locked(net, 0, (int)net->ops.size(), b);
+        net->in_override = nullptr;
+        if (rc) return rc;
+        c->stats.total_flops += net->flops_per_frame * b;
+        int e = launch_zhang_post(d_in, (const float*)net->bufs[net->out_buf], S, S, d_out, b, width, height, c->stream);
+        c->stats.launches++;
+        if (e) return hip_fail(c, (hipError_t)e, "zhang post");
+        HIP_TRY(c, hipMemcpyAsync(rgb_out + (size_t)f0 * fb, d_out, fb * b, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->stats.frames += n_frames;
+    return t.finish();
 }
 
 int havc_blend(havc_ctx* c, const uint8_t* a, const uint8_t* b, float w, uint8_t* out, int width, int height) {

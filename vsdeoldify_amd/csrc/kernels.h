@@ -19,6 +19,8 @@ struct ConvArgs {
     int Hi, Wi, C8;        // input spatial, number of 8-channel chunks
     int Ho, Wo, Co;        // output spatial, channels stored (multiple of 8; 3 for RGB8)
     int kh, kw, stride, pad, dil;
+    int pad_w;             // pad along W (== pad except for ConvTranspose parity sub-convs)
+    int oss, ooy, oox;     // output pixel = (ho*oss + ooy, wo*oss + oox) of an (Ho*oss) x (Wo*oss) image (oss 1 or 2)
     int Kc, Npad;          // weight matrix: Npad rows, Kc chunks (multiple of 4)
     int M;                 // batch*Ho*Wo
     int flags;
@@ -48,6 +50,17 @@ int launch_copy_ch(const half_t* x, half_t* y, int64_t npix, int C, int x_cpitch
                    int y_coff, hipStream_t s);
 int launch_prep_rgb8(const uint8_t* rgb, half_t* y0, int y0_cpitch, int y0_coff, half_t* y1, int y1_cpitch,
                      int y1_coff, int64_t npix, hipStream_t s);
+int launch_subsample2(const half_t* x, half_t* y, int B, int Ho, int Wo, int Hi, int Wi, int C, int x_cpitch, int x_coff,
+                      int y_cpitch, int y_coff, hipStream_t s);
+int launch_proj2(const half_t* x, int x_cpitch, int x_coff, int C, const float* w, const float* bias, int mode, float mul,
+                 float* out, int64_t npix, hipStream_t s);
+int launch_bilinear2(const float* x, float* y, int B, int Hi, int Wi, int Ho, int Wo, float mul, hipStream_t s);
+int launch_prep_lab_l(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff, int64_t npix, hipStream_t s);
+// Pillow 8bpc resample passes (integer coefficient tables from the host) and the Zhang post-process
+int launch_pil_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* tmp, uint8_t* dst, int dw, int dh, int n_frames,
+                             const int* hb, const int* hk, int hks, const int* vb, const int* vk, int vks, hipStream_t s);
+int launch_zhang_post(const uint8_t* orig, const float* ab, int abH, int abW, uint8_t* out, int n_frames, int w, int h,
+                      hipStream_t s);
 // attention: qk [B][N][qk_pitch] (f at f_coff, g at g_coff, d channels each), vT [B][dv][npitch],
 // x/out NHWC; out = gamma*attn + x
 int launch_attention(const half_t* qk, int qk_pitch, int f_coff, int g_coff, int d, const half_t* vT, int dv,

@@ -1,0 +1,169 @@
+// Zhang et al. colorizers: colour-space pre/post kernels and Pillow's 8-bit resampler.
+//   rgb -> CIELAB L  and  Lab -> rgb follow scikit-image's float64 formulas (skimage/color/colorconv.py: rgb2xyz,
+//   xyz2lab, lab2xyz, xyz2rgb; D65 / 2 deg) as used by preprocess_img / postprocess_tens
+//   (vsdeoldify/colorization/colorizers/util.py:25-55).  fp64 on the device: HBM-bound kernels, and the reference
+//   truncates x*255, so fp32 colour math would flip LSBs for no speed gain.
+//   pil_resize_*: Pillow ImagingResample 8bpc (libImaging/Resample.c), integer coefficients from the host: bit-exact.
+#include "kernels.h"
+
+static inline int grid_for(int64_t work) {
+    int64_t b = (work + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ double srgb_to_linear(double c) { return c > 0.04045 ? pow((c + 0.055) / 1.055, 2.4) : c / 12.92; }
+
+__device__ __forceinline__ double lab_f(double t) { return t > 0.008856 ? cbrt(t) : 7.787 * t + 16.0 / 116.0; }
+
+__device__ __forceinline__ double rgb_to_L(int r, int g, int b) {
+    const double R = srgb_to_linear(r / 255.0), G = srgb_to_linear(g / 255.0), B = srgb_to_linear(b / 255.0);
+    const double y = 0.212671 * R + 0.715160 * G + 0.072169 * B;        // / 1.0 (D65 Yn)
+    return 116.0 * lab_f(y) - 16.0;
+}
+
+// model input: u8 RGB -> (float32(L) - 50) / 100 in channel 0 of an 8-channel fp16 pixel (channels 1..7 zero:
+// siggraph17's ab hints and mask are zeros, siggraph17.py:129-132)
+__global__ void prep_lab_l_kernel(const uint8_t* __restrict__ rgb, half_t* __restrict__ y, int y_cpitch, int y_coff, int64_t npix) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const float L = (float)rgb_to_L(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)0.f;
+        o[0] = (half_t)((L - 50.f) / 100.f);
+        *reinterpret_cast<half8*>(y + i * y_cpitch + y_coff) = o;
+    }
+}
+
+int launch_prep_lab_l(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff, int64_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(prep_lab_l_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, y, y_cpitch, y_coff, npix);
+    return (int)hipGetLastError();
+}
+
+// postprocess_tens + the uint8 cast of colorize_frame: L of the ORIGINAL frame, ab = bilinear(ab map -> frame size)
+// (identity when sizes match), lab2rgb in float64, uint8(clip(x*255, 0, 255)).
+__device__ __forceinline__ void bilin_src_f(int dst, float scale, int in, int& i0, int& i1, float& l) {
+    float src = ((float)dst + 0.5f) * scale - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i0 = i0 > in - 1 ? in - 1 : i0;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l = src - (float)i0;
+}
+
+__device__ __forceinline__ double lab_finv(double t) { return t > 0.2068966 ? t * t * t : (t - 16.0 / 116.0) / 7.787; }
+__device__ __forceinline__ double linear_to_srgb(double c) { return c > 0.0031308 ? 1.055 * pow(c, 1.0 / 2.4) - 0.055 : c * 12.92; }
+
+__global__ void zhang_post_kernel(const uint8_t* __restrict__ orig, const float2* __restrict__ ab, int abH, int abW,
+                                  uint8_t* __restrict__ out, int n_frames, int w, int h, float sh, float sw,
+                                  double m00, double m01, double m02, double m10, double m11, double m12, double m20, double m21,
+                                  double m22) {
+    const int64_t total = (int64_t)n_frames * w * h;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w), y = (int)((i / w) % h), f = (int)(i / ((int64_t)w * h));
+        const double L = (double)(float)rgb_to_L(orig[i * 3], orig[i * 3 + 1], orig[i * 3 + 2]);
+        const float2* base = ab + (int64_t)f * abH * abW;
+        float a, bb;
+        if (abH == h && abW == w) {
+            const float2 v = base[y * abW + x];
+            a = v.x; bb = v.y;
+        } else {
+            int y0, y1, x0, x1;
+            float ly, lx;
+            bilin_src_f(y, sh, abH, y0, y1, ly);
+            bilin_src_f(x, sw, abW, x0, x1, lx);
+            const float2 p00 = base[y0 * abW + x0], p01 = base[y0 * abW + x1], p10 = base[y1 * abW + x0], p11 = base[y1 * abW + x1];
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            a = hy * (hx * p00.x + lx * p01.x) + ly * (hx * p10.x + lx * p11.x);
+            bb = hy * (hx * p00.y + lx * p01.y) + ly * (hx * p10.y + lx * p11.y);
+        }
+        const double fy = (L + 16.0) / 116.0;
+        const double fx = (double)a / 500.0 + fy;
+        double fz = fy - (double)bb / 200.0;
+        fz = fz < 0.0 ? 0.0 : fz;
+        const double X = lab_finv(fx) * 0.95047, Y = lab_finv(fy), Z = lab_finv(fz) * 1.08883;
+        const double r = linear_to_srgb(m00 * X + m01 * Y + m02 * Z);
+        const double g = linear_to_srgb(m10 * X + m11 * Y + m12 * Z);
+        const double b = linear_to_srgb(m20 * X + m21 * Y + m22 * Z);
+        const double rc = fmin(fmax(r, 0.0), 1.0) * 255.0, gc = fmin(fmax(g, 0.0), 1.0) * 255.0, bc = fmin(fmax(b, 0.0), 1.0) * 255.0;
+        out[i * 3] = (uint8_t)(int)rc; out[i * 3 + 1] = (uint8_t)(int)gc; out[i * 3 + 2] = (uint8_t)(int)bc;
+    }
+}
+
+int launch_zhang_post(const uint8_t* orig, const float* ab, int abH, int abW, uint8_t* out, int n_frames, int w, int h,
+                      hipStream_t s) {
+    // rgb_from_xyz = inv(xyz_from_rgb) exactly as skimage computes it (scipy.linalg.inv of the 3x3 sRGB matrix)
+    static const double M[9] = {3.240481343200526, -1.5371515162713185, -0.4985363261688878,
+                                -0.9692549499965682, 1.8759900014898907, 0.04155592655829284,
+                                0.05564663913517716, -0.20404133836651123, 1.0573110696453443};
+    hipLaunchKernelGGL(zhang_post_kernel, dim3(grid_for((int64_t)n_frames * w * h)), dim3(256), 0, s, orig, (const float2*)ab, abH, abW,
+                       out, n_frames, w, h, (float)abH / (float)h, (float)abW / (float)w, M[0], M[1], M[2], M[3], M[4], M[5], M[6],
+                       M[7], M[8]);
+    return (int)hipGetLastError();
+}
+
+// ---- Pillow 8bpc resample: out = clip8((2^21 + sum_k px[xmin+k] * coef[k]) >> 22) ----
+__global__ void pil_resize_h_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const int* __restrict__ bounds,
+                                    const int* __restrict__ kk, int ksize, int sw, int dw, int64_t rows) {
+    const int64_t total = rows * dw;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % dw);
+        const int64_t row = i / dw;
+        const uint8_t* sp = src + row * sw * 3;
+        const int xmin = bounds[x * 2], xmax = bounds[x * 2 + 1];
+        const int* k = kk + (int64_t)x * ksize;
+        int r = 1 << 21, g = 1 << 21, b = 1 << 21;
+        for (int t = 0; t < xmax; ++t) {
+            const int c = k[t];
+            const uint8_t* p = sp + (xmin + t) * 3;
+            r += p[0] * c; g += p[1] * c; b += p[2] * c;
+        }
+        r >>= 22; g >>= 22; b >>= 22;
+        uint8_t* o = dst + i * 3;
+        o[0] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        o[1] = (uint8_t)(g < 0 ? 0 : (g > 255 ? 255 : g));
+        o[2] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
+    }
+}
+
+__global__ void pil_resize_v_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const int* __restrict__ bounds,
+                                    const int* __restrict__ kk, int ksize, int sh, int dh, int w, int n_frames) {
+    const int64_t total = (int64_t)n_frames * dh * w;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w), y = (int)((i / w) % dh), f = (int)(i / ((int64_t)w * dh));
+        const int ymin = bounds[y * 2], ymax = bounds[y * 2 + 1];
+        const int* k = kk + (int64_t)y * ksize;
+        const uint8_t* base = src + ((int64_t)f * sh * w + x) * 3;
+        int r = 1 << 21, g = 1 << 21, b = 1 << 21;
+        for (int t = 0; t < ymax; ++t) {
+            const int c = k[t];
+            const uint8_t* p = base + (int64_t)(ymin + t) * w * 3;
+            r += p[0] * c; g += p[1] * c; b += p[2] * c;
+        }
+        r >>= 22; g >>= 22; b >>= 22;
+        uint8_t* o = dst + i * 3;
+        o[0] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        o[1] = (uint8_t)(g < 0 ? 0 : (g > 255 ? 255 : g));
+        o[2] = (uint8_t)(b < 0 ? 0 : (b > 255 ? 255 : b));
+    }
+}
+
+// horizontal pass (skipped when sw == dw) into tmp [n][sh][dw][3], vertical pass (skipped when sh == dh) into dst
+int launch_pil_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* tmp, uint8_t* dst, int dw, int dh, int n_frames,
+                             const int* hb, const int* hk, int hks, const int* vb, const int* vk, int vks, hipStream_t s) {
+    const uint8_t* mid = src;
+    if (sw != dw) {
+        uint8_t* o = (sh != dh) ? tmp : dst;
+        hipLaunchKernelGGL(pil_resize_h_kernel, dim3(grid_for((int64_t)n_frames * sh * dw)), dim3(256), 0, s, src, o, hb, hk, hks, sw, dw,
+                           (int64_t)n_frames * sh);
+        mid = o;
+    }
+    if (sh != dh) {
+        hipLaunchKernelGGL(pil_resize_v_kernel, dim3(grid_for((int64_t)n_frames * dh * dw)), dim3(256), 0, s, mid, dst, vb, vk, vks, sh, dh,
+                           dw, n_frames);
+    } else if (sw == dw) {
+        (void)hipMemcpyAsync(dst, src, (size_t)n_frames * sh * sw * 3, hipMemcpyDeviceToDevice, s);
+    }
+    return (int)hipGetLastError();
+}

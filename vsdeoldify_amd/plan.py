@@ -200,15 +200,21 @@ class PlanBuilder:
         return len(self.ops) - 1
 
     def conv(self, name, pc, x, y, stride=1, pad=0, dil=1, flags=0, res=None, tag=None, f=(0, 0, 0, 0), Co=None,
-             aux0=0):
-        """y may be a View (fp16 NHWC / pixel-shuffled target) or a raw buffer id (RGB8 / transposed)."""
+             aux0=0, pad_w=None, out_hw=None, out_step=1, out_oy=0, out_ox=0):
+        """y may be a View (fp16 NHWC / pixel-shuffled target) or a raw buffer id (RGB8 / transposed).
+        out_step=2 scatters output pixel (ho, wo) to (2*ho + out_oy, 2*wo + out_ox) of y (ConvTranspose parity convs,
+        which also use dil=-1, asymmetric pad (pad_w) and an explicit out_hw)."""
         assert x.span == pc.Ci, (name, x.span, pc.Ci)
-        Ho = (x.H + 2 * pad - dil * (pc.kh - 1) - 1) // stride + 1
-        Wo = (x.W + 2 * pad - dil * (pc.kw - 1) - 1) // stride + 1
+        if out_hw is not None:
+            Ho, Wo = out_hw
+        else:
+            Ho = (x.H + 2 * pad - dil * (pc.kh - 1) - 1) // stride + 1
+            Wo = (x.W + 2 * pad - dil * (pc.kw - 1) - 1) // stride + 1
         kw = dict(type=nat.OP_CONV, flags=flags, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, Hi=x.H, Wi=x.W,
                   Ci=pc.Ci, Ho=Ho, Wo=Wo, kh=pc.kh, kw=pc.kw, stride=stride, pad=pad, dil=dil, Kc=pc.Kc,
                   Npad=pc.Npad, w_off=pc.w_off, bias_off=pc.bias_off, scale_off=pc.scale_off, shift_off=pc.shift_off,
                   f0=f[0], f1=f[1], f2=f[2], f3=f[3], aux0=aux0, aux1=pc.C8a,
+                  pad_w_delta=(0 if pad_w is None else pad_w - pad), out_step=out_step, out_oy=out_oy, out_ox=out_ox,
                   flops=2 * Ho * Wo * pc.Cout * pc.Cin * pc.kh * pc.kw)
         if isinstance(y, View):
             kw.update(dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch)
@@ -216,7 +222,7 @@ class PlanBuilder:
                 assert y.H == 2 * Ho and y.W == 2 * Wo and pc.Cout == 4 * y.C and y.C % 4 == 0, name
                 kw["Co"] = y.C
             else:
-                assert y.H == Ho and y.W == Wo and y.C == pc.Cout, (name, y.H, Ho, y.C, pc.Cout)
+                assert y.H == Ho * out_step and y.W == Wo * out_step and y.C == pc.Cout, (name, y.H, Ho, y.C, pc.Cout)
                 kw["Co"] = y.span
         else:
             kw.update(dst=y, Co=Co)
@@ -246,6 +252,24 @@ class PlanBuilder:
                         dst_coff=y.coff, dst_cpitch=y.cpitch, src2=qk.buf, res_coff=qk.coff, res_cpitch=qk.cpitch,
                         Hi=x.H, Wi=x.W, Ci=x.C, Ho=x.H, Wo=x.W, Co=x.C, aux0=d, aux1=vT_buf, Kc=npitch, f0=gamma,
                         flops=2 * N * N * d + 2 * N * N * x.C)
+
+    def subsample2(self, name, x, y):
+        assert y.H == (x.H + 1) // 2 and y.W == (x.W + 1) // 2 and x.span == y.span
+        return self._op(name, type=nat.OP_SUBSAMPLE2, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf,
+                        dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.span, Ho=y.H, Wo=y.W, Co=y.span)
+
+    def proj2(self, name, x, w_off, bias_off, mode, mul, out_buf):
+        """per pixel C -> 2 projection in fp32 (mode 1: softmax first, mode 2: + bias, tanh); out_buf: fp32 [H*W*2]."""
+        return self._op(name, type=nat.OP_PROJ2, flags=mode, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=out_buf,
+                        Hi=x.H, Wi=x.W, Ci=x.C, Ho=x.H, Wo=x.W, Co=2, w_off=w_off, bias_off=bias_off, f0=mul,
+                        flops=2 * x.H * x.W * x.C * 2)
+
+    def bilinear2(self, name, src_buf, Hi, Wi, dst_buf, Ho, Wo, mul):
+        return self._op(name, type=nat.OP_BILINEAR2, src=src_buf, dst=dst_buf, Hi=Hi, Wi=Wi, Ci=2, Ho=Ho, Wo=Wo, Co=2, f0=mul)
+
+    def prep_lab_l(self, name, in_buf, S, y):
+        return self._op(name, type=nat.OP_PREP_LAB_L, src=in_buf, dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=S, Wi=S,
+                        Ci=8, Ho=S, Wo=S, Co=8)
 
     def prep_rgb8(self, name, in_buf, S, y0, y1=None):
         kw = dict(type=nat.OP_PREP_RGB8, src=in_buf, dst=y0.buf, dst_coff=y0.coff, dst_cpitch=y0.cpitch, Hi=S, Wi=S,

@@ -174,3 +174,93 @@ def _synth_state_dict(arch, seed=0):
     out = OrderedDict((k, sd[k]) for k in spec)          # reference order
     assert all(v is not None for v in out.values())
     return out
+
+
+# ---- Zhang et al. colorizers ------------------------------------------------------------------------------------
+def _zstack(spec, p, cin, couts, bn=True, first=0, k=3):
+    i = first
+    for co in couts:
+        spec[f"{p}.{i}.weight"] = (co, cin, k, k)
+        spec[f"{p}.{i}.bias"] = (co,)
+        cin = co
+        i += 2
+    if bn:
+        _bn(spec, f"{p}.{i}", cin)
+    return cin
+
+
+def zhang_state_dict_spec(model):
+    """name -> shape in the reference's state_dict() order (eccv16.py:9-85, siggraph17.py:7-126)."""
+    spec = OrderedDict()
+    if model == "eccv16":
+        c = _zstack(spec, "model1", 1, [64, 64])
+        c = _zstack(spec, "model2", c, [128, 128])
+        c = _zstack(spec, "model3", c, [256, 256, 256])
+        for m in ("model4", "model5", "model6", "model7"):
+            c = _zstack(spec, m, c, [512, 512, 512])
+        spec["model8.0.weight"] = (512, 256, 4, 4); spec["model8.0.bias"] = (256,)
+        _zstack(spec, "model8", 256, [256, 256], bn=False, first=2)
+        spec["model8.6.weight"] = (313, 256, 1, 1); spec["model8.6.bias"] = (313,)
+        spec["model_out.weight"] = (2, 313, 1, 1)
+        return spec
+    c = _zstack(spec, "model1", 4, [64, 64])
+    c = _zstack(spec, "model2", c, [128, 128])
+    c = _zstack(spec, "model3", c, [256, 256, 256])
+    for m in ("model4", "model5", "model6", "model7"):
+        c = _zstack(spec, m, c, [512, 512, 512])
+    spec["model8up.0.weight"] = (512, 256, 4, 4); spec["model8up.0.bias"] = (256,)
+    _zstack(spec, "model8", 256, [256, 256], first=1)
+    spec["model9up.0.weight"] = (256, 128, 4, 4); spec["model9up.0.bias"] = (128,)
+    _zstack(spec, "model9", 128, [128], first=1)
+    spec["model10up.0.weight"] = (128, 128, 4, 4); spec["model10up.0.bias"] = (128,)
+    spec["model10.1.weight"] = (128, 128, 3, 3); spec["model10.1.bias"] = (128,)
+    spec["model3short8.0.weight"] = (256, 256, 3, 3); spec["model3short8.0.bias"] = (256,)
+    spec["model2short9.0.weight"] = (128, 128, 3, 3); spec["model2short9.0.bias"] = (128,)
+    spec["model1short10.0.weight"] = (128, 64, 3, 3); spec["model1short10.0.bias"] = (128,)
+    spec["model_class.0.weight"] = (529, 256, 1, 1); spec["model_class.0.bias"] = (529,)
+    spec["model_out.0.weight"] = (2, 128, 1, 1); spec["model_out.0.bias"] = (2,)
+    return spec
+
+
+def synth_zhang_state_dict(model, seed=0):
+    """seeded weights keeping activations O(1): He-scaled convs, BN stats matched to post-ReLU statistics."""
+    key = ("zhang", model, int(seed))
+    if key in _CACHE:
+        return _CACHE[key]
+    sd = OrderedDict()
+    for name, shape in zhang_state_dict_spec(model).items():
+        r = _rng(seed, "zhang." + model + "." + name)
+        leaf = name.rsplit(".", 1)[1]
+        if leaf == "num_batches_tracked":
+            sd[name] = np.array(100, np.int64)
+        elif leaf == "weight" and len(shape) == 4:
+            transposed = "up.0" in name or name == "model8.0.weight"
+            fan_in = (shape[0] if transposed else shape[1]) * shape[2] * shape[3]
+            if transposed:
+                fan_in //= 4                                      # each output pixel sees 2x2 of the 4x4 taps
+            gain = np.sqrt(2.0)
+            if "short" in name:
+                gain = 0.7
+            w = r.standard_normal(shape) * gain / np.sqrt(fan_in)
+            if name == "model8.6.weight":                         # eccv16 logits: peaky 313-way softmax
+                w = r.standard_normal(shape) * 4.0 / np.sqrt(fan_in)
+            if name == "model_out.weight":                        # eccv16 ab bin centres / 110
+                w = r.uniform(-1.0, 1.0, shape)
+            if name == "model_out.0.weight":                      # siggraph17: keep tanh out of saturation
+                w = r.standard_normal(shape) * 0.15 / np.sqrt(fan_in)
+                w -= w.mean(axis=1, keepdims=True)
+            sd[name] = w.astype(np.float32)
+        elif leaf == "bias" and (name[:-5] + ".running_mean") not in zhang_state_dict_spec(model):
+            sd[name] = (r.standard_normal(shape) * 0.05).astype(np.float32)
+        elif leaf == "weight":
+            sd[name] = r.uniform(0.8, 1.2, shape).astype(np.float32)
+        elif leaf == "bias":
+            sd[name] = (r.standard_normal(shape) * 0.1).astype(np.float32)
+        elif leaf == "running_mean":
+            sd[name] = (r.standard_normal(shape) * 0.1 + 0.5).astype(np.float32)          # BN follows a ReLU
+        elif leaf == "running_var":
+            sd[name] = (r.uniform(0.7, 1.3, shape) * 0.5).astype(np.float32)
+        else:
+            raise KeyError(name)
+    _CACHE[key] = sd
+    return sd
