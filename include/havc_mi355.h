@@ -169,6 +169,22 @@ int havc_chroma_post_process(havc_ctx* ctx, const uint8_t* color, const uint8_t*
 int havc_chroma_stabilizer(havc_ctx* ctx, const uint8_t* img_stable, const uint8_t* img_new, double alpha,
                            double weight, uint8_t* out, int width, int height);
 
+/* chroma_stabilizer_adaptive(img_stable, img_new, base_tol, max_extra, weight) — imfilters.py:202-269 (ChromaBoundAdaptiveMerge) */
+int havc_chroma_stabilizer_adaptive(havc_ctx* ctx, const uint8_t* img_stable, const uint8_t* img_new, double base_tol,
+                                    double max_extra, double weight, uint8_t* out, int width, int height);
+/* _chroma_temporal_limiter(cur_img, prv_img, alpha) — imfilters.py:638-666 (vs_chroma_limiter, vsfilters.py:473-487) */
+int havc_chroma_temporal_limiter(havc_ctx* ctx, const uint8_t* cur, const uint8_t* prv, double alpha, uint8_t* out, int width,
+                                 int height);
+/* _color_temporal_stabilizer(img_f, weight_list) — imfilters.py:680-705: n <= 9 frames, weights already / 100 */
+int havc_color_temporal_stabilizer(havc_ctx* ctx, const uint8_t* const* frames, const double* weights, int n, uint8_t* out,
+                                   int width, int height);
+/* image_luma_merge (mode 0, tresh = round(luma*255)) / w_image_luma_merge (mode 1: tresh, grad as computed by
+ * w_np_rgb_to_gray; mode 2: weight = luma/255; mode 3: weight = uint8(luma)/255 = image_luma_merge(luma=0)) — imfilters.py:66-100, nputils.py:101-253 (LumaMaskedMerge) */
+int havc_image_luma_merge(havc_ctx* ctx, const uint8_t* img_dark, const uint8_t* img_white, int mode, double tresh, double grad,
+                          uint8_t* out, int width, int height);
+/* get_image_luma — imfilters.py:597-601: mean of the cv2 Y plane, in [0, 255] (caller divides / rounds) (AdaptiveLumaMerge) */
+int havc_image_luma(havc_ctx* ctx, const uint8_t* img, int width, int height, double* mean_y);
+
 /* ---- device-resident clip pipeline (bench + multi-GPU shard path) -----------------
  * One call colours n_frames 1080p-class frames that are ALREADY in HBM:
  *   d_src [n][h][w][3] u8 gray-as-RGB  -> Spline64 squash to S x S (harness stand-in for zimg,

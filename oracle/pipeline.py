@@ -85,3 +85,88 @@ def colorize_frame_fullsize(sds, modelname, frame_u8, render_factor, video_weigh
     col = model_image_render(sds, modelname, sq, render_factor, video_weight, True)
     up = col if (w, h) == (S, S) else resample.resize_rgb8(col, w, h)
     return post_process(up, frame_u8)
+
+
+# ---- merge-method filters (vsslib/imfilters.py, nputils.py) restated ------------------------------------------------
+def _np_luma(img):
+    a = np.asarray(img)
+    return (a[:, :, 0] * 0.299 + a[:, :, 1] * 0.587 + a[:, :, 2] * 0.114).clip(0, 255)          # nputils.py:101-112
+
+
+def image_luma_merge(img_dark, img_white, luma=0):
+    """imfilters.py:66-77 -> np_rgb_to_gray (nputils.py:101-122) + np_image_mask_merge (nputils.py:196-211)."""
+    l2 = _np_luma(img_white)
+    if luma > 0:
+        mask = np.where(l2 > round(luma * 255), 255, 0).astype(np.uint8)
+    else:
+        mask = l2.astype(np.uint8)
+    mw = (mask / 255).astype(float)[..., None]
+    m = np.asarray(img_dark) * (1 - mw) + np.asarray(img_white) * mw
+    return m.clip(0, 255).astype(np.uint8)
+
+
+def w_image_luma_merge(img_dark, img_white, dark_luma=0.3, white_luma=0.9):
+    """imfilters.py:80-100 -> w_np_rgb_to_gray (nputils.py:141-183) + w_np_image_mask_merge (nputils.py:224-253)."""
+    if dark_luma >= white_luma:
+        return np.asarray(img_dark)
+    l2 = _np_luma(img_white)
+    if dark_luma > 0:
+        max_white = round(white_luma * 255)
+        tresh = min(round(dark_luma * 255), max_white - 10)
+        grad = round(1 / (max_white - tresh), 3)
+        lg = ((l2 - tresh) * grad).astype(float)
+        w = np.where(lg > 1.0, 1.0, lg).astype(np.float32)
+        w = np.where(w < 0.0, 0.0, w).astype(np.float32)
+    else:
+        w = np.divide(l2, 255.0)
+    mw = w.astype(float)[..., None]
+    m = np.multiply(np.asarray(img_dark), 1 - mw) + np.multiply(np.asarray(img_white), mw)
+    return m.clip(0, 255).astype(np.uint8)
+
+
+def get_image_luma(img, maxrange=255):
+    """imfilters.py:597-601."""
+    return round(float(np.mean(cvcolor.rgb2yuv_u8(img)[:, :, 0])) / maxrange, 6)
+
+
+def chroma_temporal_limiter(cur_img, prv_img, alpha=0.05):
+    """imfilters.py:638-666 (float64 bounds, cap then floor, truncating uint8 casts)."""
+    yuv1 = cvcolor.rgb2yuv_u8(prv_img)
+    yuv2 = cvcolor.rgb2yuv_u8(cur_img)
+    out = np.copy(yuv2)
+    for ch in (1, 2):
+        up, dn = np.multiply(yuv1[..., ch], 1 + alpha), np.multiply(yuv1[..., ch], 1 - alpha)
+        a = np.where(yuv2[..., ch] > up, up, yuv2[..., ch]).astype(np.uint8)
+        out[..., ch] = np.where(a < dn, dn, a).astype(np.uint8)
+    return cvcolor.yuv2rgb_u8(out)
+
+
+def chroma_stabilizer_adaptive(img_stable, img_new, base_tol=18, max_extra=22, weight=1.0):
+    """imfilters.py:202-269."""
+    yuv1 = cvcolor.rgb2yuv_u8(np.asarray(img_stable).astype(np.uint8))
+    y1 = yuv1[:, :, 0].astype(np.float32)
+    u1 = yuv1[:, :, 1].astype(np.int16) - 128
+    v1 = yuv1[:, :, 2].astype(np.int16) - 128
+    yuv2 = cvcolor.rgb2yuv_u8(np.asarray(img_new).astype(np.uint8))
+    u2 = yuv2[:, :, 1].astype(np.int16) - 128
+    v2 = yuv2[:, :, 2].astype(np.int16) - 128
+    texture = np.clip(np.abs(cvcolor.Laplacian(y1, cvcolor.CV_32F)) / 255.0, 0.0, 1.0)
+    tol = base_tol + max_extra * texture
+    u_m = np.clip(u2, np.clip(u1 - tol, -128, 127), np.clip(u1 + tol, -128, 127))
+    v_m = np.clip(v2, np.clip(v1 - tol, -128, 127), np.clip(v1 + tol, -128, 127))
+    yuv_out = np.stack([yuv1[:, :, 0], (u_m + 128).astype(np.uint8), (v_m + 128).astype(np.uint8)], axis=2)
+    rgb = cvcolor.yuv2rgb_u8(yuv_out)
+    return imaging.pil_blend(img_stable, rgb, weight) if weight < 1.0 else rgb
+
+
+def color_temporal_stabilizer(img_f, weight_list):
+    """imfilters.py:680-705."""
+    n = len(weight_list)
+    nh = round((n - 1) / 2)
+    yuv_new = cvcolor.rgb2yuv_u8(np.asarray(img_f[nh]))
+    yuv_m = np.multiply(yuv_new, weight_list[nh] / 100.0)
+    for i in list(range(0, nh)) + list(range(nh + 1, n)):
+        yuv_m += np.multiply(cvcolor.rgb2yuv_u8(np.asarray(img_f[i])), weight_list[i] / 100.0)
+    yuv_new[:, :, 1] = yuv_m[:, :, 1]
+    yuv_new[:, :, 2] = yuv_m[:, :, 2]
+    return cvcolor.yuv2rgb_u8(yuv_new)

@@ -81,6 +81,11 @@ SYMBOLS = [
     ("havc_blend", _I, [_P, _P, _P, _F, _P, _I, _I]),
     ("havc_chroma_post_process", _I, [_P, _P, _P, _P, _I, _I]),
     ("havc_chroma_stabilizer", _I, [_P, _P, _P, _D, _D, _P, _I, _I]),
+    ("havc_chroma_stabilizer_adaptive", _I, [_P, _P, _P, _D, _D, _D, _P, _I, _I]),
+    ("havc_chroma_temporal_limiter", _I, [_P, _P, _P, _D, _P, _I, _I]),
+    ("havc_color_temporal_stabilizer", _I, [_P, _P, _P, _I, _P, _I, _I]),
+    ("havc_image_luma_merge", _I, [_P, _P, _P, _I, _D, _D, _P, _I, _I]),
+    ("havc_image_luma", _I, [_P, _P, _I, _I, C.POINTER(C.c_double)]),
     ("havc_colorize_clip", _I, [_P, _P, _P, _F, _P, _P, _I, _I, _I]),
     ("havc_dev_alloc", _I, [_P, _SZ, C.POINTER(_P)]),
     ("havc_dev_free", _I, [_P, _P]),

@@ -173,3 +173,172 @@ int launch_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* dst, int d
                        v_start, v_w, v_taps, sh, dh, dw, n_frames);
     return (int)hipGetLastError();
 }
+
+// ---- luma-masked merges (imfilters.py:66-100 -> nputils.py:101-253).  luma = R*0.299 + G*0.587 + B*0.114 in float64,
+// exactly as numpy evaluates it ((R*0.299 + G*0.587) + B*0.114).  mode 0: image_luma_merge — hard mask, pixel of
+// img_white where luma(img_white) > tresh else img_dark.  mode 1: w_image_luma_merge — weight
+// w = float32(clip((luma - tresh) * grad, 0, 1)) (mode 2: w = luma / 255), out = uint8(img_dark*(1-w) + img_white*w). ----
+__global__ void luma_merge_kernel(const uint8_t* __restrict__ dark, const uint8_t* __restrict__ white, int mode, double tresh,
+                                  double grad, uint8_t* __restrict__ out, int64_t npix) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r2 = white[i * 3], g2 = white[i * 3 + 1], b2 = white[i * 3 + 2];
+        double luma = ((double)r2 * 0.299 + (double)g2 * 0.587) + (double)b2 * 0.114;
+        luma = fmin(fmax(luma, 0.0), 255.0);
+        if (mode == 0) {
+            const bool wsel = luma > tresh;
+            out[i * 3] = wsel ? (uint8_t)r2 : dark[i * 3];
+            out[i * 3 + 1] = wsel ? (uint8_t)g2 : dark[i * 3 + 1];
+            out[i * 3 + 2] = wsel ? (uint8_t)b2 : dark[i * 3 + 2];
+            continue;
+        }
+        double wgt;
+        if (mode == 1) {
+            double lg = (luma - tresh) * grad;
+            float w32 = (float)(lg > 1.0 ? 1.0 : lg);          // array_max(.., 1.0).astype(float32)
+            w32 = w32 < 0.0f ? 0.0f : w32;                      // array_min(.., 0.0).astype(float32)
+            wgt = (double)w32;
+        } else if (mode == 2) {
+            wgt = luma / 255.0;                                 // w_np_rgb_to_gray(as_weight=True, dark_luma <= 0)
+        } else {
+            wgt = (double)(int)luma / 255.0;                    // image_luma_merge(luma=0): mask stored as uint8, then / 255
+        }
+        const double wb = 1.0 - wgt;
+        const int white_px[3] = {r2, g2, b2};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double p1 = (double)dark[i * 3 + c] * wb;
+            const double p2 = (double)white_px[c] * wgt;
+            const double v = fmin(fmax(p1 + p2, 0.0), 255.0);
+            out[i * 3 + c] = (uint8_t)(int)v;
+        }
+    }
+}
+
+int launch_luma_merge(const uint8_t* dark, const uint8_t* white, int mode, double tresh, double grad, uint8_t* out, int64_t npix,
+                      hipStream_t s) {
+    hipLaunchKernelGGL(luma_merge_kernel, dim3(grid_for(npix)), dim3(256), 0, s, dark, white, mode, tresh, grad, out, npix);
+    return (int)hipGetLastError();
+}
+
+// ---- get_image_luma (imfilters.py:597-601): sum of cv2 Y over the frame (exact integer sum; the host divides) ----
+__global__ void luma_sum_kernel(const uint8_t* __restrict__ img, unsigned long long* __restrict__ sum, int64_t npix) {
+    unsigned long long acc = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        int y, u, v;
+        rgb2yuv(img[i * 3], img[i * 3 + 1], img[i * 3 + 2], y, u, v);
+        acc += (unsigned)y;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
+}
+
+int launch_luma_sum(const uint8_t* img, unsigned long long* d_sum, int64_t npix, hipStream_t s) {
+    (void)hipMemsetAsync(d_sum, 0, sizeof(unsigned long long), s);
+    hipLaunchKernelGGL(luma_sum_kernel, dim3(grid_for(npix) > 1024 ? 1024 : grid_for(npix)), dim3(256), 0, s, img, d_sum, npix);
+    return (int)hipGetLastError();
+}
+
+// ---- _chroma_temporal_limiter (imfilters.py:638-666): U,V of cur clipped into [U_prv(1-a), U_prv(1+a)] with FLOAT64
+// bounds (not truncated to uint8 first, unlike chroma_stabilizer), Y,U,V otherwise from cur ----
+__global__ void chroma_temporal_limiter_kernel(const uint8_t* __restrict__ cur, const uint8_t* __restrict__ prv, double alpha,
+                                               uint8_t* __restrict__ out, int64_t npix) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        int y1, u1, v1, y2, u2, v2, r, g, b;
+        rgb2yuv(prv[i * 3], prv[i * 3 + 1], prv[i * 3 + 2], y1, u1, v1);
+        rgb2yuv(cur[i * 3], cur[i * 3 + 1], cur[i * 3 + 2], y2, u2, v2);
+        const double u_up = (double)u1 * (1.0 + alpha), u_dn = (double)u1 * (1.0 - alpha);
+        const double v_up = (double)v1 * (1.0 + alpha), v_dn = (double)v1 * (1.0 - alpha);
+        if ((double)u2 > u_up) u2 = (int)(uint8_t)(int)u_up;
+        if ((double)u2 < u_dn) u2 = (int)(uint8_t)(int)u_dn;
+        if ((double)v2 > v_up) v2 = (int)(uint8_t)(int)v_up;
+        if ((double)v2 < v_dn) v2 = (int)(uint8_t)(int)v_dn;
+        yuv2rgb(y2, u2, v2, r, g, b);
+        out[i * 3] = (uint8_t)r; out[i * 3 + 1] = (uint8_t)g; out[i * 3 + 2] = (uint8_t)b;
+    }
+}
+
+int launch_chroma_temporal_limiter(const uint8_t* cur, const uint8_t* prv, double alpha, uint8_t* out, int64_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(chroma_temporal_limiter_kernel, dim3(grid_for(npix)), dim3(256), 0, s, cur, prv, alpha, out, npix);
+    return (int)hipGetLastError();
+}
+
+// ---- chroma_stabilizer_adaptive (imfilters.py:202-269): per-pixel chroma tolerance base_tol + max_extra * texture,
+// texture = clip(|Laplacian(Y_stable)| / 255, 0, 1) (cv2.Laplacian CV_32F, aperture 1: [[0,1,0],[1,-4,1],[0,1,0]],
+// BORDER_REFLECT_101), on signed chroma (U-128, V-128); float32 like the numpy code ----
+__device__ __forceinline__ float y_at(const uint8_t* __restrict__ img, int x, int y, int w, int h) {
+    x = x < 0 ? -x : (x >= w ? 2 * w - 2 - x : x);
+    y = y < 0 ? -y : (y >= h ? 2 * h - 2 - y : y);
+    const uint8_t* p = img + ((int64_t)y * w + x) * 3;
+    int yy, u, v;
+    rgb2yuv(p[0], p[1], p[2], yy, u, v);
+    return (float)yy;
+}
+
+__global__ void chroma_stabilizer_adaptive_kernel(const uint8_t* __restrict__ st, const uint8_t* __restrict__ nw, float base_tol,
+                                                  float max_extra, float weight, int do_blend, uint8_t* __restrict__ out, int w, int h) {
+    const int64_t npix = (int64_t)w * h;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w), y = (int)(i / w);
+        int y1, u1, v1, y2, u2, v2, r, g, b;
+        const int sr = st[i * 3], sg = st[i * 3 + 1], sb = st[i * 3 + 2];
+        rgb2yuv(sr, sg, sb, y1, u1, v1);
+        rgb2yuv(nw[i * 3], nw[i * 3 + 1], nw[i * 3 + 2], y2, u2, v2);
+        const float lap = ((y_at(st, x, y - 1, w, h) + y_at(st, x, y + 1, w, h)) + (y_at(st, x - 1, y, w, h) + y_at(st, x + 1, y, w, h))) -
+                          4.0f * (float)y1;
+        float tex = fabsf(lap) / 255.0f;
+        tex = fminf(fmaxf(tex, 0.0f), 1.0f);
+        const float tol = base_tol + max_extra * tex;
+        const float su1 = (float)(u1 - 128), sv1 = (float)(v1 - 128);
+        const float ul = fminf(fmaxf(su1 - tol, -128.f), 127.f), uh = fminf(fmaxf(su1 + tol, -128.f), 127.f);
+        const float vl = fminf(fmaxf(sv1 - tol, -128.f), 127.f), vh = fminf(fmaxf(sv1 + tol, -128.f), 127.f);
+        const float um = fminf(fmaxf((float)(u2 - 128), ul), uh), vm = fminf(fmaxf((float)(v2 - 128), vl), vh);
+        yuv2rgb(y1, (int)(uint8_t)(int)(um + 128.f), (int)(uint8_t)(int)(vm + 128.f), r, g, b);
+        if (do_blend) {
+            r = blend1((uint8_t)sr, (uint8_t)r, weight);
+            g = blend1((uint8_t)sg, (uint8_t)g, weight);
+            b = blend1((uint8_t)sb, (uint8_t)b, weight);
+        }
+        out[i * 3] = (uint8_t)r; out[i * 3 + 1] = (uint8_t)g; out[i * 3 + 2] = (uint8_t)b;
+    }
+}
+
+int launch_chroma_stabilizer_adaptive(const uint8_t* stable, const uint8_t* inew, float base_tol, float max_extra, float weight,
+                                      uint8_t* out, int w, int h, hipStream_t s) {
+    hipLaunchKernelGGL(chroma_stabilizer_adaptive_kernel, dim3(grid_for((int64_t)w * h)), dim3(256), 0, s, stable, inew, base_tol, max_extra,
+                       weight, weight < 1.0f ? 1 : 0, out, w, h);
+    return (int)hipGetLastError();
+}
+
+// ---- _color_temporal_stabilizer (imfilters.py:680-705): U,V = weighted mean over the frame window (float64, centre frame
+// first, then the others in list order), truncated to uint8; Y of the centre frame ----
+struct FrameList { const uint8_t* f[9]; double w[9]; int n, centre; };
+
+__global__ void color_temporal_stabilizer_kernel(FrameList fl, uint8_t* __restrict__ out, int64_t npix) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        int yc, u, v, y, r, g, b;
+        const uint8_t* pc = fl.f[fl.centre] + i * 3;
+        rgb2yuv(pc[0], pc[1], pc[2], yc, u, v);
+        double um = (double)u * fl.w[fl.centre], vm = (double)v * fl.w[fl.centre];
+        for (int k = 0; k < fl.n; ++k) {
+            if (k == fl.centre) continue;
+            const uint8_t* p = fl.f[k] + i * 3;
+            rgb2yuv(p[0], p[1], p[2], y, u, v);
+            um += (double)u * fl.w[k];
+            vm += (double)v * fl.w[k];
+        }
+        yuv2rgb(yc, (int)(uint8_t)(int)um, (int)(uint8_t)(int)vm, r, g, b);
+        out[i * 3] = (uint8_t)r; out[i * 3 + 1] = (uint8_t)g; out[i * 3 + 2] = (uint8_t)b;
+    }
+}
+
+int launch_color_temporal_stabilizer(const uint8_t* const* frames, const double* weights, int n, uint8_t* out, int64_t npix,
+                                     hipStream_t s) {
+    if (n < 1 || n > 9) return (int)hipErrorInvalidValue;
+    FrameList fl;
+    fl.n = n;
+    fl.centre = (int)lrint((n - 1) / 2.0);      // Python round((n-1)/2): banker's rounding, like lrint
+    for (int k = 0; k < n; ++k) { fl.f[k] = frames[k]; fl.w[k] = weights[k]; }
+    hipLaunchKernelGGL(color_temporal_stabilizer_kernel, dim3(grid_for(npix)), dim3(256), 0, s, fl, out, npix);
+    return (int)hipGetLastError();
+}

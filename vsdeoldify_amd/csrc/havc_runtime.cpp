@@ -863,6 +863,78 @@ int havc_chroma_stabilizer(havc_ctx* c, const uint8_t* img_stable, const uint8_t
                                 launch_chroma_stabilizer(da, db, alpha, (float)weight, dout, (int64_t)width * height, c->stream));
 }
 
+int havc_chroma_stabilizer_adaptive(havc_ctx* c, const uint8_t* img_stable, const uint8_t* img_new, double base_tol, double max_extra,
+                                    double weight, uint8_t* out, int width, int height) {
+    if (!c || !img_stable || !img_new || !out || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "chroma_stabilizer_adaptive: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t nb = (size_t)width * height * 3;
+    uint8_t *da, *db, *dout;
+    int rc = host_filter_prologue(c, img_stable, img_new, nb, &da, &db, &dout);
+    if (rc) return rc;
+    return host_filter_epilogue(c, out, dout, nb,
+                                launch_chroma_stabilizer_adaptive(da, db, (float)base_tol, (float)max_extra, (float)weight, dout, width, height, c->stream));
+}
+
+int havc_chroma_temporal_limiter(havc_ctx* c, const uint8_t* cur, const uint8_t* prv, double alpha, uint8_t* out, int width, int height) {
+    if (!c || !cur || !prv || !out || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "chroma_temporal_limiter: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t nb = (size_t)width * height * 3;
+    uint8_t *da, *db, *dout;
+    int rc = host_filter_prologue(c, cur, prv, nb, &da, &db, &dout);
+    if (rc) return rc;
+    return host_filter_epilogue(c, out, dout, nb, launch_chroma_temporal_limiter(da, db, alpha, dout, (int64_t)width * height, c->stream));
+}
+
+int havc_image_luma_merge(havc_ctx* c, const uint8_t* img_dark, const uint8_t* img_white, int mode, double tresh, double grad, uint8_t* out,
+                          int width, int height) {
+    if (!c || !img_dark || !img_white || !out || width <= 0 || height <= 0 || mode < 0 || mode > 3) return fail(c, HAVC_E_INVALID, "image_luma_merge: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t nb = (size_t)width * height * 3;
+    uint8_t *da, *db, *dout;
+    int rc = host_filter_prologue(c, img_dark, img_white, nb, &da, &db, &dout);
+    if (rc) return rc;
+    return host_filter_epilogue(c, out, dout, nb, launch_luma_merge(da, db, mode, tresh, grad, dout, (int64_t)width * height, c->stream));
+}
+
+int havc_image_luma(havc_ctx* c, const uint8_t* img, int width, int height, double* mean_y) {
+    if (!c || !img || !mean_y || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "image_luma: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t nb = (size_t)width * height * 3;
+    int rc;
+    if ((rc = ensure_scratch(c, 0, nb)) || (rc = ensure_scratch(c, 6, 256))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->scratch[0], img, nb, hipMemcpyHostToDevice, c->stream));
+    int e = launch_luma_sum((const uint8_t*)c->scratch[0], (unsigned long long*)c->scratch[6], (int64_t)width * height, c->stream);
+    c->stats.launches++;
+    if (e) return hip_fail(c, (hipError_t)e, "luma sum");
+    unsigned long long sum = 0;
+    HIP_TRY(c, hipMemcpyAsync(&sum, c->scratch[6], sizeof(sum), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *mean_y = (double)sum / ((double)width * (double)height);
+    return HAVC_OK;
+}
+
+int havc_color_temporal_stabilizer(havc_ctx* c, const uint8_t* const* frames, const double* weights, int n, uint8_t* out, int width, int height) {
+    if (!c || !frames || !weights || !out || n < 1 || n > 9 || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "color_temporal_stabilizer: bad args (1..9 frames)");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t nb = (size_t)width * height * 3;
+    int rc;
+    if ((rc = ensure_scratch(c, 0, nb * n)) || (rc = ensure_scratch(c, 2, nb))) return rc;
+    const uint8_t* d_frames[9];
+    for (int k = 0; k < n; ++k) {
+        if (!frames[k]) return fail(c, HAVC_E_INVALID, "color_temporal_stabilizer: NULL frame");
+        uint8_t* d = (uint8_t*)c->scratch[0] + nb * k;
+        HIP_TRY(c, hipMemcpyAsync(d, frames[k], nb, hipMemcpyHostToDevice, c->stream));
+        d_frames[k] = d;
+    }
+    return host_filter_epilogue(c, out, (uint8_t*)c->scratch[2], nb,
+                                launch_color_temporal_stabilizer(d_frames, weights, n, (uint8_t*)c->scratch[2], (int64_t)width * height, c->stream));
+}
+
 int havc_colorize_clip(havc_ctx* c, havc_net* video, havc_net* second, float video_weight, const uint8_t* d_src,
                        uint8_t* d_dst, int n_frames, int width, int height) {
     if (!c || !video || !d_src || !d_dst || n_frames < 0 || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "colorize_clip: bad args");

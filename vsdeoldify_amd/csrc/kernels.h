@@ -72,6 +72,14 @@ int launch_blend_u8(const uint8_t* a, const uint8_t* b, float w, uint8_t* out, i
 int launch_yuv_merge(const uint8_t* color, const uint8_t* orig, uint8_t* out, int64_t npix, hipStream_t s);
 int launch_chroma_stabilizer(const uint8_t* stable, const uint8_t* inew, double alpha, float weight, uint8_t* out,
                              int64_t npix, hipStream_t s);
+int launch_luma_merge(const uint8_t* dark, const uint8_t* white, int mode, double tresh, double grad, uint8_t* out, int64_t npix,
+                      hipStream_t s);
+int launch_luma_sum(const uint8_t* img, unsigned long long* d_sum, int64_t npix, hipStream_t s);
+int launch_chroma_temporal_limiter(const uint8_t* cur, const uint8_t* prv, double alpha, uint8_t* out, int64_t npix, hipStream_t s);
+int launch_chroma_stabilizer_adaptive(const uint8_t* stable, const uint8_t* inew, float base_tol, float max_extra, float weight,
+                                      uint8_t* out, int w, int h, hipStream_t s);
+int launch_color_temporal_stabilizer(const uint8_t* const* frames, const double* weights, int n, uint8_t* out, int64_t npix,
+                                     hipStream_t s);
 // separable polyphase resample of interleaved u8 RGB (tap tables from the host; Spline64 = harness stand-in
 // for zimg resize.Spline64).  orig != null fuses chroma_post_process (luma of orig, chroma of the resampled).
 int launch_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int n_frames, float* tmp,
