@@ -58,3 +58,24 @@ def test_gpu_filters_bit_exact_vs_golden_and_oracle(ctx, g):
     assert np.array_equal(F.chroma_stabilizer_adaptive_np(ctx, x, y, 18, 22, 0.6), pipeline.chroma_stabilizer_adaptive(x, y, 18, 22, 0.6))
     assert np.array_equal(F.chroma_temporal_limiter_np(ctx, x, y, 0.1), pipeline.chroma_temporal_limiter(x, y, 0.1))
     assert abs(F.image_luma_np(ctx, x) / 255 - pipeline.get_image_luma(x)) < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_merge_methods(ctx, g):
+    """per-frame bodies of HAVC_merge methods 2/3/4/5/7 (mcomb.py) against the oracle composition of the same filters."""
+    from oracle import imaging
+    from vsdeoldify_amd import mcomb
+    a, b = g["a"], g["b"]
+    assert np.array_equal(mcomb.simple_merge(a, b, 0.4), imaging.pil_blend(a, b, 0.4))
+    assert np.array_equal(mcomb.constrained_chroma_merge(a, b, 0.5, 0.2, red_fix=False), pipeline.chroma_stabilizer(a, b, 0.2, 0.5))
+    assert np.array_equal(mcomb.chroma_bound_adaptive_merge(a, b, False, 14, 18, 0.5), pipeline.chroma_stabilizer_adaptive(a, b, 14, 18, 0.5))
+    masked = pipeline.w_image_luma_merge(a, b, 0.4, 0.7)
+    assert np.array_equal(mcomb.luma_masked_merge(a, b, None, 0.4, 0.7, 0.5), imaging.pil_blend(a, masked, 0.5))
+    luma = pipeline.get_image_luma(b)
+    w = max(0.5 * pow(luma / 0.6, 1.0), 0.15) if luma < 0.6 else 0.5
+    assert np.array_equal(mcomb.adaptive_luma_merge(a, b, 0.6, 1.0, 0.5, 0.15), imaging.pil_blend(a, b, w))
+    # bright frames pass the red-fix gate unchanged; dark ones are refused loudly (image_tweak not provided yet)
+    bright = np.clip(a.astype(int) + 120, 0, 255).astype(np.uint8)
+    assert np.array_equal(mcomb.constrained_chroma_merge(bright, bright, 0.5, 0.2, True), pipeline.chroma_stabilizer(bright, bright, 0.2, 0.5))
+    with pytest.raises(NotImplementedError):
+        mcomb.constrained_chroma_merge(a // 8, b // 8, 0.5, 0.2, True)

@@ -1,0 +1,62 @@
+"""Per-frame bodies of the HAVC model-combination methods (vsdeoldify/vsslib/mcomb.py `merge_frame` selectors), on
+uint8 HWC frames, backed by the HIP filters.  The VapourSynth wrappers (ModifyFrame plumbing, scene-change
+passthrough) stay in the reference; these are the functions they would call once per frame.
+
+  method 2  SimpleMerge               mcomb.py:206-223   Image.blend(a, b, w)
+  method 3  ConstrainedChromaMerge    mcomb.py:333-367   chroma_stabilizer (+ dark-frame red fix)
+  method 4  LumaMaskedMerge           mcomb.py:238-271   (w_)image_luma_merge + weighted merge
+  method 5  AdaptiveLumaMerge         mcomb.py:289-314   frame-mean luma -> weight -> blend
+  method 7  ChromaBoundAdaptiveMerge  mcomb.py:370-437   chroma_stabilizer_adaptive (+ red fix)
+The dark-frame "red fix" (luma <= 0.3) needs image_tweak (PIL ImageEnhance + HSV hue ranges, imfilters.py:463-504),
+which is not on the GPU yet: frames that would take it raise NotImplementedError so the caller can fall back.
+"""
+import numpy as np
+
+from . import imfilters as F
+from .render import get_context
+
+
+def simple_merge(a, b, weight=0.5, device_index=0):
+    if weight == 0.0:
+        return np.asarray(a)
+    if weight == 1.0:
+        return np.asarray(b)
+    return F.blend_np(get_context(device_index), a, b, weight)
+
+
+def _red_fix(ctx, img_stab):
+    luma = round(F.image_luma_np(ctx, img_stab) / 255, 6)
+    if luma > 0.3:
+        return img_stab
+    raise NotImplementedError(f"dark frame (luma {luma}): red fix needs image_tweak, not provided by vsdeoldify_amd yet")
+
+
+def constrained_chroma_merge(a, b, clipb_weight=0.5, chroma_threshold=0.2, red_fix=True, device_index=0):
+    ctx = get_context(device_index)
+    img_stab = F.chroma_stabilizer_np(ctx, a, b, chroma_threshold, clipb_weight)
+    return _red_fix(ctx, img_stab) if red_fix else img_stab
+
+
+def chroma_bound_adaptive_merge(a, b, red_fix=True, base_tol=14, max_extra=18, clipb_weight=0.5, device_index=0):
+    ctx = get_context(device_index)
+    img_stab = F.chroma_stabilizer_adaptive_np(ctx, a, b, base_tol, max_extra, clipb_weight)
+    return _red_fix(ctx, img_stab) if red_fix else img_stab
+
+
+def luma_masked_merge(a, b, c=None, luma_mask_limit=0.4, luma_white_limit=0.7, clipm_weight=0.5, device_index=0):
+    """a = clipa frame, b = clipb frame, c = de-saturated clipa frame (== a when luma_mask_sat >= 1)."""
+    from PIL import Image
+    c = a if c is None else c
+    pc, pb = Image.fromarray(np.asarray(c)), Image.fromarray(np.asarray(b))
+    if luma_mask_limit == luma_white_limit:
+        masked = np.asarray(F.image_luma_merge(pc, pb, luma_mask_limit, device_index=device_index))
+    else:
+        masked = np.asarray(F.w_image_luma_merge(pc, pb, luma_mask_limit, luma_white_limit, device_index=device_index))
+    return simple_merge(a, masked, clipm_weight, device_index) if clipm_weight < 1.0 else masked
+
+
+def adaptive_luma_merge(a, b, luma_threshold=0.6, alpha=1.0, clipb_weight=0.5, min_weight=0.15, device_index=0):
+    ctx = get_context(device_index)
+    luma = round(F.image_luma_np(ctx, b) / 255, 6)
+    w = max(clipb_weight * pow(luma / luma_threshold, alpha), min_weight) if luma < luma_threshold else clipb_weight
+    return F.blend_np(ctx, a, b, w)
