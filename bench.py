@@ -133,6 +133,13 @@ def main():
     c = 259
     conv_flops = 2.0 * args.batch * S * S * c * c * 9            # algorithmic FLOPs of ONE tail res-conv launch
     achieved = conv_flops / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
+    traffic = None                                   # HBM bytes per launch from PMC passes on this same command
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_tail_conv_pmc.json")))
+        if pmc.get("frames_per_launch") == args.batch:
+            traffic = pmc["traffic_bytes_per_launch"]
+    except Exception:
+        pass
     out = {
         "metric": METRIC, "value": round(total_frames / elapsed, 3), "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -143,7 +150,7 @@ def main():
                    "parallelism": f"frame-sharded x{world}, weight replica per GPU, no collective"},
         "whole_path_tflops": round(total_frames * 2759.32e9 / elapsed / 1e12 / world, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                     "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                     "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
                      "kernel": "conv_igemm_kernel (layers.10 res-block 3x3 259->259 @560x560, 2 launches/pass)",
                      "launches_timed": int(launches.value), "avg_launch_ms": round(avg_ms.value, 4),
                      "flops_per_launch": conv_flops},

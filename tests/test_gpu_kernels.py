@@ -63,6 +63,10 @@ GLDS_CASES = [  # (cfg, B, Cin, Cout, k, stride, pad, H, W): software-pipelined 
     (60, 1, 32, 100, 3, 1, 2, 20, 20), (60, 1, 768, 512, 3, 1, 1, 20, 20), (60, 1, 40, 256, 5, 1, 2, 18, 18),
     (60, 1, 3, 64, 7, 2, 3, 48, 48), (60, 2, 400, 300, 3, 1, 1, 17, 15), (60, 1, 2048, 512, 1, 1, 0, 5, 5),
     (61, 1, 259, 259, 3, 1, 1, 32, 32), (61, 2, 264, 259, 3, 1, 1, 21, 13), (61, 3, 259, 259, 3, 1, 1, 9, 11),
+    # smaller tile geometries of the same kernel: 128x128 (70), 128x256 (71), 64x128 (72)
+    (70, 1, 320, 256, 3, 1, 1, 24, 24), (70, 2, 64, 128, 1, 1, 0, 19, 21), (70, 1, 128, 256, 3, 2, 1, 33, 33), (70, 1, 3, 64, 7, 2, 3, 48, 48),
+    (71, 1, 768, 512, 3, 1, 1, 20, 20), (71, 2, 2048, 512, 1, 1, 0, 5, 5), (71, 1, 40, 300, 3, 1, 1, 18, 18),
+    (72, 1, 256, 256, 3, 1, 1, 18, 18), (72, 3, 96, 128, 3, 1, 1, 9, 11), (72, 1, 1024, 256, 1, 1, 0, 35, 35),
     (0, 2, 259, 259, 3, 1, 1, 112, 112), (0, 1, 320, 256, 3, 1, 1, 210, 210),      # heuristic picks the pipelined kernel
 ]
 

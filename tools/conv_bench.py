@@ -19,9 +19,23 @@ SHAPES = {  # name: (Cin, Cout, k, stride, pad, H, W, flags)
     "mid1": (4096, 2048, 3, 1, 1, 18, 18, nat.F_RELU_PRE | nat.F_AFFINE),
     "l8ps": (256, 1024, 1, 1, 0, 280, 280, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),
     "l7ps": (512, 1024, 1, 1, 0, 140, 140, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),
+    "l8nops": (256, 1024, 1, 1, 0, 280, 280, nat.F_RELU_PRE),
+    "l7nops": (512, 1024, 1, 1, 0, 140, 140, nat.F_RELU_PRE),
     "enc3x3_35": (256, 256, 3, 1, 1, 35, 35, nat.F_RELU_PRE),
     "enc1x1_35": (1024, 256, 1, 1, 0, 35, 35, nat.F_RELU_PRE),
     "enc3x3_140": (64, 64, 3, 1, 1, 140, 140, nat.F_RELU_PRE),
+    "e3_c3_1x1": (256, 1024, 1, 1, 0, 35, 35, nat.F_RELU_POST),
+    "e4_c2_3x3": (512, 512, 3, 1, 1, 18, 18, nat.F_RELU_PRE),
+    "e4_c1_1x1": (2048, 512, 1, 1, 0, 18, 18, nat.F_RELU_PRE),
+    "e4_c3_1x1": (512, 2048, 1, 1, 0, 18, 18, nat.F_RELU_POST),
+    "e2_c2_3x3": (128, 128, 3, 1, 1, 70, 70, nat.F_RELU_PRE),
+    "e2_c1_1x1": (512, 128, 1, 1, 0, 70, 70, nat.F_RELU_PRE),
+    "e2_c3_1x1": (128, 512, 1, 1, 0, 70, 70, nat.F_RELU_POST),
+    "e1_c3_1x1": (64, 256, 1, 1, 0, 140, 140, nat.F_RELU_POST),
+    "e1_c1_1x1": (256, 64, 1, 1, 0, 140, 140, nat.F_RELU_PRE),
+    "attn_qk": (512, 128, 1, 1, 0, 70, 70, 0),
+    "l4ps": (2048, 2048, 1, 1, 0, 18, 18, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),
+    "l5ps": (512, 2048, 1, 1, 0, 35, 35, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),
 }
 
 

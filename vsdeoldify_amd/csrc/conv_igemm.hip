@@ -168,19 +168,31 @@ static int pick_config(const ConvArgs& a) {
 
 bool conv_pipe_supported(const ConvArgs& a, int extra);
 
-// 0 = register-staged kernels below; 60 / 61 = software-pipelined 256x256 kernel (conv_igemm_pipe.hip)
+// 0 = register-staged kernels below; 60 / 61 / 70 / 72 = software-pipelined LDS-DMA kernel (conv_igemm_pipe.hip) with
+// 256x256(+16) / 128x128 / 64x128 tiles.  Thresholds from tools/conv_bench.py sweeps (profiles/r1_convbench_tiles.txt):
+// the big tile needs >= 160 blocks to fill 256 CUs; the 18x18..70x70 encoder / bottleneck layers want many small tiles.
 static int pick_pipe(const ConvArgs& a) {
     if (a.flags & HAVC_F_OUT_RGB8) return 0;
     const int extra = (a.Npad % 256 == 16) ? 1 : 0;
-    if (a.Npad < 256 || (a.Npad % 256 != 0 && !extra)) return 0;
     if (!conv_pipe_supported(a, extra)) return 0;
-    const int64_t blocks = (int64_t)((a.M + 255) / 256) * ((a.Npad - 16 * extra) / 256);
-    if (blocks < 160) return 0;                       // too few 256x256 tiles to fill 256 CUs: smaller tiles win
-    return 60 + extra;
+    if (a.Npad >= 256 && (a.Npad % 256 == 0 || extra)) {
+        const int64_t blocks = (int64_t)((a.M + 255) / 256) * ((a.Npad - 16 * extra) / 256);
+        if (blocks >= 160) return 60 + extra;
+    }
+    if (a.Npad % 128 == 0) {
+        const int64_t blocks128 = (int64_t)((a.M + 127) / 128) * (a.Npad / 128);
+        return blocks128 >= 200 ? 70 : 72;
+    }
+    return 0;
 }
 
 const char* conv_config_name(const ConvArgs& a) {
-    if (pick_pipe(a)) return pick_pipe(a) == 61 ? "pipe256x272" : "pipe256x256";
+    switch (pick_pipe(a)) {
+        case 60: return "pipe256x256";
+        case 61: return "pipe256x272";
+        case 70: return "pipe128x128";
+        case 72: return "pipe64x128";
+    }
     static const char* names[] = {"128x128", "128x64", "64x64", "128x272", "128x304", "128x16", "64x128"};
     return names[pick_config(a)];
 }

@@ -24,15 +24,27 @@
 
 namespace {
 
-constexpr int BM = 256, BN = 256, NW = 8;     // 8 waves as 2 (M) x 4 (N)
-constexpr int FM = 8, FN = 4;                 // 16-pixel / 16-channel fragments per wave
+constexpr int FN = 4;                         // 16-channel fragments per wave: every wave owns 64 output channels
 constexpr unsigned OOB = 0xF0000000u;         // voffset beyond every descriptor range -> DMA writes zeros
 
-template <int EXTRA>
+// Tile geometry: WM x WN waves, each wave (FM*16 pixels) x 64 channels.
+//   <2,4,8>: 256 x 256, 8 waves  (the big decoder / tail convs)
+//   <2,2,4>: 128 x 128, 4 waves  (encoder / bottleneck layers: more, smaller tiles; 2 blocks per CU)
+//   <1,4,8>: 128 x 256, 4 waves  (few pixels, many channels: the 18x18 / 35x35 layers)
+template <int WM, int WN, int FM, int EXTRA>
 struct Geo {
+    static constexpr int NW = WM * WN;
+    static constexpr int BM = WM * FM * 16, BN = WN * 64;
+    static constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;      // 1-KiB DMA pieces per wave per stage
+    static constexpr int NS = 2 * FM;                                 // steps per stage
+    static constexpr int PIECES = A_IT + B_IT;
     static constexpr int ROWS = BM + BN + 16 * EXTRA;
     static constexpr int STAGE_BYTES = ROWS * 128;
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
+    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0, "pieces must divide over an even number of waves");
+    static_assert(FM >= FN, "second-half weight fragments are prefetched during the first FM steps");
+    static_assert(!EXTRA || (WM == 2 && WN == 4 && FM == 8), "extra columns: 256x256 tile only");
+    static_assert(NW * FM * 2048 <= LDS_BYTES, "LDS epilogue image");
 };
 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
@@ -45,15 +57,16 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 
 // ABL (profiling only, wrong results): 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no MFMA, 5 = no epilogue
 // (Tried and dropped: staggering the DMA slots of the two waves sharing a SIMD -- 3-12 % slower, profiles/r1_conv_ablation.txt.)
-template <int EXTRA, int ABL = 0>
-__global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
-    using G = Geo<EXTRA>;
+template <int WM, int WN, int FM, int EXTRA, int ABL = 0>
+__global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p) {
+    using G = Geo<WM, WN, FM, EXTRA>;
+    constexpr int NW = G::NW, BM = G::BM, BN = G::BN, A_IT = G::A_IT, B_IT = G::B_IT, NS = G::NS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 15, lg = lane >> 4;
 
     const int nwg = gridDim.x;
@@ -72,14 +85,14 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.w), 0, p.w_bytes, 0x00020000);
 
     // ---- DMA lane role: row lane>>3 of an 8-row piece, LDS position lane&7, source chunk c = pos ^ f(row) ----
-    // wave w owns pieces w, w+8, w+16, w+24 (same parity => same f) of both the pixel and the weight tile.
+    // wave w owns pieces w, w+NW, w+2NW, ... (same parity => same f) of both the pixel and the weight tile.
     const int r8 = lane >> 3;
     const int c = (lane & 7) ^ ((((wave & 1) << 2) + (r8 >> 1)) & 7);
 
-    unsigned a_base[4];      // byte offset of (pixel row, tap 0, channel 0) in the input buffer (wraps when hi0/wi0 < 0)
-    int a_hw0[4];            // hi0 | wi0 << 16 (signed 16-bit each)
+    unsigned a_base[A_IT];   // byte offset of (pixel row, tap 0, channel 0) in the input buffer (wraps when hi0/wi0 < 0)
+    int a_hw0[A_IT];         // hi0 | wi0 << 16 (signed 16-bit each)
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < A_IT; ++it) {
         const int row = (wave + it * NW) * 8 + r8;
         const int m = m0 + row;
         const bool ok = m < p.M;
@@ -92,9 +105,9 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
         a_hw0[it] = (hi0 & 0xffff) | (wi0 << 16);
         a_base[it] = (unsigned)((((int64_t)(b * p.Hi + hi0) * p.Wi + wi0) * p.x_cpitch + p.x_coff) * 2);
     }
-    unsigned b_voff[4];
+    unsigned b_voff[B_IT];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) {
+    for (int it = 0; it < B_IT; ++it) {
         const int n = n0 + (wave + it * NW) * 8 + r8;
         b_voff[it] = n < p.Npad ? (unsigned)((n * p.Kc + c) * 16) : OOB;
     }
@@ -114,7 +127,7 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
 
     // ---- fragment read addresses (bytes): per-lane constants + immediates; the second K half is base ^ 64 ----
     const int fsw = (lr >> 1) & 7;
-    const int a_l0 = (wm * 128 + lr) * 128 + ((lg ^ fsw) << 4), a_l1 = a_l0 ^ 64;
+    const int a_l0 = (wm * (FM * 16) + lr) * 128 + ((lg ^ fsw) << 4), a_l1 = a_l0 ^ 64;
     const int b_l0 = BM * 128 + (wn * 64 + lr) * 128 + ((lg ^ fsw) << 4), b_l1 = b_l0 ^ 64;
     const int x_l0 = (BM + BN + lr) * 128 + ((lg ^ fsw) << 4), x_l1 = x_l0 ^ 64;
 
@@ -129,16 +142,15 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
     // ---- prologue: stage 0 ----
     int2 e_nx = kt_lane[0];
 #pragma unroll
-    for (int it = 0; it < 4; ++it) dma16(rx, smem + (wave + it * NW) * 1024, a_voff(it, e_nx), 0);
+    for (int it = 0; it < A_IT; ++it) dma16(rx, smem + (wave + it * NW) * 1024, a_voff(it, e_nx), 0);
 #pragma unroll
-    for (int it = 0; it < 4; ++it) dma16(rw, smem + BM * 128 + (wave + it * NW) * 1024, b_voff[it], 0);
+    for (int it = 0; it < B_IT; ++it) dma16(rw, smem + BM * 128 + (wave + it * NW) * 1024, b_voff[it], 0);
     if (EXTRA && extra_wave) dma16(rw, smem + (BM + BN) * 128 + (wave & 1) * 1024, x_voff, 0);
     e_nx = kt_lane[(KT > 1 ? 1 : 0) * 8];
 
     // one 64-deep stage; MORE (compile time): the next stage exists and its DMA is issued from inside this one
     auto stage = [&](int kt, auto more_tag) {
         constexpr bool MORE = decltype(more_tag)::value && ABL != 1;
-        constexpr int GRP = 0;
         const char* cur = smem + (kt & 1) * G::STAGE_BYTES;
         char* nxt = smem + ((kt & 1) ^ 1) * G::STAGE_BYTES;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -155,23 +167,26 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
         int2 e_n2 = e_nx;
 
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {                 // step s: K half s>>3, pixel fragment s&7
-            const int ks = s >> 3, mi = s & 7;
-            if (s + 2 < 16 && ABL != 2) {              // (1) pixel fragment two steps ahead
+        for (int s = 0; s < NS; ++s) {                 // step s: K half s / FM, pixel fragment s % FM
+            const int ks = s / FM, mi = s % FM;
+            if (s + 2 < NS && ABL != 2) {              // (1) pixel fragment two steps ahead
                 const int s2 = s + 2;
-                af[s2 % 3] = *reinterpret_cast<const half8*>(cur + ((s2 >> 3) ? a_l1 : a_l0) + (s2 & 7) * 2048);
+                af[s2 % 3] = *reinterpret_cast<const half8*>(cur + ((s2 / FM) ? a_l1 : a_l0) + (s2 % FM) * 2048);
             }
-            if (s >= 4 && s < 8 && ABL != 2)           // (2) weight fragments of the second K half
-                bf[1][s - 4] = *reinterpret_cast<const half8*>(cur + b_l1 + (s - 4) * 2048);
+            if (ks == 0 && mi >= FM - FN && ABL != 2)  // (2) weight fragments of the second K half
+                bf[1][mi - (FM - FN)] = *reinterpret_cast<const half8*>(cur + b_l1 + (mi - (FM - FN)) * 2048);
             if (EXTRA && s == 3) xb[1] = *reinterpret_cast<const half8*>(cur + x_l1);
-            if (MORE) {                                // (3) one DMA piece of the next stage
-                const int sa = GRP ? s - 8 : s, sb = GRP ? s - 12 : s - 4;     // pixel / weight piece index at this step
-                if (sa >= 0 && sa < 4) dma16(rx, nxt + (wave + sa * NW) * 1024, a_voff(sa, e_nx), 0);
-                if (sb >= 0 && sb < 4) dma16(rw, nxt + BM * 128 + (wave + sb * NW) * 1024, b_voff[sb], (unsigned)(kt + 1) * 128u);
-                if (EXTRA && s == (GRP ? 7 : 8)) {
+            if (MORE) {                                // (3) the DMA pieces of the next stage, spread over the steps
+                constexpr int P = G::PIECES;
+#pragma unroll
+                for (int q = (s * P) / NS; q < ((s + 1) * P) / NS; ++q) {
+                    if (q < A_IT) dma16(rx, nxt + (wave + q * NW) * 1024, a_voff(q, e_nx), 0);
+                    else dma16(rw, nxt + BM * 128 + (wave + (q - A_IT) * NW) * 1024, b_voff[q - A_IT], (unsigned)(kt + 1) * 128u);
+                }
+                if (EXTRA && s == NS - 3) {
                     if (extra_wave) dma16(rw, nxt + (BM + BN) * 128 + (wave & 1) * 1024, x_voff, (unsigned)(kt + 1) * 128u);
                 }
-                if (s == (GRP ? 6 : 9)) e_n2 = kt_lane[(kt + 2 < KT ? kt + 2 : KT - 1) * 8];   // K table entry, stage after next
+                if (s == NS - 2) e_n2 = kt_lane[(kt + 2 < KT ? kt + 2 : KT - 1) * 8];    // K table entry, stage after next
             }
             const half8 a = af[ABL == 2 ? s % 2 : s % 3];                     // (4) the MFMAs of this step
 #pragma unroll
@@ -210,13 +225,13 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
     if (!lds_epi) {
 #pragma unroll
         for (int mi = 0; mi < FM; ++mi) {
-            const int m = m0 + wm * 128 + mi * 16 + lr;
+            const int m = m0 + wm * (FM * 16) + mi * 16 + lr;
 #pragma unroll
             for (int ni = 0; ni < FN; ++ni) epilogue_frag(p, acc[ni][mi], m, n0 + wn * 64 + ni * 16 + lg * 4, HoWo);
         }
     } else {
         __syncthreads();                                   // every wave is done reading the last stage
-        char* img = smem + wave * 16384;
+        char* img = smem + wave * (FM * 2048);
         const bool leaky = p.flags & HAVC_F_LEAKY;
         const int nw0 = n0 + wn * 64;                      // first channel of this wave's 64-channel slice
 #pragma unroll
@@ -255,7 +270,7 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
             for (int mi = 0; mi < FM; ++mi)
 #pragma unroll
                 for (int hp = 0; hp < 2; ++hp) {
-                    const int m = m0 + wm * 128 + mi * 16 + (lane >> 3) + hp * 8;
+                    const int m = m0 + wm * (FM * 16) + mi * 16 + (lane >> 3) + hp * 8;
                     rres[mi][hp] = half8{0, 0, 0, 0, 0, 0, 0, 0};
                     if (do_res && m < p.M) rres[mi][hp] = *reinterpret_cast<const half8*>(p.res + out_pixel(p, m, HoWo) * p.res_cpitch + p.res_coff + n);
                 }
@@ -265,7 +280,7 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
 #pragma unroll
             for (int hp = 0; hp < 2; ++hp) {
                 const int px = (lane >> 3) + hp * 8;
-                const int m = m0 + wm * 128 + mi * 16 + px;
+                const int m = m0 + wm * (FM * 16) + mi * 16 + px;
                 const half8 v = *reinterpret_cast<const half8*>(img + mi * 2048 + px * 128 + ((ch ^ (px & 7)) << 4));
                 if (m >= p.M) continue;
                 half_t* y = reinterpret_cast<half_t*>(p.y);
@@ -296,39 +311,43 @@ __global__ void __launch_bounds__(512) conv_pipe_kernel(const ConvArgs p) {
     if (EXTRA && has_extra) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int m = m0 + wm * 128 + (wn * 2 + i) * 16 + lr;
+            const int m = m0 + wm * (FM * 16) + (wn * 2 + i) * 16 + lr;
             epilogue_frag(p, accx[i], m, n0 + BN + lg * 4, HoWo);
         }
     }
 }
 
-template <int EXTRA, int ABL = 0>
+template <int WM, int WN, int FM, int EXTRA, int ABL = 0>
 static int launch_pipe(const ConvArgs& a, hipStream_t s) {
+    using G = Geo<WM, WN, FM, EXTRA>;
     if ((a.Kc & 7) || !a.ktab || a.x_bytes == 0 || a.x_bytes >= OOB || a.w_bytes >= OOB) return (int)hipErrorInvalidValue;
-    const int MT = (a.M + BM - 1) / BM, NT = (a.Npad - 16 * EXTRA + BN - 1) / BN;
-    constexpr int LDS = Geo<EXTRA>::LDS_BYTES;
+    const int MT = (a.M + G::BM - 1) / G::BM, NT = (a.Npad - 16 * EXTRA + G::BN - 1) / G::BN;
+    constexpr int LDS = G::LDS_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pipe_kernel<EXTRA, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pipe_kernel<WM, WN, FM, EXTRA, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         attr_set = true;
     }
-    hipLaunchKernelGGL((conv_pipe_kernel<EXTRA, ABL>), dim3(MT * NT), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, ABL>), dim3(MT * NT), dim3(G::NW * 64), LDS, s, a);
     return (int)hipGetLastError();
 }
 
 bool conv_pipe_supported(const ConvArgs& a, int extra) {
-    return !(a.Kc & 7) && a.ktab && a.x_bytes != 0 && a.x_bytes < OOB && a.w_bytes < OOB && (!extra || (a.Npad - 16) % BN == 0);
+    return !(a.Kc & 7) && a.ktab && a.x_bytes != 0 && a.x_bytes < OOB && a.w_bytes < OOB && (!extra || (a.Npad - 16) % 256 == 0);
 }
 
 int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
     switch (cfg) {
-        case 60: return launch_pipe<0>(a, s);
-        case 61: return launch_pipe<1>(a, s);
-        case 62: return launch_pipe<0, 1>(a, s);
-        case 63: return launch_pipe<0, 2>(a, s);
-        case 64: return launch_pipe<0, 4>(a, s);
-        case 65: return launch_pipe<0, 5>(a, s);
+        case 60: return launch_pipe<2, 4, 8, 0>(a, s);        // 256 x 256
+        case 61: return launch_pipe<2, 4, 8, 1>(a, s);        // 256 x (256 + 16)
+        case 62: return launch_pipe<2, 4, 8, 0, 1>(a, s);     // ablations of cfg 60 (profiling only)
+        case 63: return launch_pipe<2, 4, 8, 0, 2>(a, s);
+        case 64: return launch_pipe<2, 4, 8, 0, 4>(a, s);
+        case 65: return launch_pipe<2, 4, 8, 0, 5>(a, s);
+        case 70: return launch_pipe<2, 2, 4, 0>(a, s);        // 128 x 128, 4 waves
+        case 71: return launch_pipe<1, 4, 8, 0>(a, s);        // 128 x 256, 4 waves
+        case 72: return launch_pipe<1, 2, 4, 0>(a, s);        // 64 x 128, 2 waves
     }
     return (int)hipErrorInvalidValue;
 }
