@@ -1,4 +1,4 @@
-// Shared device helpers of the LDS-DMA convolution kernels (conv_igemm_glds.hip, conv_igemm_pipe.hip).
+// Shared device helpers of the convolution kernels (conv_igemm.hip, conv_igemm_pipe.hip): the fused epilogue.
 #pragma once
 #include "kernels.h"
 #include "../../include/havc_mi355.h"
@@ -6,16 +6,6 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
-
-// 16 bytes of zeros: LDS-DMA lanes that fall on padding / M tail / K tail fetch these (no per-lane zero fill in DMA)
-static __device__ __attribute__((aligned(16))) unsigned int havc_zero_page[4] = {0, 0, 0, 0};
-
-__device__ __forceinline__ int swz2(int row) { return (4 - ((row >> 2) & 3)) & 3; }
-
-__device__ __forceinline__ void glds16(const void* g, half_t* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
 
 // output pixel index of GEMM row m (identity unless the conv scatters with an output step: ConvTranspose parity convs)
 __device__ __forceinline__ int64_t out_pixel(const ConvArgs& p, int m, int HoWo) {
