@@ -66,6 +66,10 @@ enum havc_op_type {
 #define HAVC_F_OUT_TRANSPOSED 0x20 /* store as [b][n][pix_pitch] (V^T for attention)                       */
 #define HAVC_F_OUT_RGB8 0x40      /* SigmoidRange(f0,f1) -> *std+mean -> clamp01 -> trunc(*255) -> u8 RGB   */
 #define HAVC_F_LEAKY 0x80         /* RELU_* use LeakyReLU(f2)                                              */
+#define HAVC_F_FUSE_RGB8 0x100    /* the conv output is NOT stored: a following 1x1 conv to 3 channels (fp32 weights at
+                                     scale_off [3][Npad], bias at shift_off [3]) + OUT_RGB8 maths run in the epilogue and
+                                     write u8 RGB to buffer aux0 (layers.10.1 + layers.11 + layers.12 of the generator);
+                                     needs Npad == 272 (one 256+16 tile holds every channel of a pixel)              */
 
 typedef struct havc_op {
     int32_t type, flags;

@@ -106,3 +106,20 @@ def test_batch_matches_single(ctx, sds):
         assert np.array_equal(raw_gpu(ctx, rt, frames), np.concatenate([raw_gpu(ctx, rt, f[None]) for f in frames]))
     finally:
         rt.close()
+
+
+def test_fused_final_conv_matches_unfused(ctx, sds):
+    """HAVC_F_FUSE_RGB8 (layers.11 + SigmoidRange + u8 inside the res-block conv epilogue) keeps the unfused path's
+    rounding points (fp16 r2, fp16 weights, fp32 accumulate); only the summation order of the 259-term dot differs."""
+    frames = np.stack([make_frame(96, 5), make_frame(96, 6)])
+    outs = []
+    for fuse in (True, False):
+        rt = GeneratorRuntime(ctx, sds["video"], "wide", fuse_final=fuse)
+        try:
+            names = rt.net(96, 2).names
+            assert ("layers.11.0" in names) != fuse and ("layers.10.layers.1.0+11" in names) == fuse
+            outs.append(raw_gpu(ctx, rt, frames))
+        finally:
+            rt.close()
+    d = np.abs(outs[0].astype(np.int32) - outs[1].astype(np.int32))
+    assert d.max() <= 1 and (d == 0).mean() > 0.999, (int(d.max()), float((d == 0).mean()))

@@ -11,7 +11,7 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 560
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 ctx = get_context(0)
 t = time.time()
-rt = GeneratorRuntime(ctx, synth_state_dict(arch, 1), arch)
+rt = GeneratorRuntime(ctx, synth_state_dict(arch, 1), arch, fuse_final=os.environ.get("FUSE_FINAL", "1") == "1")
 print(f"pack+upload {time.time()-t:.1f}s")
 net = rt.net(S, batch)
 for _ in range(2):

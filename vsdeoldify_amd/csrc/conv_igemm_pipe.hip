@@ -222,12 +222,115 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
     // ReLU, global store.  TRANSPOSED / RGB8 / odd pixel-shuffle widths keep the per-fragment path.
     const bool lds_epi = !(p.flags & (HAVC_F_OUT_TRANSPOSED | HAVC_F_OUT_RGB8)) &&
                          (!(p.flags & HAVC_F_OUT_PIXSHUF) || (p.Co & 63) == 0);
+    bool fused_done = false;
     if (!lds_epi) {
 #pragma unroll
         for (int mi = 0; mi < FM; ++mi) {
             const int m = m0 + wm * (FM * 16) + mi * 16 + lr;
 #pragma unroll
             for (int ni = 0; ni < FN; ++ni) epilogue_frag(p, acc[ni][mi], m, n0 + wn * 64 + ni * 16 + lg * 4, HoWo);
+        }
+    } else if (EXTRA && has_extra && (p.flags & HAVC_F_FUSE_RGB8)) {
+        // ---- fused layers.11 (1x1 conv -> 3 channels) + SigmoidRange + denormalise + trunc u8 (HAVC_F_FUSE_RGB8) ----
+        // r2 = fp16(ReLU(acc + bias)) + residual never leaves the registers: an accumulator fragment (lane = pixel lr,
+        // channels lg*4..+3) IS the B operand of v_mfma_f32_16x16x16_f16, so the 1x1 conv is FN MFMAs per pixel
+        // fragment with the (3 real of 16) output rows as A.  The 259-channel row of a pixel is spread over the four
+        // N-waves and the extra-column fragments; the five partial sums go through LDS and are added in a FIXED
+        // order, so a frame colours identically in any batch.
+        fused_done = true;
+        const bool leaky = p.flags & HAVC_F_LEAKY;
+        const int nw0 = n0 + wn * 64;
+        half4 wa[FN];
+        float4 bvs[FN];
+#pragma unroll
+        for (int ni = 0; ni < FN; ++ni) {
+            const int n = nw0 + ni * 16 + lg * 4;
+            wa[ni] = half4{0, 0, 0, 0};
+            if (lr < 3) {
+                const float4 w4 = *reinterpret_cast<const float4*>(p.fuse_w + lr * p.Npad + n);
+                wa[ni] = half4{(half_t)w4.x, (half_t)w4.y, (half_t)w4.z, (half_t)w4.w};
+            }
+            bvs[ni] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4v facc[FM];
+#pragma unroll
+        for (int mh = 0; mh < FM; mh += 4) {               // four pixel fragments at a time: 16 residual loads in flight
+            half4 rr[4][FN];
+#pragma unroll
+            for (int mj = 0; mj < 4; ++mj) {
+                const int m = m0 + wm * (FM * 16) + (mh + mj) * 16 + lr;
+#pragma unroll
+                for (int ni = 0; ni < FN; ++ni) {
+                    rr[mj][ni] = half4{0, 0, 0, 0};
+                    if ((p.flags & HAVC_F_RESIDUAL) && m < p.M)
+                        rr[mj][ni] = *reinterpret_cast<const half4*>(p.res + out_pixel(p, m, HoWo) * p.res_cpitch + p.res_coff + nw0 + ni * 16 + lg * 4);
+                }
+            }
+#pragma unroll
+            for (int mj = 0; mj < 4; ++mj) {
+                const int mi = mh + mj;
+                facc[mi] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ni = 0; ni < FN; ++ni) {
+                    const float bb[4] = {bvs[ni].x, bvs[ni].y, bvs[ni].z, bvs[ni].w};
+                    half4 o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = acc[ni][mi][r] + bb[r];
+                        if (p.flags & HAVC_F_RELU_PRE) v = v > 0.f ? v : (leaky ? v * p.f2 : 0.f);
+                        o[r] = (half_t)v;
+                    }
+                    o = o + rr[mj][ni];                    // fp16 add = the rounding of the unfused store path
+                    facc[mi] = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[ni], o, facc[mi], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                   // every wave is done reading the last stage
+        float* part = reinterpret_cast<float*>(smem);      // [5][BM][3]
+        if (lg == 0) {
+#pragma unroll
+            for (int mi = 0; mi < FM; ++mi) {
+                float* q = part + (wn * BM + wm * (FM * 16) + mi * 16 + lr) * 3;
+                q[0] = facc[mi][0]; q[1] = facc[mi][1]; q[2] = facc[mi][2];
+            }
+            const int nx = n0 + BN;                        // extra columns: channels nx .. nx+2 are real (x0's RGB)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pl = wm * (FM * 16) + (wn * 2 + i) * 16 + lr;
+                const int m = m0 + pl;
+                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = accx[i][r] + (p.bias ? p.bias[nx + r] : 0.f);
+                    if (p.flags & HAVC_F_RELU_PRE) v = v > 0.f ? v : (leaky ? v * p.f2 : 0.f);
+                    half_t h = (half_t)v;
+                    if ((p.flags & HAVC_F_RESIDUAL) && m < p.M && nx + r < p.Co)
+                        h = h + p.res[out_pixel(p, m, HoWo) * p.res_cpitch + p.res_coff + nx + r];
+                    const float f = (float)h;
+                    d0 += f * (float)(half_t)p.fuse_w[nx + r];
+                    d1 += f * (float)(half_t)p.fuse_w[p.Npad + nx + r];
+                    d2 += f * (float)(half_t)p.fuse_w[2 * p.Npad + nx + r];
+                }
+                float* q = part + (4 * BM + pl) * 3;
+                q[0] = d0; q[1] = d1; q[2] = d2;
+            }
+        }
+        __syncthreads();
+        for (int pl = threadIdx.x; pl < BM; pl += NW * 64) {
+            const int m = m0 + pl;
+            if (m >= p.M) continue;
+            uint8_t* y = p.fuse_rgb + out_pixel(p, m, HoWo) * 3;
+#pragma unroll
+            for (int jo = 0; jo < 3; ++jo) {
+                float t = p.fuse_b[jo];
+#pragma unroll
+                for (int w = 0; w < 5; ++w) t += part[(w * BM + pl) * 3 + jo];
+                float sg = 1.f / (1.f + __expf(-t));
+                sg = sg * (p.f1 - p.f0) + p.f0;
+                sg = sg * p.istd[jo] + p.mean[jo];
+                sg = fminf(fmaxf(sg, 0.f), 1.f);
+                y[jo] = (uint8_t)(int)(sg * 255.f);
+            }
         }
     } else {
         __syncthreads();                                   // every wave is done reading the last stage
@@ -308,7 +411,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
             }
         }
     }
-    if (EXTRA && has_extra) {
+    if (EXTRA && has_extra && !(fused_done)) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int m = m0 + wm * (FM * 16) + (wn * 2 + i) * 16 + lr;

@@ -256,6 +256,12 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             a.bias = wptr<float>(n, op.bias_off);
             a.scale = wptr<float>(n, op.scale_off);
             a.shift = wptr<float>(n, op.shift_off);
+            if (op.flags & HAVC_F_FUSE_RGB8) {
+                if (op.Npad != 272 || !a.scale || !a.shift || op.aux0 < 0 || op.aux0 >= (int)n->bufs.size())
+                    return fail(c, HAVC_E_INVALID, "conv op: FUSE_RGB8 needs Npad 272, fused weights/bias and an RGB8 buffer");
+                a.fuse_w = a.scale; a.fuse_b = a.shift; a.scale = a.shift = nullptr;
+                a.fuse_rgb = (uint8_t*)bufptr(n, op.aux0);
+            }
             a.res = (op.flags & HAVC_F_RESIDUAL) ? (const half_t*)bufptr(n, op.src2) : nullptr;
             a.y = bufptr(n, op.dst);
             a.x_cpitch = op.src_cpitch; a.x_coff = op.src_coff;
@@ -295,11 +301,13 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                 const uint64_t big = std::max(xf, std::max(yf, rf));
                 if (big * (uint64_t)batch > lim) chunk = (int)std::max<uint64_t>(1, lim / big);
                 const char* x0 = (const char*)a.x; const char* r0 = (const char*)a.res; char* y0 = (char*)a.y;
+                uint8_t* rgb0 = a.fuse_rgb;
                 for (int f0 = 0; f0 < batch && e == 0; f0 += chunk) {
                     const int nb = std::min(chunk, batch - f0);
                     a.x = (const half_t*)(x0 + (uint64_t)f0 * xf);
                     a.y = y0 + (uint64_t)f0 * yf;
                     if (r0) a.res = (const half_t*)(r0 + (uint64_t)f0 * rf);
+                    if (rgb0) a.fuse_rgb = rgb0 + (uint64_t)f0 * op.Ho * op.Wo * 3;
                     a.M = nb * op.Ho * op.Wo;
                     a.x_bytes = (unsigned)std::min<uint64_t>(xf * (uint64_t)nb + 256, 0xEFFFFFFFull);
                     e = launch_conv(a, s);

@@ -30,6 +30,9 @@ struct ConvArgs {
     int cfg;               // 0 = heuristic; otherwise forced tile configuration (tools/conv_bench.py A/B runs)
     const int2* ktab;      // [Kc] per 16-byte K chunk: .x = byte offset of (tap, cin chunk) from the tap-0 pixel,
                            //      .y = dh | dw << 16 (input-pixel displacement of the tap; pad entries: dh = 0x7fff)
+    const float* fuse_w;   // FUSE_RGB8: fp32 [3][Npad] weights of the fused 1x1 conv, fuse_b: its 3 biases
+    const float* fuse_b;
+    uint8_t* fuse_rgb;     // FUSE_RGB8: u8 RGB output [M][3]
     unsigned x_bytes;      // size of the input allocation (buffer descriptor range; OOB lanes read zeros)
     unsigned w_bytes;      // Npad * Kc * 16
 };

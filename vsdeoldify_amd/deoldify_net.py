@@ -23,9 +23,9 @@ def conv_out(n, k, s, p, d=1):
 class DeoldifyGenerator:
     """Packs a reference state dict once; emits a plan per render size S = render_factor * 16."""
 
-    def __init__(self, state_dict, arch="wide"):
+    def __init__(self, state_dict, arch="wide", fuse_final=True):
         assert arch in RESNET
-        self.sd, self.arch = to_np(state_dict), arch
+        self.sd, self.arch, self.fuse_final = to_np(state_dict), arch, fuse_final
         self.pack, self._pc, self._vec = WeightPack(), {}, {}
         self._frozen = False
         self.plan(64)                      # dry run: packs every tensor
@@ -194,11 +194,27 @@ class DeoldifyGenerator:
         r1 = View(b.buf(S * S * tail_pitch), 0, tail_pitch, S, S, c8 + 3, tail_span, tail_cmap)
         b.conv("layers.10.layers.0.0", res_pc("layers.10.layers.0.0"), cat, r1, pad=1, flags=nat.F_RELU_PRE,
                tag=TAG_TAIL_RES)
-        r2 = View(b.buf(S * S * tail_pitch), 0, tail_pitch, S, S, c8 + 3, tail_span, tail_cmap)
-        b.conv("layers.10.layers.1.0", res_pc("layers.10.layers.1.0"), r1, r2, pad=1,
-               flags=nat.F_RELU_PRE | nat.F_RESIDUAL, res=cat, tag=TAG_TAIL_RES)
-        pc = self._conv("layers.11.0", lambda: pack_conv(self.pack, conv_weight(sd, "layers.11.0"), tail_cmap, tail_span,
-                                                         bias=sd["layers.11.0.bias"]))
-        b.conv("layers.11.0", pc, r2, out_buf, flags=nat.F_OUT_RGB8, f=(Y_RANGE[0], Y_RANGE[1], 0, 0), Co=3)
+        pc2 = res_pc("layers.10.layers.1.0")
+        if pc2.Npad == 272 and self.fuse_final:
+            # layers.11 (1x1 conv to RGB) + SigmoidRange + denormalise + u8 run in the epilogue of the second res_block
+            # conv: r2 (2.65 GB per 16 frames at 560^2) is never written or re-read (HAVC_F_FUSE_RGB8).
+            def fused():
+                W = conv_weight(sd, "layers.11.0").astype(np.float32)[:, :, 0, 0]            # [3, 259]
+                fw = np.zeros((3, pc2.Npad), np.float32)
+                fw[:, tail_cmap] = W
+                return fw, sd["layers.11.0.bias"].astype(np.float32)
+            fw_off, fb_off = self._vecs("layers.11.0#fused", fused)
+            oi = b.conv("layers.10.layers.1.0+11", pc2, r1, View(r1.buf, 0, tail_pitch, S, S, c8 + 3, tail_span, tail_cmap),
+                        pad=1, flags=nat.F_RELU_PRE | nat.F_RESIDUAL | nat.F_FUSE_RGB8, res=cat, tag=TAG_TAIL_RES,
+                        f=(Y_RANGE[0], Y_RANGE[1], 0, 0), aux0=out_buf)
+            b.ops[oi]["scale_off"], b.ops[oi]["shift_off"] = fw_off, fb_off
+            b.ops[oi]["flops"] += 2 * S * S * 3 * (c8 + 3)
+        else:
+            r2 = View(b.buf(S * S * tail_pitch), 0, tail_pitch, S, S, c8 + 3, tail_span, tail_cmap)
+            b.conv("layers.10.layers.1.0", pc2, r1, r2, pad=1,
+                   flags=nat.F_RELU_PRE | nat.F_RESIDUAL, res=cat, tag=TAG_TAIL_RES)
+            pc = self._conv("layers.11.0", lambda: pack_conv(self.pack, conv_weight(sd, "layers.11.0"), tail_cmap, tail_span,
+                                                             bias=sd["layers.11.0.bias"]))
+            b.conv("layers.11.0", pc, r2, out_buf, flags=nat.F_OUT_RGB8, f=(Y_RANGE[0], Y_RANGE[1], 0, 0), Co=3)
         ops, bufs = b.finish()
         return ops, bufs, in_buf, out_buf, b.names

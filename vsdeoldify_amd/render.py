@@ -41,9 +41,9 @@ def _load_pth(path):
 class GeneratorRuntime:
     """Packed weights on one GPU + a cache of nets keyed by (render size, max_batch)."""
 
-    def __init__(self, ctx, state_dict, arch):
+    def __init__(self, ctx, state_dict, arch, fuse_final=True):
         self.ctx, self.arch = ctx, arch
-        self.gen = DeoldifyGenerator(state_dict, arch)
+        self.gen = DeoldifyGenerator(state_dict, arch, fuse_final=fuse_final)
         self.weights = nat.Weights(ctx, self.gen.blob)
         self.nets = {}
 
