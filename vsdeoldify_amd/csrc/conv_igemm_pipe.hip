@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
         }
     } else if (EXTRA && has_extra && (p.flags & HAVC_F_FUSE_RGB8)) {
         // ---- fused layers.11 (1x1 conv -> 3 channels) + SigmoidRange + denormalise + trunc u8 (HAVC_F_FUSE_RGB8) ----
-        // r2 = fp16(ReLU(acc + bias)) + residual never leaves the registers: an accumulator fragment (lane = pixel lr,
+        // r2 = fp16(ReLU(acc + bias) + residual) never leaves the registers: an accumulator fragment (lane = pixel lr,
         // channels lg*4..+3) IS the B operand of v_mfma_f32_16x16x16_f16, so the 1x1 conv is FN MFMAs per pixel
         // fragment with the (3 real of 16) output rows as A.  The 259-channel row of a pixel is spread over the four
         // N-waves and the extra-column fragments; the five partial sums go through LDS and are added in a FIXED
@@ -278,9 +278,8 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
                     for (int r = 0; r < 4; ++r) {
                         float v = acc[ni][mi][r] + bb[r];
                         if (p.flags & HAVC_F_RELU_PRE) v = v > 0.f ? v : (leaky ? v * p.f2 : 0.f);
-                        o[r] = (half_t)v;
+                        o[r] = (half_t)(v + (float)rr[mj][ni][r]);    // one rounding, as epilogue_frag
                     }
-                    o = o + rr[mj][ni];                    // fp16 add = the rounding of the unfused store path
                     facc[mi] = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[ni], o, facc[mi], 0, 0, 0);
                 }
             }
@@ -303,10 +302,9 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
                 for (int r = 0; r < 4; ++r) {
                     float v = accx[i][r] + (p.bias ? p.bias[nx + r] : 0.f);
                     if (p.flags & HAVC_F_RELU_PRE) v = v > 0.f ? v : (leaky ? v * p.f2 : 0.f);
-                    half_t h = (half_t)v;
-                    if ((p.flags & HAVC_F_RESIDUAL) && m < p.M && nx + r < p.Co)
-                        h = h + p.res[out_pixel(p, m, HoWo) * p.res_cpitch + p.res_coff + nx + r];
-                    const float f = (float)h;
+                    if ((p.flags & HAVC_F_RESIDUAL) && m < p.M && nx + r < p.Co)      // as epilogue_frag: one rounding
+                        v += (float)p.res[out_pixel(p, m, HoWo) * p.res_cpitch + p.res_coff + nx + r];
+                    const float f = (float)(half_t)v;
                     d0 += f * (float)(half_t)p.fuse_w[nx + r];
                     d1 += f * (float)(half_t)p.fuse_w[p.Npad + nx + r];
                     d2 += f * (float)(half_t)p.fuse_w[2 * p.Npad + nx + r];
