@@ -55,7 +55,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 
 }  // namespace
 
-// ABL (profiling only, wrong results): 1 = no DMA inside the loop, 2 = no fragment reads, 4 = no MFMA, 5 = no epilogue
+// ABL (profiling only, wrong results): 1 = no DMA inside the loop, 4 = no MFMA, 5 = no epilogue
 // (Tried and dropped: staggering the DMA slots of the two waves sharing a SIMD -- 3-12 % slower, profiles/r1_conv_ablation.txt.)
 template <int WM, int WN, int FM, int EXTRA, int ABL = 0>
 __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p) {
@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
     const int NT = (p.Npad - 16 * EXTRA + BN - 1) / BN;
-    const int m0 = (pid / NT) * BM;
+    const int m0 = (ABL == 9 ? (pid / NT) % 64 : pid / NT) * BM;      // ABL 9: L2-resident source, DMA ceiling
     const int n0 = (pid % NT) * BN;
     const bool has_extra = EXTRA && (n0 + BN + 16 == p.Npad);
     const int HoWo = p.Ho * p.Wo;
@@ -139,60 +139,89 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
         for (int mi = 0; mi < FM; ++mi) acc[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
     accx[0] = accx[1] = float4v{0.f, 0.f, 0.f, 0.f};
 
-    // ---- prologue: stage 0 ----
+    // ---- prologue: all of stage 0, the first two pieces of stage 1, the first fragments of stage 0 ----
+    constexpr int P = G::PIECES;
+    constexpr int EARLY = 2;                               // pieces of stage kt+2 issued in the last two steps of stage kt
+    constexpr int NSD = NS / 2;                            // the other pieces go out in the first NSD steps of stage kt+1
+    auto dma_piece = [&](int q, char* buf, int2 e, int kstage) {
+        if (q < A_IT) dma16(rx, buf + (wave + q * NW) * 1024, a_voff(q, e), 0);
+        else dma16(rw, buf + BM * 128 + (wave + (q - A_IT) * NW) * 1024, b_voff[q - A_IT], (unsigned)kstage * 128u);
+    };
     int2 e_nx = kt_lane[0];
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it) dma16(rx, smem + (wave + it * NW) * 1024, a_voff(it, e_nx), 0);
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) dma16(rw, smem + BM * 128 + (wave + it * NW) * 1024, b_voff[it], 0);
+    for (int q = 0; q < P; ++q) dma_piece(q, smem, e_nx, 0);
     if (EXTRA && extra_wave) dma16(rw, smem + (BM + BN) * 128 + (wave & 1) * 1024, x_voff, 0);
     e_nx = kt_lane[(KT > 1 ? 1 : 0) * 8];
+    if (KT > 1) {
+#pragma unroll
+        for (int q = 0; q < EARLY; ++q) dma_piece(q, smem + G::STAGE_BYTES, e_nx, 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(e_nx.x), "+v"(e_nx.y));         // (see the note at the stage barrier)
+    __builtin_amdgcn_s_barrier();
 
-    // one 64-deep stage; MORE (compile time): the next stage exists and its DMA is issued from inside this one
-    auto stage = [&](int kt, auto more_tag) {
-        constexpr bool MORE = decltype(more_tag)::value && ABL != 1;
+    half8 bf[2][FN];                                   // weight fragments, K half 0 / 1
+    half8 xb[2];                                       // extra-column weight fragment
+    half8 af[4];                                       // pixel fragment ring (two steps ahead)
+#pragma unroll
+    for (int ni = 0; ni < FN; ++ni) bf[0][ni] = *reinterpret_cast<const half8*>(smem + b_l0 + ni * 2048);
+    if (EXTRA) xb[0] = *reinterpret_cast<const half8*>(smem + x_l0);
+    af[0] = *reinterpret_cast<const half8*>(smem + a_l0);
+    af[1] = *reinterpret_cast<const half8*>(smem + a_l0 + 2048);
+
+    // One 64-deep stage (NS steps of FN MFMAs).  LVL (compile time): 2 = stages kt+1 and kt+2 exist, 1 = only kt+1,
+    // 0 = last stage.  Two LDS buffers; the single barrier of a stage sits at step NS-3, right after the LAST fragment
+    // read of this stage's buffer has been issued: behind it (a) the buffer can be refilled (stage kt+2), so the DMA
+    // gets the rest of this stage plus most of the next one to land instead of racing the next barrier, and (b) stage
+    // kt+1's data is complete, so its first fragments are fetched under the MFMAs of steps NS-2, NS-1 -- the MFMA
+    // pipe no longer drains at a stage boundary.
+    auto stage = [&](int kt, auto lvl_tag) {
+        constexpr int LVL = ABL == 10 ? 0 : ABL == 1 ? (decltype(lvl_tag)::value ? 1 : 0) : decltype(lvl_tag)::value;
+        constexpr bool RD = ABL != 10;
+        constexpr bool DMA_ON = ABL != 1;
         const char* cur = smem + (kt & 1) * G::STAGE_BYTES;
         char* nxt = smem + ((kt & 1) ^ 1) * G::STAGE_BYTES;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-
-        half8 bf[2][FN];                               // weight fragments, K half 0 / 1
-        half8 xb[2];                                   // extra-column weight fragment
-        half8 af[3];                                   // pixel fragment ring
-#pragma unroll
-        for (int ni = 0; ni < FN; ++ni) bf[0][ni] = *reinterpret_cast<const half8*>(cur + b_l0 + ni * 2048);
-        if (EXTRA) xb[0] = *reinterpret_cast<const half8*>(cur + x_l0);
-        af[0] = *reinterpret_cast<const half8*>(cur + a_l0);
-        af[1] = *reinterpret_cast<const half8*>(cur + a_l0 + 2048);
         int2 e_n2 = e_nx;
-
 #pragma unroll
         for (int s = 0; s < NS; ++s) {                 // step s: K half s / FM, pixel fragment s % FM
             const int ks = s / FM, mi = s % FM;
-            if (s + 2 < NS && ABL != 2) {              // (1) pixel fragment two steps ahead
+            if (s == 0 && LVL == 2) e_n2 = kt_lane[(kt + 2) * 8];             // K table entry of stage kt+2
+            {                                          // (1) pixel fragment two steps ahead (next stage's at the end)
                 const int s2 = s + 2;
-                af[s2 % 3] = *reinterpret_cast<const half8*>(cur + ((s2 / FM) ? a_l1 : a_l0) + (s2 % FM) * 2048);
+                if (s2 < NS && RD) af[s2 % 4] = *reinterpret_cast<const half8*>(cur + ((s2 / FM) ? a_l1 : a_l0) + (s2 % FM) * 2048);
             }
-            if (ks == 0 && mi >= FM - FN && ABL != 2)  // (2) weight fragments of the second K half
+            if (s == NS - 3 && LVL >= 1) {             // (B) the barrier of this stage
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                // "use" the table entry here, where nothing is outstanding: otherwise the compiler's own wait for that
+                // load lands at the top of the next stage as vmcnt(0) and drains the early pieces issued below.
+                asm volatile("" : "+v"(e_n2.x), "+v"(e_n2.y));
+                __builtin_amdgcn_s_barrier();
+            }
+            if (s >= NS - 2 && LVL >= 1) {             // first fragments of stage kt+1
+                const int j = s - (NS - 2);
+                af[(s + 2) % 4] = *reinterpret_cast<const half8*>(nxt + a_l0 + j * 2048);
+#pragma unroll
+                for (int ni = 2 * j; ni < 2 * j + 2; ++ni) bf[0][ni] = *reinterpret_cast<const half8*>(nxt + b_l0 + ni * 2048);
+                if (EXTRA && j == 1) xb[0] = *reinterpret_cast<const half8*>(nxt + x_l0);
+            }
+            if (ks == 0 && mi >= FM - FN && RD)        // (2) weight fragments of the second K half
                 bf[1][mi - (FM - FN)] = *reinterpret_cast<const half8*>(cur + b_l1 + (mi - (FM - FN)) * 2048);
             if (EXTRA && s == 3) xb[1] = *reinterpret_cast<const half8*>(cur + x_l1);
-            if (MORE) {                                // (3) the DMA pieces of the next stage, spread over the steps
-                constexpr int P = G::PIECES;
+            if (LVL >= 1 && DMA_ON && s < NSD) {       // (3) the rest of stage kt+1's DMA pieces
 #pragma unroll
-                for (int q = (s * P) / NS; q < ((s + 1) * P) / NS; ++q) {
-                    if (q < A_IT) dma16(rx, nxt + (wave + q * NW) * 1024, a_voff(q, e_nx), 0);
-                    else dma16(rw, nxt + BM * 128 + (wave + (q - A_IT) * NW) * 1024, b_voff[q - A_IT], (unsigned)(kt + 1) * 128u);
-                }
-                if (EXTRA && s == NS - 3) {
-                    if (extra_wave) dma16(rw, nxt + (BM + BN) * 128 + (wave & 1) * 1024, x_voff, (unsigned)(kt + 1) * 128u);
-                }
-                if (s == NS - 2) e_n2 = kt_lane[(kt + 2 < KT ? kt + 2 : KT - 1) * 8];    // K table entry, stage after next
+                for (int q = EARLY + (s * (P - EARLY)) / NSD; q < EARLY + ((s + 1) * (P - EARLY)) / NSD; ++q)
+                    dma_piece(q, nxt, e_nx, kt + 1);
             }
-            const half8 a = af[ABL == 2 ? s % 2 : s % 3];                     // (4) the MFMAs of this step
+            if (EXTRA && LVL >= 1 && DMA_ON && s == NSD) {
+                if (extra_wave) dma16(rw, nxt + (BM + BN) * 128 + (wave & 1) * 1024, x_voff, (unsigned)(kt + 1) * 128u);
+            }
+            if (LVL == 2 && DMA_ON && s >= NS - 2)     //     and, behind the barrier, the first pieces of stage kt+2
+                dma_piece(s - (NS - 2), const_cast<char*>(cur), e_n2, kt + 2);
+            const half8 a = af[s % 4];                 // (4) the MFMAs of this step
 #pragma unroll
             for (int ni = 0; ni < FN; ++ni) {
-                if (ABL == 4) asm volatile("" ::"v"(bf[ABL == 2 ? 0 : ks][ni]), "v"(a));
-                else acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ABL == 2 ? 0 : ks][ni], a, acc[ni][mi], 0, 0, 0);
+                if (ABL == 4 || ABL == 9) asm volatile("" ::"v"(bf[ks][ni]), "v"(a));
+                else acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][ni], a, acc[ni][mi], 0, 0, 0);
             }
             if (EXTRA && has_extra) {                  // extra column fragment x pixel fragment mi: N-wave mi >> 1
                 if (wn == (mi >> 1)) accx[mi & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], a, accx[mi & 1], 0, 0, 0);
@@ -202,11 +231,12 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
         e_nx = e_n2;
     };
     int kt = 0;
-    for (; kt + 1 < KT; ++kt) stage(kt, std::true_type{});
-    stage(kt, std::false_type{});
+    for (; kt + 2 < KT; ++kt) stage(kt, std::integral_constant<int, 2>{});
+    if (KT >= 2) { stage(kt, std::integral_constant<int, 1>{}); ++kt; }
+    stage(kt, std::integral_constant<int, 0>{});
 
     // ---- epilogue ----
-    if (ABL == 5) {
+    if (ABL == 5 || ABL == 9 || ABL == 10) {
         float t = 0.f;
 #pragma unroll
         for (int mi = 0; mi < FM; ++mi)
@@ -443,8 +473,9 @@ int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
         case 60: return launch_pipe<2, 4, 8, 0>(a, s);        // 256 x 256
         case 61: return launch_pipe<2, 4, 8, 1>(a, s);        // 256 x (256 + 16)
         case 62: return launch_pipe<2, 4, 8, 0, 1>(a, s);     // ablations of cfg 60 (profiling only)
-        case 63: return launch_pipe<2, 4, 8, 0, 2>(a, s);
         case 64: return launch_pipe<2, 4, 8, 0, 4>(a, s);
+        case 69: return launch_pipe<2, 4, 8, 0, 9>(a, s);
+        case 73: return launch_pipe<2, 4, 8, 0, 10>(a, s);
         case 65: return launch_pipe<2, 4, 8, 0, 5>(a, s);
         case 70: return launch_pipe<2, 2, 4, 0>(a, s);        // 128 x 128, 4 waves
         case 71: return launch_pipe<1, 4, 8, 0>(a, s);        // 128 x 256, 4 waves
