@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhavc_mi355.so")
+LIB_PATH = os.environ.get("HAVC_MI355_LIB") or os.path.join(_HERE, "lib", "libhavc_mi355.so")   # override: A/B builds in tools/
 
 HAVC_OK, HAVC_E_INVALID, HAVC_E_OOM, HAVC_E_HIP, HAVC_E_NODEVICE = 0, -1, -2, -3, -4
 
