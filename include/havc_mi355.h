@@ -189,6 +189,23 @@ int havc_image_luma_merge(havc_ctx* ctx, const uint8_t* img_dark, const uint8_t*
 /* get_image_luma — imfilters.py:597-601: mean of the cv2 Y plane, in [0, 255] (caller divides / rounds) (AdaptiveLumaMerge) */
 int havc_image_luma(havc_ctx* ctx, const uint8_t* img, int width, int height, double* mean_y);
 
+/* image_tweak (vsslib/imfilters.py:463-504) without its gamma step (which raises in the reference, imfilters.py:517):
+ * Pillow HSV hue shift by hue_offset (Pillow hue units, int(hue_deg / 360 * 255)), then ImageEnhance Brightness(brightness),
+ * Contrast(contrast), Color(color) -- a factor of exactly 1 skips the step like the reference's `!= 1.0` tests -- then
+ * np_adjust_chroma2 (vsslib/restcolor.py:353-376): only pixels whose cv2 hue in the ORIGINAL lies strictly inside one of
+ * the n_ranges [lo, hi] degree ranges keep the tweaked value.  n_ranges <= 8. */
+int havc_image_tweak(havc_ctx* ctx, const uint8_t* img, uint8_t* out, int width, int height, int hue_offset, float brightness,
+                     float contrast, float color, const double* hue_ranges /* lo0, hi0, lo1, hi1, ... */, int n_ranges);
+/* the per-pixel half of luma_adjusted_levels (vsslib/imfilters.py:335-372): cv2 RGB->YUV, Y' = lut[Y], YUV->RGB.  The caller
+ * derives the 256-entry table from havc_image_luma exactly like the reference (vsdeoldify_amd/imfilters.py). */
+int havc_luma_lut(havc_ctx* ctx, const uint8_t* img, const uint8_t* lut256, uint8_t* out, int width, int height);
+/* restore_color_gradient (vsslib/restcolor.py:98-134), the per-frame body of ChromaRetentionMerge (vsslib/mcomb.py:450-516):
+ * gray pixels of img_gray (low cv2 HSV saturation, mask algo 0/1/2 of restcolor.py:137-217) take the colours of img_color
+ * (saturation scaled by sat); weight > 0 merges towards the colour image, < 0 towards the gray one; return_mask != 0
+ * returns the mask replicated to RGB. */
+int havc_restore_color_gradient(havc_ctx* ctx, const uint8_t* img_color, const uint8_t* img_gray, uint8_t* out, int width, int height,
+                                double sat, int tht, double weight, double alpha, int algo, int return_mask);
+
 /* ---- device-resident clip pipeline (bench + multi-GPU shard path) -----------------
  * One call colours n_frames 1080p-class frames that are ALREADY in HBM:
  *   d_src [n][h][w][3] u8 gray-as-RGB  -> Spline64 squash to S x S (harness stand-in for zimg,

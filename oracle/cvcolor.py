@@ -40,33 +40,48 @@ def yuv2rgb_u8(yuv):
     return np.clip(np.stack([r, g, b], -1), 0, 255).astype(np.uint8)
 
 
+_HSV_SHIFT = 12
+_SDIV = np.array([0] + [int(round((255 << _HSV_SHIFT) / i)) for i in range(1, 256)], np.int64)
+_HDIV180 = np.array([0] + [int(round((180 << _HSV_SHIFT) / (6.0 * i))) for i in range(1, 256)], np.int64)
+
+
 def rgb2hsv_u8(rgb):
-    """cv2 8-bit RGB->HSV (H in [0,180), S,V in [0,255]); float formula + rounding (unpinned)."""
-    a = np.asarray(rgb).astype(np.float32)
+    """cv2 8-bit RGB->HSV (H in [0,180), S,V in [0,255]): OpenCV's integer path (color_hsv: RGB2HSV_b) -- 12-bit
+    reciprocal tables sdiv = round(255<<12 / v), hdiv = round(180<<12 / (6 diff)), h sextant from the max channel,
+    descale by (x + 2048) >> 12, h += 180 when negative.  Restated from memory of the published source: unpinned."""
+    a = np.asarray(rgb).astype(np.int64)
     r, g, b = a[..., 0], a[..., 1], a[..., 2]
-    v = np.max(a, -1)
-    mn = np.min(a, -1)
-    d = v - mn
-    s = np.where(v > 0, d / np.where(v > 0, v, 1) * 255.0, 0)
-    dd = np.where(d > 0, d, 1)
-    h = np.where(v == r, (g - b) / dd, np.where(v == g, 2 + (b - r) / dd, 4 + (r - g) / dd)) * 60.0
-    h = np.where(d > 0, h, 0)
-    h = np.where(h < 0, h + 360, h) / 2.0
-    out = np.stack([np.rint(h) % 180, np.rint(s), v], -1)
-    return np.clip(out, 0, 255).astype(np.uint8)
+    v = np.maximum(np.maximum(r, g), b)
+    vmin = np.minimum(np.minimum(r, g), b)
+    diff = v - vmin
+    s = (diff * _SDIV[v] + (1 << (_HSV_SHIFT - 1))) >> _HSV_SHIFT
+    h = np.where(v == r, g - b, np.where(v == g, b - r + 2 * diff, r - g + 4 * diff))
+    h = (h * _HDIV180[diff] + (1 << (_HSV_SHIFT - 1))) >> _HSV_SHIFT
+    h = np.where(h < 0, h + 180, h)
+    return np.stack([h, s, v], -1).astype(np.uint8)
 
 
 def hsv2rgb_u8(hsv):
-    a = np.asarray(hsv).astype(np.float32)
-    h, s, v = a[..., 0] * 2.0, a[..., 1] / 255.0, a[..., 2] / 255.0
-    hh = (h / 60.0) % 6
-    i = np.floor(hh).astype(np.int32)
-    f = hh - i
-    p, q, t = v * (1 - s), v * (1 - s * f), v * (1 - s * (1 - f))
+    """cv2 8-bit HSV->RGB (HSV2RGB_b -> HSV2RGB_f, hrange 180), float32 throughout: h = H * (6/180), s = S * (1/255),
+    v = V * (1/255) (multiplications by float32 reciprocals), sector = floor(h) (h wrapped into [0, 6)), tab = {v, v(1-s),
+    v(1-s h), v(1-s(1-h))}, output saturate_cast<uchar>(x * 255) = round-half-even.  Restated from memory: unpinned."""
+    f32 = np.float32
+    a = np.asarray(hsv).astype(f32)
+    h = a[..., 0] * f32(f32(6.0) / f32(180.0))
+    s = a[..., 1] * f32(f32(1.0) / f32(255.0))
+    v = a[..., 2] * f32(f32(1.0) / f32(255.0))
+    h = np.where(h >= f32(6.0), h - f32(6.0), h)
+    i = np.floor(h).astype(np.int32)
+    f = (h - i.astype(f32)).astype(f32)
+    one = f32(1.0)
+    p, q, t = v * (one - s), v * (one - s * f), v * (one - s * (one - f))
     r = np.choose(i, [v, q, p, p, t, v])
     g = np.choose(i, [t, v, v, q, p, p])
     b = np.choose(i, [p, p, t, v, v, q])
-    return np.clip(np.rint(np.stack([r, g, b], -1) * 255.0), 0, 255).astype(np.uint8)
+    out = np.stack([r, g, b], -1).astype(f32) * f32(255.0)
+    gray = (a[..., 1] == 0)[..., None]
+    out = np.where(gray, (v * f32(255.0))[..., None], out)
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
 
 
 def cvtColor(src, code):

@@ -74,8 +74,10 @@ def test_gpu_merge_methods(ctx, g):
     luma = pipeline.get_image_luma(b)
     w = max(0.5 * pow(luma / 0.6, 1.0), 0.15) if luma < 0.6 else 0.5
     assert np.array_equal(mcomb.adaptive_luma_merge(a, b, 0.6, 1.0, 0.5, 0.15), imaging.pil_blend(a, b, w))
-    # bright frames pass the red-fix gate unchanged; dark ones are refused loudly (image_tweak not provided yet)
+    # bright frames pass the red-fix gate unchanged; dark ones take the image_tweak branches (mcomb.py:350-361)
     bright = np.clip(a.astype(int) + 120, 0, 255).astype(np.uint8)
     assert np.array_equal(mcomb.constrained_chroma_merge(bright, bright, 0.5, 0.2, True), pipeline.chroma_stabilizer(bright, bright, 0.2, 0.5))
-    with pytest.raises(NotImplementedError):
-        mcomb.constrained_chroma_merge(a // 8, b // 8, 0.5, 0.2, True)
+    from oracle import tweaks
+    for div in (2, 3, 8):
+        assert np.array_equal(mcomb.constrained_chroma_merge(a // div, b // div, 0.5, 0.2, True),
+                              tweaks.constrained_chroma_merge(a // div, b // div, 0.2, 0.5)), div

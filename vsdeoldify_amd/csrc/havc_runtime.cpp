@@ -925,6 +925,63 @@ int havc_image_luma(havc_ctx* c, const uint8_t* img, int width, int height, doub
     return HAVC_OK;
 }
 
+int havc_image_tweak(havc_ctx* c, const uint8_t* img, uint8_t* out, int width, int height, int hue_offset, float brightness, float contrast,
+                     float color, const double* hue_ranges, int n_ranges) {
+    if (!c || !img || !out || width <= 0 || height <= 0 || n_ranges < 0 || n_ranges > HAVC_MAX_HUE_RANGES || (n_ranges && !hue_ranges))
+        return fail(c, HAVC_E_INVALID, "image_tweak: bad args (at most 8 hue ranges)");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t nb = (size_t)width * height * 3;
+    const int64_t npix = (int64_t)width * height;
+    int rc;
+    if ((rc = ensure_scratch(c, 0, nb)) || (rc = ensure_scratch(c, 2, nb)) || (rc = ensure_scratch(c, 6, 256))) return rc;
+    uint8_t* din = (uint8_t*)c->scratch[0];
+    uint8_t* dout = (uint8_t*)c->scratch[2];
+    HIP_TRY(c, hipMemcpyAsync(din, img, nb, hipMemcpyHostToDevice, c->stream));
+    TweakArgs a{};
+    a.hue_offset = hue_offset; a.brightness = brightness; a.contrast = contrast; a.color = color; a.mean_l = 0; a.n_ranges = n_ranges;
+    for (int k = 0; k < n_ranges; ++k) { a.range_lo[k] = hue_ranges[2 * k]; a.range_hi[k] = hue_ranges[2 * k + 1]; }
+    if (contrast != 1.f) {
+        // ImageEnhance.Contrast: degenerate = solid int(mean(L) + 0.5) of the image as it enters the step
+        int e = launch_image_tweak(din, dout, npix, a, (unsigned long long*)c->scratch[6], true, c->stream);
+        c->stats.launches++;
+        if (e) return hip_fail(c, (hipError_t)e, "image_tweak (L sum)");
+        unsigned long long sum = 0;
+        HIP_TRY(c, hipMemcpyAsync(&sum, c->scratch[6], sizeof(sum), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        a.mean_l = (int)((double)sum / (double)npix + 0.5);
+    }
+    return host_filter_epilogue(c, out, dout, nb, launch_image_tweak(din, dout, npix, a, (unsigned long long*)c->scratch[6], false, c->stream));
+}
+
+int havc_luma_lut(havc_ctx* c, const uint8_t* img, const uint8_t* lut256, uint8_t* out, int width, int height) {
+    if (!c || !img || !lut256 || !out || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "luma_lut: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t nb = (size_t)width * height * 3;
+    int rc;
+    if ((rc = ensure_scratch(c, 0, nb)) || (rc = ensure_scratch(c, 2, nb)) || (rc = ensure_scratch(c, 6, 256))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->scratch[0], img, nb, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->scratch[6], lut256, 256, hipMemcpyHostToDevice, c->stream));
+    return host_filter_epilogue(c, out, (uint8_t*)c->scratch[2], nb,
+                                launch_luma_lut((const uint8_t*)c->scratch[0], (const uint8_t*)c->scratch[6], (uint8_t*)c->scratch[2],
+                                                (int64_t)width * height, c->stream));
+}
+
+int havc_restore_color_gradient(havc_ctx* c, const uint8_t* img_color, const uint8_t* img_gray, uint8_t* out, int width, int height, double sat,
+                                int tht, double weight, double alpha, int algo, int return_mask) {
+    if (!c || !img_color || !img_gray || !out || width <= 0 || height <= 0 || algo < 0 || algo > 2)
+        return fail(c, HAVC_E_INVALID, "restore_color_gradient: bad args (algo 0..2)");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t nb = (size_t)width * height * 3;
+    uint8_t *da, *db, *dout;
+    int rc = host_filter_prologue(c, img_color, img_gray, nb, &da, &db, &dout);
+    if (rc) return rc;
+    return host_filter_epilogue(c, out, dout, nb,
+                                launch_restore_color_gradient(da, db, dout, (int64_t)width * height, sat, tht, alpha, weight, algo, return_mask, c->stream));
+}
+
 int havc_color_temporal_stabilizer(havc_ctx* c, const uint8_t* const* frames, const double* weights, int n, uint8_t* out, int width, int height) {
     if (!c || !frames || !weights || !out || n < 1 || n > 9 || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "color_temporal_stabilizer: bad args (1..9 frames)");
     std::lock_guard<std::mutex> lk(c->mu);

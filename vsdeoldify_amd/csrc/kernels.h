@@ -83,6 +83,21 @@ int launch_chroma_stabilizer_adaptive(const uint8_t* stable, const uint8_t* inew
                                       uint8_t* out, int w, int h, hipStream_t s);
 int launch_color_temporal_stabilizer(const uint8_t* const* frames, const double* weights, int n, uint8_t* out, int64_t npix,
                                      hipStream_t s);
+// tweaks.hip: image_tweak chain (Pillow hue shift, ImageEnhance Brightness / Contrast / Color, hue-range mask), Y table of
+// luma_adjusted_levels, restore_color_gradient.
+#define HAVC_MAX_HUE_RANGES 8
+struct TweakArgs {
+    int hue_offset;               // Pillow hue units (0..255 per turn); 0 = no hue shift
+    float brightness, contrast, color;    // ImageEnhance factors; 1 = step skipped
+    int mean_l;                   // Contrast: int(mean(L) + 0.5) of the image in front of the contrast step
+    int n_ranges;                 // hue-range mask on the ORIGINAL image (degrees, strict inequalities); 0 = none
+    double range_lo[HAVC_MAX_HUE_RANGES], range_hi[HAVC_MAX_HUE_RANGES];
+};
+int launch_image_tweak(const uint8_t* img, uint8_t* out, int64_t npix, const TweakArgs& a, unsigned long long* d_sum, bool sum_only,
+                       hipStream_t s);
+int launch_luma_lut(const uint8_t* img, const uint8_t* d_lut, uint8_t* out, int64_t npix, hipStream_t s);
+int launch_restore_color_gradient(const uint8_t* color, const uint8_t* gray, uint8_t* out, int64_t npix, double sat, int tht, double alpha,
+                                  double weight, int algo, int return_mask, hipStream_t s);
 // separable polyphase resample of interleaved u8 RGB (tap tables from the host; Spline64 = harness stand-in
 // for zimg resize.Spline64).  orig != null fuses chroma_post_process (luma of orig, chroma of the resampled).
 int launch_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int n_frames, float* tmp,

@@ -153,3 +153,89 @@ def w_image_luma_merge(img_dark, img_white, dark_luma=0.3, white_luma=0.9, retur
     else:
         out = luma_merge_np(ctx, np.asarray(img_dark), np.asarray(img_white), 2)
     return Image.fromarray(out)
+
+
+# ---- tweaks and gray-pixel restoration ----------------------------------------------------
+_HUE_NAMES = {"red": (0, 30), "orange": (30, 60), "yellow": (60, 90), "yellow-green": (90, 120), "green": (120, 150),
+              "blue-green": (150, 180), "cyan": (180, 210), "blue": (210, 240), "blue-violet": (240, 270),
+              "violet": (270, 300), "red-violet": (300, 330), "rose": (330, 360)}
+
+
+def parse_hue_ranges(hue_range):
+    """restcolor.py:417-470: 'name' or 'min:max' tokens separated by commas -> flat [lo0, hi0, lo1, hi1, ...] in degrees."""
+    flat = []
+    for tok in hue_range.split(","):
+        if tok in _HUE_NAMES:
+            lo, hi = _HUE_NAMES[tok]
+        else:
+            lo, hi = (float(v) for v in tok.split(":"))
+        flat += [float(lo), float(hi)]
+    return flat
+
+
+def image_tweak_np(ctx, img, sat=1.0, cont=1.0, bright=0.0, hue=0.0, gamma=1.0, hue_range="none"):
+    import ctypes as C
+    if gamma != 1.0:
+        # imfilters.py:507-517: the reference passes `uint8_array * 3` (256 entries) to Image.point of an RGB image and
+        # Pillow raises; the gamma branch of image_tweak has never produced a frame.  Same error, same text.
+        raise ValueError("wrong number of lut entries")
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    out = np.empty_like(a)
+    rng = [] if hue_range in ("none", "") else parse_hue_ranges(hue_range)
+    arr = (C.c_double * max(len(rng), 1))(*rng)
+    hue_off = int((hue / 360.0) * 255) if hue != 0.0 else 0                  # imfilters.py:530
+    nat.check(ctx.lib.havc_image_tweak(ctx.h, nat.as_ptr(a), nat.as_ptr(out), a.shape[1], a.shape[0], hue_off,
+                                       float(1 + bright / 255) if bright != 0.0 else 1.0, float(cont), float(sat), arr,
+                                       len(rng) // 2), ctx.h)
+    return out
+
+
+def image_tweak(img, sat=1, cont=1.0, bright=0, hue=0, gamma=1.0, hue_range="none", device_index=0):
+    """imfilters.py:463-504 (PIL in / PIL out): hue shift through Pillow's HSV, ImageEnhance Brightness / Contrast / Color,
+    optional hue-range mask against the original."""
+    from PIL import Image
+    return Image.fromarray(image_tweak_np(get_context(device_index), np.asarray(img), sat, cont, bright, hue, gamma, hue_range))
+
+
+def luma_levels_lut(luma, luma_min=0.0, gamma=1.0, gamma_luma_min=0.0, gamma_alpha=0.0, gamma_min=0.2, i_min=0, i_max=255):
+    """The scalar half of luma_adjusted_levels (imfilters.py:346-364) as the reference writes it, applied to all 256 Y
+    values (numpy, so the uint8 wrap of np.add and numpy's own pow are the reference's)."""
+    y = np.arange(256, dtype=np.uint8)
+    i_alpha = int(255 * (luma_min - luma)) if luma < luma_min else 0
+    y_new = np.add(y, i_alpha).clip(i_min, i_max).astype(np.uint8) if i_alpha > 1 else y
+    if gamma != 1 and luma < gamma_luma_min:
+        g_new = max(gamma * pow(luma / gamma_luma_min, gamma_alpha), gamma_min) if gamma_alpha != 0 else gamma
+        y_new = np.power(y_new / 255, 1 / g_new)
+        y_new = np.multiply(y_new, 255).clip(i_min, i_max).astype(np.uint8)
+    return np.ascontiguousarray(y_new, dtype=np.uint8)
+
+
+def luma_adjusted_levels_np(ctx, img, luma_min=0.0, gamma=1.0, gamma_luma_min=0.0, gamma_alpha=0.0, gamma_min=0.2, i_min=0, i_max=255):
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    luma = image_luma_np(ctx, a) / 255
+    lut = luma_levels_lut(luma, luma_min, gamma, gamma_luma_min, gamma_alpha, gamma_min, i_min, i_max)
+    out = np.empty_like(a)
+    nat.check(ctx.lib.havc_luma_lut(ctx.h, nat.as_ptr(a), nat.as_ptr(lut), nat.as_ptr(out), a.shape[1], a.shape[0]), ctx.h)
+    return out
+
+
+def luma_adjusted_levels(img, luma_min=0, gamma=1.0, gamma_luma_min=0, gamma_alpha=0, gamma_min=0.2, i_min=0, i_max=255,
+                         device_index=0):
+    """imfilters.py:335-372."""
+    from PIL import Image
+    return Image.fromarray(luma_adjusted_levels_np(get_context(device_index), np.asarray(img), luma_min, gamma, gamma_luma_min,
+                                                   gamma_alpha, gamma_min, i_min, i_max))
+
+
+def restore_color_gradient_np(ctx, img_color, img_gray, sat=1.0, tht=50, weight=0.0, alpha=2.0, return_mask=False, algo=0):
+    a, b, out = _prep(img_color, img_gray)
+    nat.check(ctx.lib.havc_restore_color_gradient(ctx.h, nat.as_ptr(a), nat.as_ptr(b), nat.as_ptr(out), a.shape[1], a.shape[0],
+                                                  float(sat), int(tht), float(weight), float(alpha), int(algo), int(bool(return_mask))), ctx.h)
+    return out
+
+
+def restore_color_gradient(img_color, img_gray, sat=1.0, tht=50, weight=0, alpha=2.0, return_mask=False, algo=0, device_index=0):
+    """restcolor.py:98-134."""
+    from PIL import Image
+    return Image.fromarray(restore_color_gradient_np(get_context(device_index), np.asarray(img_color), np.asarray(img_gray), sat, tht,
+                                                     weight, alpha, return_mask, algo))

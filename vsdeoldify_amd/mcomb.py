@@ -7,13 +7,17 @@ passthrough) stay in the reference; these are the functions they would call once
   method 4  LumaMaskedMerge           mcomb.py:238-271   (w_)image_luma_merge + weighted merge
   method 5  AdaptiveLumaMerge         mcomb.py:289-314   frame-mean luma -> weight -> blend
   method 7  ChromaBoundAdaptiveMerge  mcomb.py:370-437   chroma_stabilizer_adaptive (+ red fix)
-The dark-frame "red fix" (luma <= 0.3) needs image_tweak (PIL ImageEnhance + HSV hue ranges, imfilters.py:463-504),
-which is not on the GPU yet: frames that would take it raise NotImplementedError so the caller can fall back.
+  method 6  ChromaRetentionMerge      mcomb.py:450-516   restore_color_gradient (+ blend); the optional Spline64 round
+                                                         trip of chroma_resize stays with the caller (zimg)
+The dark-frame "red fix" (frame luma <= 0.3, mcomb.py:350-361) = image_tweak (ImageEnhance.Color + hue-range mask) merged
+back through w_image_luma_merge.
 """
 import numpy as np
 
 from . import imfilters as F
 from .render import get_context
+
+DEF_STANDARD_DARK, DEF_STANDARD_BRIGHT = 0.22, 0.78        # vsslib/constants.py:28-29
 
 
 def simple_merge(a, b, weight=0.5, device_index=0):
@@ -25,10 +29,17 @@ def simple_merge(a, b, weight=0.5, device_index=0):
 
 
 def _red_fix(ctx, img_stab):
+    """mcomb.py:350-361 / 409-420."""
     luma = round(F.image_luma_np(ctx, img_stab) / 255, 6)
     if luma > 0.3:
         return img_stab
-    raise NotImplementedError(f"dark frame (luma {luma}): red fix needs image_tweak, not provided by vsdeoldify_amd yet")
+    if luma > 0.1:
+        dark_luma, white_luma, sat = (0.2, 0.3, 0.9) if luma > 0.2 else (0.1, 0.2, 0.8)        # literals, as the reference writes them
+        dark = F.image_tweak_np(ctx, img_stab, sat=sat, hue_range="280:360,0:30")
+        max_white = round(white_luma * 255)                                  # w_image_luma_merge (imfilters.py:80-100)
+        tresh = min(round(dark_luma * 255), max_white - 10)
+        return F.luma_merge_np(ctx, dark, img_stab, 1, tresh, round(1 / (max_white - tresh), 3))
+    return F.image_tweak_np(ctx, img_stab, sat=0.7)
 
 
 def constrained_chroma_merge(a, b, clipb_weight=0.5, chroma_threshold=0.2, red_fix=True, device_index=0):
@@ -60,3 +71,17 @@ def adaptive_luma_merge(a, b, luma_threshold=0.6, alpha=1.0, clipb_weight=0.5, m
     luma = round(F.image_luma_np(ctx, b) / 255, 6)
     w = max(clipb_weight * pow(luma / luma_threshold, alpha), min_weight) if luma < luma_threshold else clipb_weight
     return F.blend_np(ctx, a, b, w)
+
+
+def chroma_retention_frame(a, b, sat=0.8, tht=30, mask_weight=0.0, alpha=2.0, return_mask=False, algo=0, device_index=0):
+    """The per-frame selector of ChromaRetentionMerge (mcomb.py:450-516 -> vs_sc_recover_gradient_color, vsfilters.py:391-412):
+    a = frame to repair (deoldify), b = colour donor (ddcolor).  Frames darker / brighter than the standard luma band get
+    weight <= -0.5 and alpha >= 4 (vsfilters.py:403-409).  The clip-level steps around it -- the optional Spline64 round trip
+    (chroma_resize) and the closing std.Merge(clip_a, restored, clipb_weight) -- are VapourSynth core filters and stay there."""
+    ctx = get_context(device_index)
+    alpha = max(min(alpha, 10.0), 1.0)                                       # DEF_MIN/MAX_COLOR_ALPHA, constants.py:80-81
+    luma = round(F.image_luma_np(ctx, a) / 255, 6)
+    if not (DEF_STANDARD_DARK <= luma <= DEF_STANDARD_BRIGHT):
+        mask_weight = min(mask_weight, -0.5)
+        alpha = max(alpha, 4.0)
+    return F.restore_color_gradient_np(ctx, b, a, sat, tht, mask_weight, alpha, return_mask, algo)
