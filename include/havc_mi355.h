@@ -66,6 +66,12 @@ enum havc_op_type {
 #define HAVC_F_OUT_TRANSPOSED 0x20 /* store as [b][n][pix_pitch] (V^T for attention)                       */
 #define HAVC_F_OUT_RGB8 0x40      /* SigmoidRange(f0,f1) -> *std+mean -> clamp01 -> trunc(*255) -> u8 RGB   */
 #define HAVC_F_LEAKY 0x80         /* RELU_* use LeakyReLU(f2)                                              */
+#define HAVC_F_PS_BLUR 0x200      /* with OUT_PIXSHUF: the always-on blur of CustomPixelShuffle_ICNR (ReplicationPad(1,0,1,0) +
+                                     AvgPool2d(2, 1), deoldify/unet.py:46-52) runs in the conv epilogue; the shuffled tensor is
+                                     never stored.  Needs 1x1 stride-1 conv, Co % 64 == 0, weight rows packed as
+                                     (c / 64) * 256 + q * 64 + c % 64 (plan.py pack_conv pixshuf="blur"): a 256-column tile then
+                                     holds all four sub-pixels of 64 channels, and GEMM rows are 16x16 pixel tiles that
+                                     overlap by one row / column (the blur's top-left halo).                              */
 #define HAVC_F_FUSE_RGB8 0x100    /* the conv output is NOT stored: a following 1x1 conv to 3 channels (fp32 weights at
                                      scale_off [3][Npad], bias at shift_off [3]) + OUT_RGB8 maths run in the epilogue and
                                      write u8 RGB to buffer aux0 (layers.10.1 + layers.11 + layers.12 of the generator);

@@ -123,3 +123,21 @@ def test_fused_final_conv_matches_unfused(ctx, sds):
             rt.close()
     d = np.abs(outs[0].astype(np.int32) - outs[1].astype(np.int32))
     assert d.max() <= 1 and (d == 0).mean() > 0.999, (int(d.max()), float((d == 0).mean()))
+
+
+@pytest.mark.parametrize("S", [272, 320])
+def test_fused_shuffle_blur_is_bit_identical(ctx, sds, S):
+    """HAVC_F_PS_BLUR (1x1 conv + PixelShuffle + blur in one kernel, 16x16 pixel tiles with a one-pixel halo) must give
+    exactly the bytes of the three-pass path: same fp16 rounding of the shuffled tensor, same summation order.
+    272: 136 = 9 * 15 + 1 low-res rows (a last tile of one useful row + clamping); 320: 160 rows."""
+    frames = np.stack([make_frame(S, 40), make_frame(S, 41)])
+    outs = []
+    for fuse in (True, False):
+        rt = GeneratorRuntime(ctx, sds["video"], "wide", fuse_blur=fuse)
+        try:
+            names = rt.net(S, 2).names
+            assert ("layers.8+blur" in names) == fuse and ("layers.8.blur" in names) != fuse
+            outs.append(raw_gpu(ctx, rt, frames))
+        finally:
+            rt.close()
+    assert np.array_equal(outs[0], outs[1])

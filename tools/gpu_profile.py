@@ -11,7 +11,8 @@ S = int(sys.argv[2]) if len(sys.argv) > 2 else 560
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 ctx = get_context(0)
 t = time.time()
-rt = GeneratorRuntime(ctx, synth_state_dict(arch, 1), arch, fuse_final=os.environ.get("FUSE_FINAL", "1") == "1")
+rt = GeneratorRuntime(ctx, synth_state_dict(arch, 1), arch, fuse_final=os.environ.get("FUSE_FINAL", "1") == "1",
+                      fuse_blur=os.environ.get("FUSE_BLUR", "1") == "1")
 print(f"pack+upload {time.time()-t:.1f}s")
 net = rt.net(S, batch)
 for _ in range(2):
@@ -32,6 +33,7 @@ grp = collections.OrderedDict()
 def gname(n):
     if n.startswith("layers.0."): return "encoder (" + (".".join(n.split(".")[:3]) if n.split(".")[2] in "4567" else "stem") + ")"
     if n.startswith("layers.10") or n.startswith("layers.11"): return "tail convs"
+    if n.startswith("layers.8"): return "layers.8"
     return ".".join(n.split(".")[:2])
 for i in range(len(ms)):
     g = gname(net.names[i]); a = grp.setdefault(g, [0.0, 0.0, 0]); a[0] += ms[i]; a[1] += fl[i]; a[2] += 1

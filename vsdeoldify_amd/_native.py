@@ -18,7 +18,7 @@ HAVC_OK, HAVC_E_INVALID, HAVC_E_OOM, HAVC_E_HIP, HAVC_E_NODEVICE = 0, -1, -2, -3
 OP_CONV, OP_MAXPOOL, OP_BLUR_RESIZE, OP_AFFINE, OP_ATTENTION, OP_PREP_RGB8, OP_COPY_CH = 1, 2, 3, 4, 5, 6, 7
 OP_SUBSAMPLE2, OP_PROJ2, OP_BILINEAR2, OP_PREP_LAB_L = 8, 9, 10, 11
 F_RELU_PRE, F_AFFINE, F_RESIDUAL, F_RELU_POST = 0x1, 0x2, 0x4, 0x8
-F_OUT_PIXSHUF, F_OUT_TRANSPOSED, F_OUT_RGB8, F_LEAKY, F_FUSE_RGB8 = 0x10, 0x20, 0x40, 0x80, 0x100
+F_OUT_PIXSHUF, F_OUT_TRANSPOSED, F_OUT_RGB8, F_LEAKY, F_FUSE_RGB8, F_PS_BLUR = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 
 # numpy mirror of `struct havc_op` (natural C alignment; checked against sizeof in tests)
 OP_DTYPE = np.dtype([

@@ -175,6 +175,7 @@ static int pick_pipe(const ConvArgs& a) {
     if (a.flags & HAVC_F_OUT_RGB8) return 0;
     const int extra = (a.Npad % 256 == 16) ? 1 : 0;
     if (!conv_pipe_supported(a, extra)) return 0;
+    if (a.flags & HAVC_F_PS_BLUR) return extra ? 0 : 60;   // the epilogue needs the 16x16-pixel x (4 x 64)-column tile
     if (a.flags & HAVC_F_FUSE_RGB8) return 61;           // only the 256 x (256+16) tile sees every channel of a pixel
     if (a.Npad >= 256 && (a.Npad % 256 == 0 || extra)) {
         const int64_t blocks = (int64_t)((a.M + 255) / 256) * ((a.Npad - 16 * extra) / 256);
@@ -204,7 +205,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
         const int pc = pick_pipe(a);
         if (pc) return launch_conv_pipe(a, pc, s);
     }
-    if (a.flags & HAVC_F_FUSE_RGB8) return (int)hipErrorInvalidValue;
+    if (a.flags & (HAVC_F_FUSE_RGB8 | HAVC_F_PS_BLUR)) return (int)hipErrorInvalidValue;
     switch (a.cfg > 0 ? a.cfg - 1 : pick_config(a)) {
         case CFG_128x128: return launch_cfg<128, 128, 2, 2>(a, s);
         case CFG_128x64: return launch_cfg<128, 64, 2, 2>(a, s);

@@ -97,10 +97,17 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
         const int m = m0 + row;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int b = mm / HoWo;
+        int b = mm / HoWo;
         const int rem = mm - b * HoWo;
-        const int ho = rem / p.Wo;
-        const int wo = rem - ho * p.Wo;
+        int ho = rem / p.Wo;
+        int wo = rem - ho * p.Wo;
+        if (p.flags & HAVC_F_PS_BLUR) {                    // GEMM rows = 16x16 pixel tiles, origin (15 ty - 1, 15 tx - 1), clamped
+            const int tile = m0 / BM, tt = p.tiles_y * p.tiles_x;
+            b = tile / tt;
+            const int t = tile - b * tt, ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+            ho = min(max(ty * 15 - 1 + (row >> 4), 0), p.Ho - 1);
+            wo = min(max(tx * 15 - 1 + (row & 15), 0), p.Wo - 1);
+        }
         const int hi0 = ok ? ho * p.stride - p.pad : -16384, wi0 = wo * p.stride - p.pad_w;
         a_hw0[it] = (hi0 & 0xffff) | (wi0 << 16);
         a_base[it] = (unsigned)((((int64_t)(b * p.Hi + hi0) * p.Wi + wi0) * p.x_cpitch + p.x_coff) * 2);
@@ -389,6 +396,33 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
                 const int slot = (ni * 2 + (lg >> 1)) ^ (lr & 7);
                 *reinterpret_cast<half4*>(img + mi * 2048 + lr * 128 + slot * 16 + (lg & 1) * 8) = o;
             }
+        }
+        if ((p.flags & HAVC_F_PS_BLUR) && WM == 2 && WN == 4 && FM == 8) {
+            // ---- HAVC_F_PS_BLUR: PixelShuffle(2) + ReplicationPad(1,0,1,0) + AvgPool2d(2,1) straight out of the LDS images ----
+            // The block holds the 16x16 low-res tile x (4 sub-pixels x 64 channels); wave (wm, q) owns rows wm*8..+7 of
+            // sub-pixel q.  Output = the 30x30 hi-res pixels whose 2x2 source window lies inside the tile.  Same fp16
+            // rounding of the shuffled values and the same summation order as elementwise.hip blur_resize_kernel.
+            __syncthreads();
+            const int tile = m0 / BM, tt = p.tiles_y * p.tiles_x;
+            const int b = tile / tt, t = tile - b * tt, ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+            const int h0 = ty * 15 - 1, w0 = tx * 15 - 1, H2 = 2 * p.Ho, W2 = 2 * p.Wo;
+            half_t* y = reinterpret_cast<half_t*>(p.y) + p.y_coff + (n0 >> 2);          // 64 output channels per 256-column tile
+            for (int it = tid; it < 30 * 30 * 8; it += NW * 64) {
+                const int ch = it & 7, pxl = it >> 3, Yl = pxl / 30, Xl = pxl - Yl * 30;
+                const int Y = 2 * (h0 + 1) + Yl, X = 2 * (w0 + 1) + Xl;
+                if (Y >= H2 || X >= W2) continue;
+                const int ay0 = max(Y - 1, 0), ax0 = max(X - 1, 0);
+                auto ld = [&](int ay, int ax) -> half8 {
+                    const int dy = (ay >> 1) - h0, dx = (ax >> 1) - w0, q = (ay & 1) * 2 + (ax & 1);
+                    return *reinterpret_cast<const half8*>(smem + ((dy >> 3) * WN + q) * (FM * 2048) + (dy & 7) * 2048 + dx * 128 + ((ch ^ (dx & 7)) << 4));
+                };
+                const half8 v00 = ld(ay0, ax0), v01 = ld(ay0, X), v10 = ld(Y, ax0), v11 = ld(Y, X);
+                half8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)v00[e] + (float)v01[e] + (float)v10[e] + (float)v11[e]) * 0.25f);
+                *reinterpret_cast<half8*>(y + ((int64_t)(b * H2 + Y) * W2 + X) * p.y_cpitch + ch * 8) = o;
+            }
+            return;
         }
         // phase 2: lane -> (pixel row lane>>3 (+8), 16-byte channel slot lane&7).  All residual vectors are requested
         // up front (the accumulators are dead by now) so their latency overlaps instead of serialising 16 load->store pairs.

@@ -256,6 +256,15 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             a.bias = wptr<float>(n, op.bias_off);
             a.scale = wptr<float>(n, op.scale_off);
             a.shift = wptr<float>(n, op.shift_off);
+            int rows_per_frame = op.Ho * op.Wo;
+            if (op.flags & HAVC_F_PS_BLUR) {
+                if (!(op.flags & HAVC_F_OUT_PIXSHUF) || op.kh != 1 || op.kw != 1 || op.stride != 1 || op.pad != 0 || (op.Co & 63) ||
+                    op.Npad != 4 * op.Co || (op.Npad & 255) || op.out_step > 1 || (op.flags & (HAVC_F_RESIDUAL | HAVC_F_RELU_POST)))
+                    return fail(c, HAVC_E_INVALID, "conv op: PS_BLUR needs a 1x1 stride-1 pixel-shuffle conv with Co % 64 == 0");
+                a.tiles_y = (op.Ho + 14) / 15;
+                a.tiles_x = (op.Wo + 14) / 15;
+                rows_per_frame = a.tiles_y * a.tiles_x * 256;
+            }
             if (op.flags & HAVC_F_FUSE_RGB8) {
                 if (op.Npad != 272 || !a.scale || !a.shift || op.aux0 < 0 || op.aux0 >= (int)n->bufs.size())
                     return fail(c, HAVC_E_INVALID, "conv op: FUSE_RGB8 needs Npad 272, fused weights/bias and an RGB8 buffer");
@@ -273,7 +282,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             a.pad_w = op.pad + op.pad_w_delta;
             a.oss = op.out_step == 2 ? 2 : 1; a.ooy = op.out_oy; a.oox = op.out_ox;
             a.Kc = op.Kc; a.Npad = op.Npad;
-            a.M = batch * op.Ho * op.Wo;
+            a.M = batch * op.Ho * op.Wo;   // (PS_BLUR: set below)
             a.flags = op.flags;
             a.pix_pitch = op.aux0;
             a.f0 = op.f0; a.f1 = op.f1; a.f2 = op.f2;
@@ -308,7 +317,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                     a.y = y0 + (uint64_t)f0 * yf;
                     if (r0) a.res = (const half_t*)(r0 + (uint64_t)f0 * rf);
                     if (rgb0) a.fuse_rgb = rgb0 + (uint64_t)f0 * op.Ho * op.Wo * 3;
-                    a.M = nb * op.Ho * op.Wo;
+                    a.M = nb * rows_per_frame;
                     a.x_bytes = (unsigned)std::min<uint64_t>(xf * (uint64_t)nb + 256, 0xEFFFFFFFull);
                     e = launch_conv(a, s);
                     if (f0 > 0) c->stats.launches += 1;

@@ -23,9 +23,9 @@ def conv_out(n, k, s, p, d=1):
 class DeoldifyGenerator:
     """Packs a reference state dict once; emits a plan per render size S = render_factor * 16."""
 
-    def __init__(self, state_dict, arch="wide", fuse_final=True):
+    def __init__(self, state_dict, arch="wide", fuse_final=True, fuse_blur=True):
         assert arch in RESNET
-        self.sd, self.arch, self.fuse_final = to_np(state_dict), arch, fuse_final
+        self.sd, self.arch, self.fuse_final, self.fuse_blur = to_np(state_dict), arch, fuse_final, fuse_blur
         self.pack, self._pc, self._vec = WeightPack(), {}, {}
         self._frozen = False
         self.plan(64)                      # dry run: packs every tensor
@@ -38,6 +38,20 @@ class DeoldifyGenerator:
             assert not self._frozen, key
             self._pc[key] = fn()
         return self._pc[key]
+
+    def _shuf_conv(self, key, make, fuse):
+        """pixel-shuffle conv weights in both row orders (plain / HAVC_F_PS_BLUR): which one a render size uses depends on
+        the size, and everything is packed once in the constructor's dry run."""
+        if not self._frozen:
+            pc = self._conv(key, lambda: make(True))
+            if self.fuse_blur and (pc.Cout // 4) % 64 == 0 and pc.Cout % 256 == 0:
+                self._conv(key + "#blur", lambda: make("blur"))
+        return self._pc[key + ("#blur" if fuse else "")]
+
+    def _fuse_blur(self, x, up_c, out_hw):
+        """HAVC_F_PS_BLUR applies when the blur is not followed by a resize, the channel count tiles by 64 and the 15/16
+        tile overlap wastes little (H >= 128: 280 -> 19 tiles of 15 = 1.8 %, 140 -> 7 %, 70 -> 7 % but M is tiny there)."""
+        return self.fuse_blur and 2 * x.H == out_hw and up_c % 64 == 0 and (4 * up_c) % 256 == 0 and x.H >= 128
 
     def _vecs(self, key, fn):
         if key not in self._vec:
@@ -150,20 +164,29 @@ class DeoldifyGenerator:
         for i, skip in enumerate(reversed(skips)):
             p = f"layers.{4 + i}"
 
-            def make_shuf(p=p, x=x):
+            fuse = self._fuse_blur(x, sd[p + ".shuf.conv.0.weight_orig" if p + ".shuf.conv.0.weight_orig" in sd else
+                                         p + ".shuf.conv.0.weight"].shape[0] // 4, skip.H)
+
+            def make_shuf(order, p=p, x=x):
                 s, sh = bn_scale_shift(sd, p + ".shuf.conv.1")      # conv -> BN, no activation between: fold
                 W = conv_weight(sd, p + ".shuf.conv.0")
-                return pack_conv(self.pack, W * s[:, None, None, None], x.cmap, x.span, bias=sh, pixshuf=True)
-            pc = self._conv(p + ".shuf", make_shuf)
+                return pack_conv(self.pack, W * s[:, None, None, None], x.cmap, x.span, bias=sh, pixshuf=order)
+            pc = self._shuf_conv(p + ".shuf", make_shuf, fuse)
             up_c = pc.Cout // 4
-            ps = b.tensor(2 * x.H, 2 * x.W, up_c)
-            b.conv(p + ".shuf", pc, x, ps, flags=nat.F_RELU_PRE | nat.F_OUT_PIXSHUF)
             ups, sks = pad_to(up_c, 8), pad_to(skip.C, 8)
             cat_span = ups + sks
             cat_pitch = pitch_for(cat_span)
             cat_buf = b.buf(skip.H * skip.W * cat_pitch, 2, zero_init=(ups != up_c or sks != skip.C))
-            # blur (+ nearest resize when the shuffled size != skip size, e.g. 36 -> 35 at rf=35)
-            b.blur_resize(p + ".blur", ps, View(cat_buf, 0, cat_pitch, skip.H, skip.W, up_c, ups))
+            if fuse:
+                # 1x1 conv + BN + ReLU + PixelShuffle(2) + blur in ONE kernel (HAVC_F_PS_BLUR): the shuffled tensor never
+                # reaches HBM (saves a write + a read of it: 5.1 GB per 16 frames at 560^2)
+                b.conv(p + ".shuf+blur", pc, x, View(cat_buf, 0, cat_pitch, skip.H, skip.W, up_c, ups),
+                       flags=nat.F_RELU_PRE | nat.F_OUT_PIXSHUF | nat.F_PS_BLUR)
+            else:
+                ps = b.tensor(2 * x.H, 2 * x.W, up_c)
+                b.conv(p + ".shuf", pc, x, ps, flags=nat.F_RELU_PRE | nat.F_OUT_PIXSHUF)
+                # blur (+ nearest resize when the shuffled size != skip size, e.g. 36 -> 35 at rf=35)
+                b.blur_resize(p + ".blur", ps, View(cat_buf, 0, cat_pitch, skip.H, skip.W, up_c, ups))
             so, sho = self._vecs(p + ".bn", lambda p=p: bn_scale_shift(sd, p + ".bn"))
             b.affine(p + ".bn", skip, View(cat_buf, ups, cat_pitch, skip.H, skip.W, skip.C, sks), so, sho, relu=True)
             cat = View(cat_buf, 0, cat_pitch, skip.H, skip.W, up_c + skip.C, cat_span,
@@ -179,12 +202,17 @@ class DeoldifyGenerator:
                     x = self._attention(b, p + ".conv.3", x)
 
         # ---- layers.8 PixelShuffle_ICNR (weight norm, bias, no BN) -> blur -> layers.9 dense merge ----
-        pc = self._conv("layers.8", lambda x=x: pack_conv(self.pack, conv_weight(sd, "layers.8.conv.0"), x.cmap, x.span,
-                                                           bias=sd["layers.8.conv.0.bias"], pixshuf=True))
-        ps8 = b.tensor(2 * x.H, 2 * x.W, c8)
-        assert ps8.H == S
-        b.conv("layers.8", pc, x, ps8, flags=nat.F_RELU_PRE | nat.F_OUT_PIXSHUF)
-        b.blur_resize("layers.8.blur", ps8, View(tail_buf, 0, tail_pitch, S, S, c8, c8s))
+        fuse8 = self._fuse_blur(x, c8, S)
+        pc = self._shuf_conv("layers.8", lambda order, x=x: pack_conv(self.pack, conv_weight(sd, "layers.8.conv.0"), x.cmap, x.span,
+                                                                       bias=sd["layers.8.conv.0.bias"], pixshuf=order), fuse8)
+        assert 2 * x.H == S
+        if fuse8:
+            b.conv("layers.8+blur", pc, x, View(tail_buf, 0, tail_pitch, S, S, c8, c8s),
+                   flags=nat.F_RELU_PRE | nat.F_OUT_PIXSHUF | nat.F_PS_BLUR)
+        else:
+            ps8 = b.tensor(2 * x.H, 2 * x.W, c8)
+            b.conv("layers.8", pc, x, ps8, flags=nat.F_RELU_PRE | nat.F_OUT_PIXSHUF)
+            b.blur_resize("layers.8.blur", ps8, View(tail_buf, 0, tail_pitch, S, S, c8, c8s))
         cat = View(tail_buf, 0, tail_pitch, S, S, c8 + 3, tail_span, tail_cmap)
 
         # ---- layers.10 res_block: 2 x (spectral conv3x3 + bias -> ReLU), + input; layers.11/12 ----

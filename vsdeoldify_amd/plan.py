@@ -143,6 +143,13 @@ def pack_conv(pack, W, cmap, Ci, bias=None, scale=None, shift=None, pixshuf=Fals
         cps = Cout // 4
         # packed row q*cps + c  <-  original row c*4 + q   (PixelShuffle(2): q = dy*2 + dx)
         perm = (np.arange(cps)[None, :] * 4 + np.arange(4)[:, None]).reshape(-1)
+        if pixshuf == "blur":
+            # HAVC_F_PS_BLUR: packed row (c // 64) * 256 + q * 64 + c % 64: one 256-column tile = 4 sub-pixels x 64 channels
+            assert cps % 64 == 0
+            cc = np.arange(cps)
+            perm = np.empty(Cout, np.int64)
+            for q in range(4):
+                perm[(cc // 64) * 256 + q * 64 + cc % 64] = cc * 4 + q
         Wt = Wt[perm]
         bias = None if bias is None else bias[perm]
         scale = None if scale is None else scale[perm]
@@ -221,6 +228,8 @@ class PlanBuilder:
             if flags & nat.F_OUT_PIXSHUF:
                 assert y.H == 2 * Ho and y.W == 2 * Wo and pc.Cout == 4 * y.C and y.C % 4 == 0, name
                 kw["Co"] = y.C
+                if flags & nat.F_PS_BLUR:
+                    assert pc.kh == 1 and stride == 1 and pad == 0 and y.C % 64 == 0 and pc.Npad % 256 == 0, name
             else:
                 assert y.H == Ho * out_step and y.W == Wo * out_step and y.C == pc.Cout, (name, y.H, Ho, y.C, pc.Cout)
                 kw["Co"] = y.span

@@ -41,9 +41,9 @@ def _load_pth(path):
 class GeneratorRuntime:
     """Packed weights on one GPU + a cache of nets keyed by (render size, max_batch)."""
 
-    def __init__(self, ctx, state_dict, arch, fuse_final=True):
+    def __init__(self, ctx, state_dict, arch, fuse_final=True, fuse_blur=True):
         self.ctx, self.arch = ctx, arch
-        self.gen = DeoldifyGenerator(state_dict, arch, fuse_final=fuse_final)
+        self.gen = DeoldifyGenerator(state_dict, arch, fuse_final=fuse_final, fuse_blur=fuse_blur)
         self.weights = nat.Weights(ctx, self.gen.blob)
         self.nets = {}
 
