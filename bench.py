@@ -151,7 +151,7 @@ def main():
         "whole_path_tflops": round(total_frames * 2759.32e9 / elapsed / 1e12 / world, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic,
-                     "kernel": "conv_igemm_kernel (layers.10 res-block 3x3 259->259 @560x560, 2 launches/pass)",
+                     "kernel": "conv_pipe_kernel<2,4,8,1> (layers.10 res-block 3x3 259->259 @560x560, 2 launches/pass; the 2nd also runs layers.11/12 in its epilogue)",
                      "launches_timed": int(launches.value), "avg_launch_ms": round(avg_ms.value, 4),
                      "flops_per_launch": conv_flops},
         "gpu_ms_per_frame": round(st.total_ms / max(st.frames, 1), 4),
