@@ -1,0 +1,67 @@
+"""DDColor (a13) — PARITY UNPINNED: vsddcolor is not under /root/reference and the reference holds no vectors at that boundary
+(oracle/ddcolor.py header).  CPU: the ConvNeXt pieces of the oracle restatement against the independent implementation shipped in
+the `transformers` package (pins the PUBLISHED encoder block, nothing DDColor-specific), plus shape / key bookkeeping.
+GPU: the HIP path against the oracle on seeded synthetic weights (self-consistency)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ddcolor as D
+from vsdeoldify_amd.synth import ddcolor_state_dict_spec, synth_ddcolor_state_dict
+
+SMALL = dict(depths=(1, 1, 2, 1), dec_layers=3)
+
+
+def _t(sd):
+    return {k: torch.as_tensor(v) for k, v in sd.items()}
+
+
+def test_spec_counts():
+    spec = ddcolor_state_dict_spec()
+    n = sum(int(np.prod(s)) for s in spec.values())
+    assert 220e6 < n < 230e6                                   # ConvNeXt-L encoder (196 M) + decoders
+    assert sum(1 for k in spec if k.endswith(".dwconv.weight")) == 36
+    assert spec["refine_net.0.0.weight_orig"] == (2, 103, 1, 1)
+
+
+def test_convnext_pieces_match_transformers():
+    tc = pytest.importorskip("transformers.models.convnext.modeling_convnext")
+    from transformers import ConvNextConfig
+    sd = _t(synth_ddcolor_state_dict(3, **SMALL))
+    cfg = ConvNextConfig(num_channels=3, patch_size=4, hidden_sizes=[192, 384, 768, 1536], depths=[1, 1, 2, 1], layer_scale_init_value=1.0)
+    torch.manual_seed(0)
+    x = torch.randn(2, 3, 64, 64)
+    # stem
+    emb = tc.ConvNextEmbeddings(cfg).eval()
+    with torch.no_grad():
+        emb.patch_embeddings.weight.copy_(sd["encoder.arch.downsample_layers.0.0.weight"]); emb.patch_embeddings.bias.copy_(sd["encoder.arch.downsample_layers.0.0.bias"])
+        emb.layernorm.weight.copy_(sd["encoder.arch.downsample_layers.0.1.weight"]); emb.layernorm.bias.copy_(sd["encoder.arch.downsample_layers.0.1.bias"])
+        ref = emb(x)
+        mine = D.layernorm_cf(torch.nn.functional.conv2d(x, sd["encoder.arch.downsample_layers.0.0.weight"], sd["encoder.arch.downsample_layers.0.0.bias"], stride=4),
+                              sd["encoder.arch.downsample_layers.0.1.weight"], sd["encoder.arch.downsample_layers.0.1.bias"])
+    assert torch.allclose(ref, mine, atol=2e-5), float((ref - mine).abs().max())
+    # block
+    p = "encoder.arch.stages.0.0"
+    layer = tc.ConvNextLayer(cfg, dim=192, drop_path=0.0).eval()
+    with torch.no_grad():
+        layer.dwconv.weight.copy_(sd[p + ".dwconv.weight"]); layer.dwconv.bias.copy_(sd[p + ".dwconv.bias"])
+        layer.layernorm.weight.copy_(sd[p + ".norm.weight"]); layer.layernorm.bias.copy_(sd[p + ".norm.bias"])
+        layer.pwconv1.weight.copy_(sd[p + ".pwconv1.weight"]); layer.pwconv1.bias.copy_(sd[p + ".pwconv1.bias"])
+        layer.pwconv2.weight.copy_(sd[p + ".pwconv2.weight"]); layer.pwconv2.bias.copy_(sd[p + ".pwconv2.bias"])
+        layer.layer_scale_parameter.copy_(sd[p + ".gamma"])
+        r2 = layer(ref)
+        m2 = D.convnext_block(sd, p, mine)
+    assert torch.allclose(r2, m2, atol=5e-5), float((r2 - m2).abs().max())
+
+
+def test_oracle_forward_shapes_and_determinism():
+    sd = synth_ddcolor_state_dict(1, **SMALL)
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        parts = D.forward(sd, x, return_parts=True, **SMALL)
+    assert parts["f3"].shape == (1, 1536, 2, 2) and parts["out2"].shape == (1, 256, 16, 16)
+    assert parts["out3"].shape == (1, 256, 64, 64) and parts["logits"].shape == (1, 100, 64, 64) and parts["ab"].shape == (1, 2, 64, 64)
+    assert 1.0 < float(parts["ab"].std()) < 30.0               # the synthetic weights give a live, unsaturated colour signal
+    frame = np.random.default_rng(0).integers(0, 256, (64, 64, 1), dtype=np.uint8).repeat(3, -1)
+    out = D.colorize_frame(sd, frame, **SMALL)
+    assert out.shape == (64, 64, 3) and out.dtype == np.uint8 and (out[..., 0] != out[..., 2]).mean() > 0.5

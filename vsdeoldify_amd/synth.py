@@ -264,3 +264,115 @@ def synth_zhang_state_dict(model, seed=0):
             raise KeyError(name)
     _CACHE[key] = sd
     return sd
+
+
+# ---- DDColor (public architecture, see oracle/ddcolor.py) ----------------------------------------------
+DDCOLOR_DEPTHS, DDCOLOR_DIMS = (3, 3, 27, 3), (192, 384, 768, 1536)
+
+
+def ddcolor_state_dict_spec(depths=DDCOLOR_DEPTHS, dec_layers=9, queries=100):
+    """name -> shape with the key names of the public DDColor checkpoints (encoder.arch.*, decoder.*, refine_net.0.0.*)."""
+    dims, hid, ffn = DDCOLOR_DIMS, 256, 2048
+    spec = OrderedDict()
+    e = "encoder.arch"
+
+    def ln(p, c):
+        spec[p + ".weight"], spec[p + ".bias"] = (c,), (c,)
+
+    def lin(p, o, i, *k):
+        spec[p + ".weight"], spec[p + ".bias"] = (o, i) + tuple(k), (o,)
+    lin(f"{e}.downsample_layers.0.0", dims[0], 3, 4, 4)
+    ln(f"{e}.downsample_layers.0.1", dims[0])
+    for i in range(1, 4):
+        ln(f"{e}.downsample_layers.{i}.0", dims[i - 1])
+        lin(f"{e}.downsample_layers.{i}.1", dims[i], dims[i - 1], 2, 2)
+    for i in range(4):
+        c = dims[i]
+        for j in range(depths[i]):
+            p = f"{e}.stages.{i}.{j}"
+            lin(p + ".dwconv", c, 1, 7, 7)
+            ln(p + ".norm", c)
+            lin(p + ".pwconv1", 4 * c, c)
+            lin(p + ".pwconv2", c, 4 * c)
+            spec[p + ".gamma"] = (c,)
+    for i in range(4):
+        ln(f"{e}.norm{i}", dims[i])
+    up_in = dims[3]
+    for li, (x_in, n_out) in enumerate(((dims[2], 512), (dims[1], 512), (dims[0], 256))):
+        p, up_out = f"decoder.layers.{li}", n_out // 2
+        _spectral(spec, p + ".shuf.conv.0", (up_out * 4, up_in, 1, 1)); _bn(spec, p + ".shuf.conv.1", up_out * 4)
+        _bn(spec, p + ".bn", x_in)
+        _spectral(spec, p + ".conv.0", (n_out, up_out + x_in, 3, 3)); _bn(spec, p + ".conv.2", n_out)
+        up_in = n_out
+    _spectral(spec, "decoder.last_shuf.conv.0", (256 * 16, 256, 1, 1)); _bn(spec, "decoder.last_shuf.conv.1", 256 * 16)
+    d = "decoder.color_decoder"
+    spec[d + ".query_feat.weight"] = (queries, hid)
+    spec[d + ".query_embed.weight"] = (queries, hid)
+    spec[d + ".level_embed.weight"] = (3, hid)
+    for i, c in enumerate((512, 512, 256)):
+        lin(f"{d}.input_proj.{i}", hid, c, 1, 1)
+    for i in range(dec_layers):
+        for kind, attn in (("cross", "multihead_attn"), ("self", "self_attn")):
+            p = f"{d}.transformer_{kind}_attention_layers.{i}"
+            spec[f"{p}.{attn}.in_proj_weight"], spec[f"{p}.{attn}.in_proj_bias"] = (3 * hid, hid), (3 * hid,)
+            lin(f"{p}.{attn}.out_proj", hid, hid)
+            ln(p + ".norm", hid)
+        p = f"{d}.transformer_ffn_layers.{i}"
+        lin(p + ".linear1", ffn, hid); lin(p + ".linear2", hid, ffn); ln(p + ".norm", hid)
+    ln(d + ".decoder_norm", hid)
+    for k in range(3):
+        lin(f"{d}.color_embed.layers.{k}", hid, hid)
+    _spectral(spec, "refine_net.0.0", (2, queries + 3, 1, 1), bias=True)
+    return spec
+
+
+def synth_ddcolor_state_dict(seed=0, depths=DDCOLOR_DEPTHS, dec_layers=9, queries=100):
+    """Seeded synthetic DDColor weights (no checkpoint exists offline): scales keep every stage O(1) and ab inside ~+-40."""
+    key = ("ddcolor", int(seed), tuple(depths), dec_layers, queries)
+    if key in _CACHE:
+        return _CACHE[key]
+    spec = ddcolor_state_dict_spec(depths, dec_layers, queries)
+    sd = OrderedDict()
+    for name, shape in spec.items():
+        if name in sd:
+            continue
+        r = _rng(seed, name)
+        leaf = name.rsplit(".", 1)[1]
+        parent = name.rsplit(".", 1)[0]
+        is_bn = (parent + ".running_mean") in spec
+        if leaf == "num_batches_tracked":
+            sd[name] = np.array(1000, np.int64)
+        elif is_bn:
+            post_relu = parent.endswith(".conv.2")
+            sd[name] = {"weight": r.uniform(0.8, 1.2, shape), "bias": r.standard_normal(shape) * 0.1,
+                        "running_mean": r.standard_normal(shape) * 0.1 + (0.5 if post_relu else 0.0),
+                        "running_var": r.uniform(0.7, 1.3, shape) * (0.5 if post_relu else 1.0)}[leaf].astype(np.float32)
+        elif leaf == "gamma":
+            sd[name] = r.uniform(0.05, 0.3, shape).astype(np.float32)
+        elif leaf == "weight_orig":
+            fan_in = int(np.prod(shape[1:]))
+            gain = 4.0 if name.startswith("refine_net") else np.sqrt(2.0)
+            wt = (r.standard_normal(shape) * gain / np.sqrt(fan_in)).astype(np.float32)
+            sigma0 = np.float32(r.uniform(0.5, 2.0))
+            sd[name] = wt * sigma0
+            v = _rng(seed, parent + ".weight_v").standard_normal(fan_in).astype(np.float32)
+            v /= np.linalg.norm(v)
+            t = sd[name].reshape(shape[0], -1) @ v
+            sd[parent + ".weight_v"] = v
+            sd[parent + ".weight_u"] = (t * (sigma0 / np.dot(t, t))).astype(np.float32)
+        elif leaf in ("weight_u", "weight_v"):
+            continue                                                     # filled with weight_orig
+        elif leaf == "bias" or leaf == "in_proj_bias":
+            is_ln = len(spec.get(parent + ".weight", ())) == 1
+            sd[name] = (r.standard_normal(shape) * (0.1 if is_ln else 0.02)).astype(np.float32)
+        elif len(shape) == 1:                                            # LayerNorm weight
+            sd[name] = r.uniform(0.8, 1.2, shape).astype(np.float32)
+        elif "query_" in name or "level_embed" in name:
+            sd[name] = r.standard_normal(shape).astype(np.float32)
+        else:                                                            # conv / linear weights
+            fan_in = int(np.prod(shape[1:]))
+            relu_next = any(t in name for t in ("pwconv1", "linear1", "color_embed.layers.0", "color_embed.layers.1"))
+            sd[name] = (r.standard_normal(shape) * np.sqrt((2.0 if relu_next else 1.0) / fan_in)).astype(np.float32)
+    out = OrderedDict((k, sd[k]) for k in spec)
+    _CACHE[key] = out
+    return out
