@@ -55,6 +55,16 @@ enum havc_op_type {
                                 model_out), flags&2: + bias then tanh (siggraph17 model_out); x f0; fp32 out */
     HAVC_OP_BILINEAR2 = 10,  /* 2-channel fp32 map, bilinear align_corners=False (nn.Upsample x4), x f0      */
     HAVC_OP_PREP_LAB_L = 11, /* u8 RGB -> CIELAB L (skimage rgb2lab, fp64) -> (L-50)/100 -> fp16 C8 ch 0      */
+    /* ---- DDColor (ConvNeXt encoder, colour-query transformer) ---- */
+    HAVC_OP_DWCONV7 = 12,    /* depthwise 7x7 pad 3 + bias; w_off: fp16 [49][Kc] (Kc = channel pitch), bias_off   */
+    HAVC_OP_LAYERNORM = 13,  /* LayerNorm over the Ci channels of every pixel / token: scale_off gamma, shift_off beta, f0 eps */
+    HAVC_OP_MHA = 14,        /* multi-head attention, head dim 32: Q = src view (Hi = queries, Wi = tokens per frame), K / V =
+                                buffer src2 (pitch res_cpitch, K at res_coff, V at aux0; Ho = keys, Wo = tokens per frame),
+                                kh = heads, f0 = softmax scale; dst view has the Q token stride                      */
+    HAVC_OP_PIXSHUF4_BLUR = 15, /* PixelShuffle(4) of a [Hi][Wi][16 Co] tensor whose channels are ordered (dy*4+dx)*Co + c,
+                                then the ICNR blur -> dst [4Hi][4Wi][Co]                                              */
+    HAVC_OP_PREP_DDCOLOR = 16,  /* u8 RGB -> Lab L -> RGB of Lab(L,0,0) -> imagenet normalise -> fp16 C8 (dst) and a 3-channel
+                                slice of src2 @ res_coff (the refine conv's image input)                             */
 };
 
 /* conv epilogue flags: v = acc + bias; RELU_PRE; v = v*scale+shift; v += residual; RELU_POST */
@@ -72,6 +82,9 @@ enum havc_op_type {
                                      (c / 64) * 256 + q * 64 + c % 64 (plan.py pack_conv pixshuf="blur"): a 256-column tile then
                                      holds all four sub-pixels of 64 channels, and GEMM rows are 16x16 pixel tiles that
                                      overlap by one row / column (the blur's top-left halo).                              */
+#define HAVC_F_GELU 0x400         /* exact (erf) GELU at the RELU_PRE position (ConvNeXt pwconv1)                            */
+#define HAVC_F_W_FROM_BUF 0x800   /* conv weights are ACTIVATIONS: buffer src2 holds, per frame, fp16 [Npad][Kc * 8] rows (the colour
+                                     embeddings of DDColor's einsum(bqc,bchw->bqhw)); launched once per frame; no residual  */
 #define HAVC_F_FUSE_RGB8 0x100    /* the conv output is NOT stored: a following 1x1 conv to 3 channels (fp32 weights at
                                      scale_off [3][Npad], bias at shift_off [3]) + OUT_RGB8 maths run in the epilogue and
                                      write u8 RGB to buffer aux0 (layers.10.1 + layers.11 + layers.12 of the generator);
@@ -166,6 +179,12 @@ int havc_deoldify_frames(havc_ctx* ctx, havc_net* video, havc_net* second, float
  * bilinear ab -> frame size, lab2rgb, uint8(clip(x*255)).  rgb_in/rgb_out: host u8 interleaved RGB, n frames of w*h*3. */
 int havc_zhang_frames(havc_ctx* ctx, havc_net* net, const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames, int width,
                       int height);
+/* havc_ddcolor_frames stands where vsddcolor.ddcolor(clip, model, input_size, ...) is called (vsslib/vsmodels.py:353-360,
+ * model 0 / 1) for frames that are already input_size x input_size (S of `net`; the HAVC configurations with an even
+ * render_factor): Lab L of the frame -> RGB of Lab(L, 0, 0) -> DDColor (ConvNeXt-L encoder, pixel-shuffle decoder, colour-query
+ * transformer, refine conv; the plan of `net`) -> Lab(L, ab) -> RGB u8.  PARITY UNPINNED: vsddcolor is an external wheel that is
+ * not part of the reference tree (oracle/ddcolor.py).  rgb_in / rgb_out: host u8 interleaved RGB, n frames of S*S*3. */
+int havc_ddcolor_frames(havc_ctx* ctx, havc_net* net, const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames);
 /* Pillow Image.resize (BILINEAR = 2, BICUBIC = 3), 8 bits per channel, bit-exact (libImaging/Resample.c) */
 int havc_pil_resize(havc_ctx* ctx, const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int resample);
 

@@ -65,3 +65,79 @@ def test_oracle_forward_shapes_and_determinism():
     frame = np.random.default_rng(0).integers(0, 256, (64, 64, 1), dtype=np.uint8).repeat(3, -1)
     out = D.colorize_frame(sd, frame, **SMALL)
     assert out.shape == (64, 64, 3) and out.dtype == np.uint8 and (out[..., 0] != out[..., 2]).mean() > 0.5
+
+
+# ---- GPU: HIP path vs the oracle on seeded synthetic weights (self-consistency; parity unpinned) -------------------------
+def _views(net_ops, names, name):
+    i = names.index(name)
+    return net_ops[i]
+
+
+def _download(net, op, C, batch):
+    """NHWC fp16 output view of a plan op -> float32 [B, C, H, W]"""
+    pitch, coff, H, W = int(op["dst_cpitch"]), int(op["dst_coff"]), int(op["Ho"]), int(op["Wo"])
+    raw = net.download(int(op["dst"]), (batch, H, W, pitch), np.float16)
+    return raw[..., coff:coff + C].astype(np.float32).transpose(0, 3, 1, 2)
+
+
+@pytest.mark.gpu
+def test_gpu_ddcolor_stages_match_oracle(ctx):
+    from vsdeoldify_amd.ddcolor import DDColorRuntime
+    from oracle import zhang as Z
+    S, B = 64, 2
+    sd = synth_ddcolor_state_dict(1, **SMALL)
+    rt = DDColorRuntime(ctx, sd, **SMALL)
+    try:
+        r = np.random.default_rng(5)
+        frames = r.integers(0, 256, (B, S, S, 1), dtype=np.uint8).repeat(3, -1)
+        frames[1] = r.integers(0, 256, (S, S, 3), dtype=np.uint8)                # a non-gray frame: only its L may matter
+        out = rt.colorize(frames)
+        net = rt.net(S, B)
+        gray = np.stack([Z.lab2rgb(np.concatenate([Z.rgb2lab(f)[..., :1], np.zeros((S, S, 2))], -1)) for f in frames]).astype(np.float32)
+        with torch.no_grad():
+            parts = D.forward(sd, torch.from_numpy(gray).permute(0, 3, 1, 2), return_parts=True, **SMALL)
+        names, ops = net.names, net.plan_ops
+        checks = [("encoder.arch.norm0", "f0", 192, 0.03), ("encoder.arch.norm3", "f3", 1536, 0.05), ("decoder.layers.0.conv", "out0", 512, 0.05),
+                  ("decoder.layers.2.conv", "out2", 256, 0.05), ("decoder.last_shuf.shuf+blur", "out3", 256, 0.05),
+                  ("refine_net.0.0", "ab", 2, 0.25)]
+        for opname, key, C, tol in checks:
+            got = _download(net, _views(ops, names, opname), C, B)
+            ref = parts[key].numpy()
+            err = np.abs(got - ref)
+            assert err.max() < tol * max(1.0, float(np.abs(ref).max())) and err.mean() < tol * 0.1 * max(1.0, float(np.abs(ref).std())), \
+                (opname, float(err.max()), float(err.mean()), float(np.abs(ref).max()))
+        # logits live in channels 8..107 of the coarse buffer
+        lop = _views(ops, names, "decoder.color_decoder.einsum")
+        raw = net.download(int(lop["dst"]), (B, S, S, int(lop["dst_cpitch"])), np.float16)[..., 8:108].astype(np.float32).transpose(0, 3, 1, 2)
+        ref = parts["logits"].numpy()
+        assert np.abs(raw - ref).max() < 0.02 * np.abs(ref).max() + 0.1, float(np.abs(raw - ref).max())
+        # end to end: frame in -> frame out against the oracle wrapper
+        for f, o in zip(frames, out):
+            want = D.colorize_frame(sd, f, **SMALL)
+            d = np.abs(o.astype(int) - want.astype(int))
+            assert (d <= 2).mean() > 0.99 and d.max() <= 12, (float((d <= 2).mean()), int(d.max()))
+    finally:
+        rt.close()
+
+
+@pytest.mark.gpu
+def test_gpu_ddcolor_full_depth_end_to_end(ctx):
+    """all 36 ConvNeXt blocks and 9 decoder layers at 96x96 (three feature levels of 6x6 / 12x12 / 24x24 keys)"""
+    from vsdeoldify_amd.ddcolor import DDColorRender
+    sd = synth_ddcolor_state_dict(2)
+    S = 96
+    r = np.random.default_rng(9)
+    frame = np.clip(r.normal(128, 50, (S, S, 1)), 0, 255).astype(np.uint8).repeat(3, -1)
+    dd = DDColorRender(model=1, input_size=S, state_dict=sd)
+    try:
+        got = dd.colorize_frame(frame)
+        want = D.colorize_frame(sd, frame)
+        d = np.abs(got.astype(int) - want.astype(int))
+        assert (d <= 2).mean() > 0.98 and d.max() <= 16, (float((d <= 2).mean()), int(d.max()))
+        assert (got[..., 0] != got[..., 2]).mean() > 0.5                      # a coloured frame, not the gray input
+        with pytest.raises(ValueError):
+            dd.colorize_frame(frame[:64, :64])
+    finally:
+        dd.rt.close()
+    with pytest.raises(ValueError):
+        DDColorRender(model=2, input_size=S, state_dict=sd)

@@ -43,6 +43,10 @@ __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v a
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : (leaky ? v[r] * p.f2 : 0.f);
     }
+    if (p.flags & HAVC_F_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.f + erff(v[r] * 0.70710678118654752f));
+    }
     if (p.flags & HAVC_F_AFFINE) {
         const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
         const float4 sh = *reinterpret_cast<const float4*>(p.shift + n);

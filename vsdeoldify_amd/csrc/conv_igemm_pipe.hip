@@ -390,6 +390,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[ni][mi][r] + bb[r];
                     if (p.flags & HAVC_F_RELU_PRE) v = v > 0.f ? v : (leaky ? v * p.f2 : 0.f);
+                    if (p.flags & HAVC_F_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
                     if (p.flags & HAVC_F_AFFINE) v = v * ss[r] + hh[r];
                     o[r] = (half_t)v;
                 }

@@ -253,6 +253,13 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             ConvArgs a{};
             a.x = (const half_t*)bufptr(n, op.src);
             a.w = wptr<half_t>(n, op.w_off);
+            if (op.flags & HAVC_F_W_FROM_BUF) {
+                if (op.src2 < 0 || op.src2 >= (int)n->bufs.size() || (op.flags & HAVC_F_RESIDUAL))
+                    return fail(c, HAVC_E_INVALID, "conv op: W_FROM_BUF needs a weight buffer in src2 and no residual");
+                if ((uint64_t)n->bufdesc[op.src2].elems_per_frame * n->bufdesc[op.src2].elem_bytes < (uint64_t)op.Npad * op.Kc * 16)
+                    return fail(c, HAVC_E_INVALID, "conv op: W_FROM_BUF buffer smaller than Npad x Kc x 16 bytes per frame");
+                a.w = (const half_t*)bufptr(n, op.src2);
+            }
             a.bias = wptr<float>(n, op.bias_off);
             a.scale = wptr<float>(n, op.scale_off);
             a.shift = wptr<float>(n, op.shift_off);
@@ -309,6 +316,12 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                 int chunk = batch;
                 const uint64_t big = std::max(xf, std::max(yf, rf));
                 if (big * (uint64_t)batch > lim) chunk = (int)std::max<uint64_t>(1, lim / big);
+                const char* w0 = (const char*)a.w;
+                uint64_t wf = 0;
+                if (op.flags & HAVC_F_W_FROM_BUF) {        // per-frame weights taken from an activation buffer: one launch per frame
+                    chunk = 1;
+                    wf = (uint64_t)n->bufdesc[op.src2].elems_per_frame * n->bufdesc[op.src2].elem_bytes;
+                }
                 const char* x0 = (const char*)a.x; const char* r0 = (const char*)a.res; char* y0 = (char*)a.y;
                 uint8_t* rgb0 = a.fuse_rgb;
                 for (int f0 = 0; f0 < batch && e == 0; f0 += chunk) {
@@ -316,6 +329,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                     a.x = (const half_t*)(x0 + (uint64_t)f0 * xf);
                     a.y = y0 + (uint64_t)f0 * yf;
                     if (r0) a.res = (const half_t*)(r0 + (uint64_t)f0 * rf);
+                    if (wf) a.w = (const half_t*)(w0 + (uint64_t)f0 * wf);
                     if (rgb0) a.fuse_rgb = rgb0 + (uint64_t)f0 * op.Ho * op.Wo * 3;
                     a.M = nb * rows_per_frame;
                     a.x_bytes = (unsigned)std::min<uint64_t>(xf * (uint64_t)nb + 256, 0xEFFFFFFFull);
@@ -368,6 +382,32 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
         case HAVC_OP_PREP_LAB_L:
             e = launch_prep_lab_l((const uint8_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
                                   (int64_t)batch * op.Hi * op.Wi, s);
+            break;
+        case HAVC_OP_DWCONV7:
+            if (op.w_off < 0 || (op.Ci & 7)) return fail(c, HAVC_E_INVALID, "dwconv7 op: weights / channel count");
+            e = launch_dwconv7((const half_t*)bufptr(n, op.src), wptr<half_t>(n, op.w_off), wptr<float>(n, op.bias_off), (half_t*)bufptr(n, op.dst),
+                               batch, op.Hi, op.Wi, op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff, op.Kc, s);
+            break;
+        case HAVC_OP_LAYERNORM:
+            if (op.scale_off < 0 || op.shift_off < 0) return fail(c, HAVC_E_INVALID, "layernorm op: gamma / beta");
+            e = launch_layernorm_c((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), wptr<float>(n, op.scale_off),
+                                   wptr<float>(n, op.shift_off), op.f0, (int64_t)batch * op.Hi * op.Wi, op.Ci, op.src_cpitch, op.src_coff,
+                                   op.dst_cpitch, op.dst_coff, s);
+            break;
+        case HAVC_OP_MHA:
+            if (op.src2 < 0 || op.Ci != op.kh * 32) return fail(c, HAVC_E_INVALID, "mha op: K/V buffer, head dim 32");
+            e = launch_mha32((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, op.Wi, (const half_t*)bufptr(n, op.src2), op.res_cpitch,
+                             op.res_coff, op.aux0, op.Wo, (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff, op.Wi, batch, op.kh, op.Hi,
+                             op.Ho, op.f0, s);
+            break;
+        case HAVC_OP_PIXSHUF4_BLUR:
+            e = launch_pixshuf4_blur((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), batch, op.Hi, op.Wi, op.Co, op.src_cpitch,
+                                     op.src_coff, op.dst_cpitch, op.dst_coff, s);
+            break;
+        case HAVC_OP_PREP_DDCOLOR:
+            e = launch_prep_ddcolor((const uint8_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
+                                    op.src2 >= 0 ? (half_t*)bufptr(n, op.src2) : nullptr, op.res_cpitch, op.res_coff,
+                                    (int64_t)batch * op.Hi * op.Wi, s);
             break;
         default:
             return fail(c, HAVC_E_INVALID, "unknown op type");
@@ -838,6 +878,36 @@ int havc_zhang_frames(havc_ctx* c, havc_net* net, const uint8_t* rgb_in, uint8_t
         int e = launch_zhang_post(d_in, (const float*)net->bufs[net->out_buf], S, S, d_out, b, width, height, c->stream);
         c->stats.launches++;
         if (e) return hip_fail(c, (hipError_t)e, "zhang post");
+        HIP_TRY(c, hipMemcpyAsync(rgb_out + (size_t)f0 * fb, d_out, fb * b, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    c->stats.frames += n_frames;
+    return t.finish();
+}
+
+int havc_ddcolor_frames(havc_ctx* c, havc_net* net, const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames) {
+    if (!c || !net || !rgb_in || !rgb_out || n_frames < 0) return fail(c, HAVC_E_INVALID, "ddcolor_frames: bad args");
+    if (net->ctx != c || net->bufdesc[net->out_buf].elem_bytes != 2) return fail(c, HAVC_E_INVALID, "ddcolor_frames: not a DDColor net of this ctx");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const int S = net->S, maxb = net->max_batch;
+    const size_t fb = (size_t)S * S * 3;
+    const int ab_pitch = (int)(net->bufdesc[net->out_buf].elems_per_frame / ((size_t)S * S));
+    int rc;
+    if ((rc = ensure_scratch(c, 0, fb * maxb)) || (rc = ensure_scratch(c, 3, fb * maxb))) return rc;
+    uint8_t *d_in = (uint8_t*)c->scratch[0], *d_out = (uint8_t*)c->scratch[3];
+    Timer t(c);
+    for (int f0 = 0; f0 < n_frames; f0 += maxb) {
+        const int b = std::min(maxb, n_frames - f0);
+        HIP_TRY(c, hipMemcpyAsync(d_in, rgb_in + (size_t)f0 * fb, fb * b, hipMemcpyHostToDevice, c->stream));
+        net->in_override = d_in;
+        rc = run_ops_locked(net, 0, (int)net->ops.size(), b);
+        net->in_override = nullptr;
+        if (rc) return rc;
+        c->stats.total_flops += net->flops_per_frame * b;
+        int e = launch_ddcolor_post(d_in, (const half_t*)net->bufs[net->out_buf], ab_pitch, 0, d_out, (int64_t)b * S * S, c->stream);
+        c->stats.launches++;
+        if (e) return hip_fail(c, (hipError_t)e, "ddcolor post");
         HIP_TRY(c, hipMemcpyAsync(rgb_out + (size_t)f0 * fb, d_out, fb * b, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }

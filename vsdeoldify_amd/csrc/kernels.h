@@ -84,6 +84,18 @@ int launch_chroma_stabilizer_adaptive(const uint8_t* stable, const uint8_t* inew
                                       uint8_t* out, int w, int h, hipStream_t s);
 int launch_color_temporal_stabilizer(const uint8_t* const* frames, const double* weights, int n, uint8_t* out, int64_t npix,
                                      hipStream_t s);
+// ddcolor.hip (+ the Lab wrapper kernels in zhang.hip)
+int launch_prep_ddcolor(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff, half_t* y2, int y2_cpitch, int y2_coff, int64_t npix,
+                        hipStream_t s);
+int launch_ddcolor_post(const uint8_t* orig, const half_t* ab, int ab_cpitch, int ab_coff, uint8_t* out, int64_t npix, hipStream_t s);
+int launch_dwconv7(const half_t* x, const half_t* w, const float* bias, half_t* y, int B, int H, int W, int C, int x_cpitch, int x_coff,
+                   int y_cpitch, int y_coff, int w_pitch, hipStream_t s);
+int launch_layernorm_c(const half_t* x, half_t* y, const float* gamma, const float* beta, float eps, int64_t npix, int C, int x_cpitch,
+                       int x_coff, int y_cpitch, int y_coff, hipStream_t s);
+int launch_mha32(const half_t* q, int q_cpitch, int q_coff, int q_tok, const half_t* kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,
+                 half_t* o, int o_cpitch, int o_coff, int o_tok, int B, int heads, int Lq, int Lk, float scale, hipStream_t s);
+int launch_pixshuf4_blur(const half_t* x, half_t* y, int B, int Hi, int Wi, int C, int x_cpitch, int x_coff, int y_cpitch, int y_coff,
+                         hipStream_t s);
 // tweaks.hip: image_tweak chain (Pillow hue shift, ImageEnhance Brightness / Contrast / Color, hue-range mask), Y table of
 // luma_adjusted_levels, restore_color_gradient.
 #define HAVC_MAX_HUE_RANGES 8

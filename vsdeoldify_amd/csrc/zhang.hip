@@ -103,6 +103,59 @@ int launch_zhang_post(const uint8_t* orig, const float* ab, int abH, int abW, ui
     return (int)hipGetLastError();
 }
 
+// ---- DDColor wrapper (oracle/ddcolor.py colorize_frame): the network sees the RGB rendering of Lab(L, 0, 0), imagenet-normalised ----
+__constant__ double kRgbFromXyz[9] = {3.240481343200526, -1.5371515162713185, -0.4985363261688878,
+                                      -0.9692549499965682, 1.8759900014898907, 0.04155592655829284,
+                                      0.05564663913517716, -0.20404133836651123, 1.0573110696453443};
+__device__ __forceinline__ void lab_to_rgb01(double L, double a, double bb, double& r, double& g, double& b) {
+    const double fy = (L + 16.0) / 116.0;
+    const double fx = a / 500.0 + fy;
+    double fz = fy - bb / 200.0;
+    fz = fz < 0.0 ? 0.0 : fz;
+    const double X = lab_finv(fx) * 0.95047, Y = lab_finv(fy), Z = lab_finv(fz) * 1.08883;
+    r = fmin(fmax(linear_to_srgb(kRgbFromXyz[0] * X + kRgbFromXyz[1] * Y + kRgbFromXyz[2] * Z), 0.0), 1.0);
+    g = fmin(fmax(linear_to_srgb(kRgbFromXyz[3] * X + kRgbFromXyz[4] * Y + kRgbFromXyz[5] * Z), 0.0), 1.0);
+    b = fmin(fmax(linear_to_srgb(kRgbFromXyz[6] * X + kRgbFromXyz[7] * Y + kRgbFromXyz[8] * Z), 0.0), 1.0);
+}
+__global__ void prep_ddcolor_kernel(const uint8_t* __restrict__ rgb, half_t* __restrict__ y, int y_cpitch, int y_coff, half_t* __restrict__ y2,
+                                    int y2_cpitch, int y2_coff, int64_t npix) {
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const double L = rgb_to_L(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
+        double c[3];
+        lab_to_rgb01(L, 0.0, 0.0, c[0], c[1], c[2]);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)0.f;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) o[e] = (half_t)(((float)c[e] - mean[e]) / stdv[e]);
+        *reinterpret_cast<half8*>(y + i * y_cpitch + y_coff) = o;
+        if (y2) {                                           // the refine conv's image slice: 3 channels at an arbitrary (4-aligned) offset
+            half_t* q = y2 + i * y2_cpitch + y2_coff;
+            q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+        }
+    }
+}
+int launch_prep_ddcolor(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff, half_t* y2, int y2_cpitch, int y2_coff, int64_t npix,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(prep_ddcolor_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, y, y_cpitch, y_coff, y2, y2_cpitch, y2_coff, npix);
+    return (int)hipGetLastError();
+}
+// Lab(L of the original frame, ab from the network: fp16 NHWC channels 0, 1) -> RGB u8, truncating cast of clip(x, 0, 1) * 255
+__global__ void ddcolor_post_kernel(const uint8_t* __restrict__ orig, const half_t* __restrict__ ab, int ab_cpitch, int ab_coff,
+                                    uint8_t* __restrict__ out, int64_t npix) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const double L = rgb_to_L(orig[i * 3], orig[i * 3 + 1], orig[i * 3 + 2]);
+        double r, g, b;
+        lab_to_rgb01(L, (double)(float)ab[i * ab_cpitch + ab_coff], (double)(float)ab[i * ab_cpitch + ab_coff + 1], r, g, b);
+        out[i * 3] = (uint8_t)(int)(r * 255.0); out[i * 3 + 1] = (uint8_t)(int)(g * 255.0); out[i * 3 + 2] = (uint8_t)(int)(b * 255.0);
+    }
+}
+int launch_ddcolor_post(const uint8_t* orig, const half_t* ab, int ab_cpitch, int ab_coff, uint8_t* out, int64_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(ddcolor_post_kernel, dim3(grid_for(npix)), dim3(256), 0, s, orig, ab, ab_cpitch, ab_coff, out, npix);
+    return (int)hipGetLastError();
+}
+
 // ---- Pillow 8bpc resample: out = clip8((2^21 + sum_k px[xmin+k] * coef[k]) >> 22) ----
 __global__ void pil_resize_h_kernel(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const int* __restrict__ bounds,
                                     const int* __restrict__ kk, int ksize, int sw, int dw, int64_t rows) {

@@ -1,0 +1,84 @@
+"""DDColor on the MI355X behind the call shape of `vsddcolor.ddcolor` as vs-deoldify uses it (vsslib/vsmodels.py:298-363).
+
+PARITY UNPINNED (external wheel, not in the reference tree; oracle/ddcolor.py).  `DDColorRender.colorize_frame` takes / returns
+u8 HWC frames that are already input_size x input_size (input_size = trunc(render_factor / 2) * 32, vsmodels.py:302); the RGBH /
+RGBS <-> RGB24 casts around the call stay in VapourSynth.  No CPU fallback: everything runs through libhavc_mi355.
+"""
+import numpy as np
+
+from . import _native as nat
+from .ddcolor_net import DDColorGenerator
+from .render import get_context
+
+
+class DDColorRuntime:
+    """Packed DDColor weights on one GPU + a cache of nets keyed by (input size, max_batch)."""
+
+    def __init__(self, ctx, state_dict, depths=(3, 3, 27, 3), dec_layers=9):
+        self.ctx = ctx
+        self.gen = DDColorGenerator(state_dict, depths, dec_layers)
+        self.weights = nat.Weights(ctx, self.gen.blob)
+        self.nets = {}
+
+    def net(self, S, max_batch=1):
+        key = (S, max_batch)
+        if key not in self.nets:
+            ops, bufs, i, o, names, consts = self.gen.plan(S)
+            n = nat.Net(self.ctx, self.weights, ops, bufs, i, o, S, max_batch)
+            n.names, n.plan_ops = names, ops
+            for buf, arr, pitch, rows_per_frame in consts:               # constant maps: one copy per frame slot
+                a = np.zeros((max_batch, rows_per_frame, pitch), np.float16)
+                a[:, :arr.shape[0], :arr.shape[1]] = arr.astype(np.float16)[None]
+                n.upload(buf, a)
+            self.nets[key] = n
+        return self.nets[key]
+
+    def colorize(self, frames):
+        """frames: uint8 [N, S, S, 3] -> uint8 [N, S, S, 3]."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        assert frames.ndim == 4 and frames.shape[1] == frames.shape[2] and frames.shape[3] == 3 and frames.shape[1] % 32 == 0
+        net = self.net(frames.shape[1], min(len(frames), 8))
+        out = np.empty_like(frames)
+        nat.check(self.ctx.lib.havc_ddcolor_frames(self.ctx.h, net.h, nat.as_ptr(frames), nat.as_ptr(out), len(frames)), self.ctx.h)
+        return out
+
+    def close(self):
+        for n in self.nets.values():
+            n.close()
+        self.nets.clear()
+        self.weights.close()
+
+
+def load_state_dict(path):
+    """ddcolor_modelscope.pth / ddcolor_artistic.pth: {'params': state_dict} or a bare state dict (public checkpoint layout)."""
+    import torch
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    sd = sd.get("params", sd)
+    return {k: v.numpy() for k, v in sd.items()}
+
+
+class DDColorRender:
+    """What `vsddcolor.ddcolor(clip, model, input_size, ...)` does per frame, for frames already at input_size."""
+
+    MODEL_FILES = {0: "ddcolor_modelscope.pth", 1: "ddcolor_artistic.pth"}          # __init__.py:2367-2371
+
+    def __init__(self, model=1, input_size=512, device_index=0, state_dict=None, model_dir=None, depths=(3, 3, 27, 3), dec_layers=9):
+        if model not in self.MODEL_FILES:
+            raise ValueError("ddcolor: model must be 0 (modelscope) or 1 (artistic); 2/3 are siggraph17/eccv16 (ModelColorization)")
+        if input_size % 32:
+            raise ValueError("ddcolor: input_size must be a multiple of 32")
+        if device_index == 99:
+            raise ValueError("device_index=99 (CPU) is not supported: this library is MI355X only")
+        self.input_size = input_size
+        if state_dict is None:
+            import os
+            if model_dir is None:
+                raise ValueError("ddcolor: pass state_dict or model_dir (the vsddcolor models folder)")
+            state_dict = load_state_dict(os.path.join(model_dir, self.MODEL_FILES[model]))
+        self.rt = DDColorRuntime(get_context(device_index), state_dict, depths, dec_layers)
+
+    def colorize_frame(self, frame):
+        f = np.asarray(frame)
+        if f.shape[:2] != (self.input_size, self.input_size):
+            raise ValueError(f"ddcolor: frame {f.shape[:2]} is not input_size x input_size ({self.input_size})")
+        return self.rt.colorize(f[None])[0]

@@ -1,0 +1,249 @@
+"""DDColor as a plan over the HIP ops: weight folding / packing and op emission for one input size.
+
+PARITY UNPINNED -- the architecture is the published one (piddnad/DDColor; see oracle/ddcolor.py for what is known and what is
+not): ConvNeXt-L encoder, three UnetBlockWide-style decoder stages + a x4 pixel shuffle, MultiScaleColorDecoder (100 queries,
+9 layers), refine conv.  State-dict keys as in the public checkpoints (vsdeoldify_amd/synth.py:ddcolor_state_dict_spec).
+
+How the graph maps onto the existing kernels:
+  * every Linear / 1x1 / 2x2 s2 / 4x4 s4 / 3x3 conv is `conv_pipe_kernel` (tokens are pixels of a 1 x 112 image); GELU, layer
+    scale + residual, out-projection + residual are conv epilogues (GELU / AFFINE + RESIDUAL / RESIDUAL);
+  * depthwise 7x7, channel LayerNorm, multi-head attention (head dim 32), PixelShuffle(4)+blur: csrc/ddcolor.hip;
+  * position encodings never touch the GPU as such: K = (src + pos) Wk + bk = src Wk + (pos Wk + bk), and the bracket is a
+    constant map per layer and size, computed here in fp32 and added through the RESIDUAL epilogue (same for the query embedding);
+  * einsum(bqc,bchw->bqhw) is a 1x1 conv whose weight rows ARE the colour embeddings (HAVC_F_W_FROM_BUF).
+"""
+import math
+
+import numpy as np
+
+from . import _native as nat
+from .plan import PlanBuilder, View, WeightPack, bn_scale_shift, conv_weight, pack_conv, pad_to, pitch_for, to_np
+
+DEPTHS, DIMS = (3, 3, 27, 3), (192, 384, 768, 1536)
+HIDDEN, HEADS, QUERIES, TOK = 256, 8, 100, 112            # TOK: tokens per frame incl. 12 pad rows (= Npad of the einsum conv)
+MEAN = np.array([0.485, 0.456, 0.406], np.float32)
+STD = np.array([0.229, 0.224, 0.225], np.float32)
+
+
+def position_sine(h, w, num_pos_feats=HIDDEN // 2, temperature=10000.0):
+    """PositionEmbeddingSine(normalize=True) -> [h * w, 2 * num_pos_feats] float32 (row-major pixels)."""
+    y = np.arange(1, h + 1, dtype=np.float32)[:, None].repeat(w, 1)
+    x = np.arange(1, w + 1, dtype=np.float32)[None, :].repeat(h, 0)
+    eps, scale = np.float32(1e-6), np.float32(2 * math.pi)
+    y = y / (y[-1:, :] + eps) * scale
+    x = x / (x[:, -1:] + eps) * scale
+    dim_t = np.arange(num_pos_feats, dtype=np.float32)
+    dim_t = (np.float32(temperature) ** (2 * np.floor(dim_t / 2) / np.float32(num_pos_feats))).astype(np.float32)
+    px, py = x[:, :, None] / dim_t, y[:, :, None] / dim_t
+    px = np.stack((np.sin(px[:, :, 0::2]), np.cos(px[:, :, 1::2])), axis=3).reshape(h, w, -1)
+    py = np.stack((np.sin(py[:, :, 0::2]), np.cos(py[:, :, 1::2])), axis=3).reshape(h, w, -1)
+    return np.concatenate((py, px), axis=2).reshape(h * w, -1).astype(np.float32)
+
+
+class DDColorGenerator:
+    def __init__(self, state_dict, depths=DEPTHS, dec_layers=9):
+        self.sd, self.depths, self.dec_layers = to_np(state_dict), tuple(depths), dec_layers
+        self.pack, self._pc, self._vec = WeightPack(), {}, {}
+        self._frozen = False
+        self.plan(64)
+        self.blob = self.pack.blob()
+        self._frozen = True
+
+    # ---- cached packing ---------------------------------------------------------------------------------------------
+    def _conv(self, key, fn):
+        if key not in self._pc:
+            assert not self._frozen, key
+            self._pc[key] = fn()
+        return self._pc[key]
+
+    def _vecs(self, key, fn):
+        if key not in self._vec:
+            assert not self._frozen, key
+            self._vec[key] = tuple(self.pack.add(np.asarray(v)) for v in fn())
+        return self._vec[key]
+
+    def _lin(self, key, x, W, bias=None, scale=None, shift=None):
+        """Linear / conv weights [out, in(, kh, kw)] on view x."""
+        W = np.asarray(W, np.float32)
+        if W.ndim == 2:
+            W = W[:, :, None, None]
+        return self._conv(key, lambda: pack_conv(self.pack, W, x.cmap, x.span, bias=bias, scale=scale, shift=shift))
+
+    def _ln(self, b, name, key, x, y, eps):
+        g, be = self._vecs(key, lambda: (self.sd[key + ".weight"].astype(np.float32), self.sd[key + ".bias"].astype(np.float32)))
+        b.layernorm(name, x, y, g, be, eps)
+        return y
+
+    # ---- the plan -------------------------------------------------------------------------------------------------------
+    def plan(self, S):
+        assert S % 32 == 0
+        sd, b = self.sd, PlanBuilder()
+        consts = []                                            # (buffer id, float32 array [rows, channels], row pitch in channels)
+        in_buf = b.buf(S * S * 3, 1)
+        x0 = b.tensor(S, S, 3)
+        coarse_pitch = pitch_for(112)
+        coarse_buf = b.buf(S * S * coarse_pitch, 2, zero_init=True)      # channels 0-2 image, 8-107 logits (108-111 pad-token junk)
+        b.prep_ddcolor("prep", in_buf, S, x0, View(coarse_buf, 0, coarse_pitch, S, S, 3, 8))
+
+        # ---- ConvNeXt encoder ----
+        e = "encoder.arch"
+        feats, x = [], x0
+        for i in range(4):
+            d = f"{e}.downsample_layers.{i}"
+            c = DIMS[i]
+            if i == 0:
+                pc = self._lin(d + ".0", x, sd[d + ".0.weight"], bias=sd[d + ".0.bias"])
+                t = b.tensor(x.H // 4, x.W // 4, c)
+                b.conv(d + ".0", pc, x, t, stride=4)
+                x = self._ln(b, d + ".1", d + ".1", t, b.tensor(t.H, t.W, c), 1e-6)
+            else:
+                n = self._ln(b, d + ".0", d + ".0", x, b.tensor(x.H, x.W, x.C), 1e-6)
+                pc = self._lin(d + ".1", n, sd[d + ".1.weight"], bias=sd[d + ".1.bias"])
+                x = b.tensor(n.H // 2, n.W // 2, c)
+                b.conv(d + ".1", pc, n, x, stride=2)
+            # two activation buffers ping-pong through the blocks of a stage, the scratch tensors are shared
+            dbuf, nbuf, hbuf, alt = b.tensor(x.H, x.W, c), b.tensor(x.H, x.W, c), b.tensor(x.H, x.W, 4 * c), b.tensor(x.H, x.W, c)
+            for j in range(self.depths[i]):
+                p = f"{e}.stages.{i}.{j}"
+                wdw, bdw = self._vecs(p + ".dwconv", lambda p=p, x=x: (
+                    self._dw_pack(sd[p + ".dwconv.weight"], x.span), sd[p + ".dwconv.bias"].astype(np.float32)))
+                b.dwconv7(p + ".dwconv", x, dbuf, wdw, bdw, x.span)
+                self._ln(b, p + ".norm", p + ".norm", dbuf, nbuf, 1e-6)
+                pc1 = self._lin(p + ".pwconv1", nbuf, sd[p + ".pwconv1.weight"], bias=sd[p + ".pwconv1.bias"])
+                b.conv(p + ".pwconv1", pc1, nbuf, hbuf, flags=nat.F_GELU)
+                pc2 = self._lin(p + ".pwconv2", hbuf, sd[p + ".pwconv2.weight"], bias=sd[p + ".pwconv2.bias"],
+                                scale=sd[p + ".gamma"].astype(np.float32), shift=np.zeros(c, np.float32))
+                b.conv(p + ".pwconv2", pc2, hbuf, alt, flags=nat.F_AFFINE | nat.F_RESIDUAL, res=x)
+                x, alt = alt, x
+            feats.append(self._ln(b, f"{e}.norm{i}", f"{e}.norm{i}", x, b.tensor(x.H, x.W, c), 1e-6))
+
+        # ---- decoder: three UnetBlockWide stages (deoldify/unet.py:170-205 family) ----
+        outs, up = [], feats[3]
+        for li in range(3):
+            p, skip = f"decoder.layers.{li}", feats[2 - li]
+
+            def make_shuf(p=p, up=up):
+                s, sh = bn_scale_shift(sd, p + ".shuf.conv.1")
+                return pack_conv(self.pack, conv_weight(sd, p + ".shuf.conv.0") * s[:, None, None, None], up.cmap, up.span, bias=sh, pixshuf=True)
+            pc = self._conv(p + ".shuf", make_shuf)
+            up_c = pc.Cout // 4
+            ps = b.tensor(2 * up.H, 2 * up.W, up_c)
+            b.conv(p + ".shuf", pc, up, ps, flags=nat.F_RELU_PRE | nat.F_OUT_PIXSHUF)
+            ups, sks = pad_to(up_c, 8), pad_to(skip.C, 8)
+            cat_pitch = pitch_for(ups + sks)
+            cat_buf = b.buf(skip.H * skip.W * cat_pitch, 2, zero_init=False)
+            b.blur_resize(p + ".blur", ps, View(cat_buf, 0, cat_pitch, skip.H, skip.W, up_c, ups))
+            so, sho = self._vecs(p + ".bn", lambda p=p: bn_scale_shift(sd, p + ".bn"))
+            b.affine(p + ".bn", skip, View(cat_buf, ups, cat_pitch, skip.H, skip.W, skip.C, sks), so, sho, relu=True)
+            cat = View(cat_buf, 0, cat_pitch, skip.H, skip.W, up_c + skip.C, ups + sks, np.concatenate([np.arange(up_c), ups + np.arange(skip.C)]))
+
+            def make_conv(p=p, cat=cat):
+                s, sh = bn_scale_shift(sd, p + ".conv.2")
+                return pack_conv(self.pack, conv_weight(sd, p + ".conv.0"), cat.cmap, cat.span, scale=s, shift=sh)
+            pcc = self._conv(p + ".conv", make_conv)
+            up = b.tensor(cat.H, cat.W, pcc.Cout)
+            b.conv(p + ".conv", pcc, cat, up, pad=1, flags=nat.F_RELU_PRE | nat.F_AFFINE)
+            outs.append(up)
+        # last_shuf: 1x1 conv (+BN) -> ReLU -> PixelShuffle(4) -> blur; rows re-ordered to (dy*4+dx)*256 + c for the shuffle kernel
+        p = "decoder.last_shuf"
+
+        def make_last(up=up):
+            s, sh = bn_scale_shift(sd, p + ".conv.1")
+            W = conv_weight(sd, p + ".conv.0") * s[:, None, None, None]
+            cps = W.shape[0] // 16
+            perm = (np.arange(cps)[None, :] * 16 + np.arange(16)[:, None]).reshape(-1)
+            return pack_conv(self.pack, W[perm], up.cmap, up.span, bias=sh[perm])
+        pcl = self._conv(p, make_last)
+        t4 = b.tensor(up.H, up.W, pcl.Cout)
+        b.conv(p + ".conv", pcl, up, t4, flags=nat.F_RELU_PRE)
+        img_feat = b.tensor(S, S, pcl.Cout // 16)
+        b.pixshuf4_blur(p + ".shuf+blur", t4, img_feat)
+
+        # ---- colour decoder ----
+        d = "decoder.color_decoder"
+        E = HIDDEN
+        qpos = sd[d + ".query_embed.weight"].astype(np.float32)
+
+        def tok(C):
+            return b.tensor(1, TOK, C)
+
+        def const_tokens(arr):                                     # [<= TOK, C] float32 -> constant token buffer
+            v = tok(arr.shape[1])
+            consts.append((v.buf, arr, v.cpitch, TOK))
+            return v
+        src = []
+        for i, f in enumerate(outs):
+            k = f"{d}.input_proj.{i}"
+            pc = self._lin(k, f, sd[k + ".weight"], bias=sd[k + ".bias"].astype(np.float32) + sd[d + ".level_embed.weight"][i].astype(np.float32))
+            s_i = b.tensor(f.H, f.W, E)
+            b.conv(k, pc, f, s_i)
+            src.append(s_i)
+        tgt = const_tokens(sd[d + ".query_feat.weight"].astype(np.float32))
+        scale = 1.0 / math.sqrt(E // HEADS)
+        for i in range(self.dec_layers):
+            lv = i % 3
+            s_lv = src[lv]
+            # cross attention: Q from the queries, K / V from the feature map (position term folded into a constant map)
+            c = f"{d}.transformer_cross_attention_layers.{i}"
+            Wi, bi = sd[c + ".multihead_attn.in_proj_weight"].astype(np.float32), sd[c + ".multihead_attn.in_proj_bias"].astype(np.float32)
+            cq = const_tokens(qpos @ Wi[:E].T + bi[:E])
+            q = tok(E)
+            b.conv(c + ".q", self._lin(c + ".q", tgt, Wi[:E]), tgt, q, flags=nat.F_RESIDUAL, res=cq)
+            pos = position_sine(s_lv.H, s_lv.W)
+            ckv_arr = np.concatenate([pos @ Wi[E:2 * E].T + bi[E:2 * E], np.broadcast_to(bi[2 * E:], (pos.shape[0], E))], axis=1)
+            ckv = b.tensor(s_lv.H, s_lv.W, 2 * E)
+            consts.append((ckv.buf, ckv_arr, ckv.cpitch, s_lv.H * s_lv.W))
+            kv = b.tensor(s_lv.H, s_lv.W, 2 * E)
+            b.conv(c + ".kv", self._lin(c + ".kv", s_lv, Wi[E:]), s_lv, kv, flags=nat.F_RESIDUAL, res=ckv)
+            a = tok(E)
+            b.mha(c + ".attn", q, kv, 0, E, a, HEADS, QUERIES, s_lv.H * s_lv.W, scale)
+            t1 = tok(E)
+            b.conv(c + ".out", self._lin(c + ".out", a, sd[c + ".multihead_attn.out_proj.weight"], bias=sd[c + ".multihead_attn.out_proj.bias"]),
+                   a, t1, flags=nat.F_RESIDUAL, res=tgt)
+            tgt = self._ln(b, c + ".norm", c + ".norm", t1, tok(E), 1e-5)
+            # self attention among the queries
+            s_ = f"{d}.transformer_self_attention_layers.{i}"
+            Wi, bi = sd[s_ + ".self_attn.in_proj_weight"].astype(np.float32), sd[s_ + ".self_attn.in_proj_bias"].astype(np.float32)
+            cqkv = const_tokens(np.concatenate([qpos @ Wi[:E].T + bi[:E], qpos @ Wi[E:2 * E].T + bi[E:2 * E],
+                                                np.broadcast_to(bi[2 * E:], (QUERIES, E))], axis=1))
+            qkv = tok(3 * E)
+            b.conv(s_ + ".qkv", self._lin(s_ + ".qkv", tgt, Wi), tgt, qkv, flags=nat.F_RESIDUAL, res=cqkv)
+            a = tok(E)
+            b.mha(s_ + ".attn", View(qkv.buf, 0, qkv.cpitch, 1, TOK, E, E), qkv, E, 2 * E, a, HEADS, QUERIES, QUERIES, scale)
+            t1 = tok(E)
+            b.conv(s_ + ".out", self._lin(s_ + ".out", a, sd[s_ + ".self_attn.out_proj.weight"], bias=sd[s_ + ".self_attn.out_proj.bias"]),
+                   a, t1, flags=nat.F_RESIDUAL, res=tgt)
+            tgt = self._ln(b, s_ + ".norm", s_ + ".norm", t1, tok(E), 1e-5)
+            # FFN
+            f_ = f"{d}.transformer_ffn_layers.{i}"
+            h = tok(2048)
+            b.conv(f_ + ".linear1", self._lin(f_ + ".linear1", tgt, sd[f_ + ".linear1.weight"], bias=sd[f_ + ".linear1.bias"]), tgt, h, flags=nat.F_RELU_PRE)
+            t1 = tok(E)
+            b.conv(f_ + ".linear2", self._lin(f_ + ".linear2", h, sd[f_ + ".linear2.weight"], bias=sd[f_ + ".linear2.bias"]), h, t1,
+                   flags=nat.F_RESIDUAL, res=tgt)
+            tgt = self._ln(b, f_ + ".norm", f_ + ".norm", t1, tok(E), 1e-5)
+        emb = self._ln(b, d + ".decoder_norm", d + ".decoder_norm", tgt, tok(E), 1e-5)
+        for k in range(3):
+            key = f"{d}.color_embed.layers.{k}"
+            nxt = tok(E)
+            b.conv(key, self._lin(key, emb, sd[key + ".weight"], bias=sd[key + ".bias"]), emb, nxt, flags=nat.F_RELU_PRE if k < 2 else 0)
+            emb = nxt
+        logits = View(coarse_buf, 8, coarse_pitch, S, S, QUERIES, 104)
+        b.conv_dyn(d + ".einsum", img_feat, emb, logits, QUERIES)
+
+        # ---- refine: spectral 1x1 conv on cat[logits, normalised image] ----
+        coarse = View(coarse_buf, 0, coarse_pitch, S, S, QUERIES + 3, 112, np.concatenate([8 + np.arange(QUERIES), np.arange(3)]))
+        pcr = self._conv("refine_net.0.0", lambda: pack_conv(self.pack, conv_weight(sd, "refine_net.0.0"), coarse.cmap, coarse.span,
+                                                             bias=sd["refine_net.0.0.bias"]))
+        ab = b.tensor(S, S, 2)
+        b.conv("refine_net.0.0", pcr, coarse, ab)
+        ops, bufs = b.finish()
+        return ops, bufs, in_buf, ab.buf, b.names, consts
+
+    @staticmethod
+    def _dw_pack(W, pitch):
+        """[C, 1, 7, 7] -> fp16 [49][pitch] (tap-major, channels contiguous)."""
+        C = W.shape[0]
+        out = np.zeros((49, pitch), np.float16)
+        out[:, :C] = W.reshape(C, 49).T.astype(np.float16)
+        return out

@@ -287,6 +287,47 @@ class PlanBuilder:
             kw.update(src2=y1.buf, res_coff=y1.coff, res_cpitch=y1.cpitch)
         return self._op(name, **kw)
 
+    # ---- DDColor ops (csrc/ddcolor.hip) ----
+    def dwconv7(self, name, x, y, w_off, bias_off, w_pitch):
+        assert x.span == y.span and x.H == y.H and x.W == y.W
+        return self._op(name, type=nat.OP_DWCONV7, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf, dst_coff=y.coff,
+                        dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.span, Ho=y.H, Wo=y.W, Co=y.span, w_off=w_off, bias_off=bias_off,
+                        Kc=w_pitch, kh=7, kw=7, flops=2 * x.H * x.W * x.C * 49)
+
+    def layernorm(self, name, x, y, gamma_off, beta_off, eps):
+        assert x.C == y.C and x.H * x.W == y.H * y.W
+        return self._op(name, type=nat.OP_LAYERNORM, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf, dst_coff=y.coff,
+                        dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.C, Ho=y.H, Wo=y.W, Co=y.C, scale_off=gamma_off, shift_off=beta_off, f0=eps)
+
+    def mha(self, name, q, kv, k_coff, v_coff, y, heads, n_q, n_k, scale):
+        """q / y: token views [1, tokens_per_frame, E] of which the first n_q rows are queries; kv: view over the K/V buffer
+        [*, tokens, >= E] with K at channel k_coff and V at v_coff, n_k keys."""
+        assert q.H == 1 and y.H == 1 and q.W == y.W and q.C == heads * 32
+        return self._op(name, type=nat.OP_MHA, src=q.buf, src_coff=q.coff, src_cpitch=q.cpitch, src2=kv.buf, res_cpitch=kv.cpitch,
+                        res_coff=kv.coff + k_coff, aux0=kv.coff + v_coff, dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=n_q, Wi=q.W,
+                        Ci=q.C, Ho=n_k, Wo=kv.H * kv.W, Co=q.C, kh=heads, f0=scale, flops=4 * n_q * n_k * q.C)
+
+    def pixshuf4_blur(self, name, x, y):
+        assert y.H == 4 * x.H and y.W == 4 * x.W and x.C == 16 * y.C and y.C % 8 == 0
+        return self._op(name, type=nat.OP_PIXSHUF4_BLUR, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf, dst_coff=y.coff,
+                        dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.span, Ho=y.H, Wo=y.W, Co=y.C)
+
+    def prep_ddcolor(self, name, in_buf, S, y0, y1=None):
+        kw = dict(type=nat.OP_PREP_DDCOLOR, src=in_buf, dst=y0.buf, dst_coff=y0.coff, dst_cpitch=y0.cpitch, Hi=S, Wi=S, Ci=8, Ho=S, Wo=S, Co=8)
+        if y1 is not None:
+            kw.update(src2=y1.buf, res_coff=y1.coff, res_cpitch=y1.cpitch)
+        return self._op(name, **kw)
+
+    def conv_dyn(self, name, x, wview, y, n_rows):
+        """1x1 conv whose weights are activations (HAVC_F_W_FROM_BUF): wview = token view [1, >= Npad rows, Cin] whose row pitch
+        equals x.span (packed fp16 rows), n_rows real output channels."""
+        Npad = pad_to(n_rows, 16)
+        assert wview.cpitch == x.span and wview.coff == 0 and wview.H * wview.W >= Npad and x.span % 64 == 0
+        Kc = x.span // 8
+        return self._op(name, type=nat.OP_CONV, flags=nat.F_W_FROM_BUF, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, src2=wview.buf,
+                        dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.span, Ho=x.H, Wo=x.W, Co=y.span, kh=1, kw=1,
+                        stride=1, pad=0, dil=1, Kc=Kc, Npad=Npad, aux1=Kc, out_step=1, flops=2 * x.H * x.W * n_rows * x.C)
+
     def finish(self):
         ops = np.array(self.ops, dtype=nat.OP_DTYPE)
         bufs = np.array(self.bufs, dtype=nat.BUF_DTYPE)
