@@ -1,8 +1,8 @@
 """vsdeoldify_amd — MI355X-native per-frame colorization inference behind the HAVC (vs-deoldify) API.
 
-Only the hot path lives here: the DeOldify generators and the per-pixel merge filters,
-as hand-written HIP kernels for gfx950 behind a C ABI (include/havc_mi355.h, lib/libhavc_mi355.so), plus
-the thin Python mirror of the reference's adapter classes.  No CPU fallback: see _native.py.
+Only the hot path lives here: the DeOldify generators, the Zhang colorizers, DDColor and the per-pixel
+merge / tweak filters, as hand-written HIP kernels for gfx950 behind a C ABI (include/havc_mi355.h, lib/libhavc_mi355.so),
+plus the thin Python mirror of the reference's adapter classes.  No CPU fallback: see _native.py.
 """
 __version__ = "0.1.0"
 
@@ -16,6 +16,9 @@ def __getattr__(name):
     if name == "ModelColorization":
         from .colorization import ModelColorization
         return ModelColorization
+    if name == "DDColorRender":
+        from .ddcolor import DDColorRender
+        return DDColorRender
     if name in ("image_weighted_merge", "chroma_post_process", "chroma_stabilizer"):
         from . import imfilters
         return getattr(imfilters, name)
