@@ -180,11 +180,12 @@ int havc_deoldify_frames(havc_ctx* ctx, havc_net* video, havc_net* second, float
 int havc_zhang_frames(havc_ctx* ctx, havc_net* net, const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames, int width,
                       int height);
 /* havc_ddcolor_frames stands where vsddcolor.ddcolor(clip, model, input_size, ...) is called (vsslib/vsmodels.py:353-360,
- * model 0 / 1) for frames that are already input_size x input_size (S of `net`; the HAVC configurations with an even
- * render_factor): Lab L of the frame -> RGB of Lab(L, 0, 0) -> DDColor (ConvNeXt-L encoder, pixel-shuffle decoder, colour-query
- * transformer, refine conv; the plan of `net`) -> Lab(L, ab) -> RGB u8.  PARITY UNPINNED: vsddcolor is an external wheel that is
- * not part of the reference tree (oracle/ddcolor.py).  rgb_in / rgb_out: host u8 interleaved RGB, n frames of S*S*3. */
-int havc_ddcolor_frames(havc_ctx* ctx, havc_net* net, const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames);
+ * model 0 / 1): Lab L of the frame; the frame squashed to input_size x input_size (S of `net`; Pillow BILINEAR, skipped when it
+ * already has that size -- the HAVC configurations with equal render factors) -> RGB of Lab(L, 0, 0) -> DDColor (ConvNeXt-L
+ * encoder, pixel-shuffle decoder, colour-query transformer, refine conv; the plan of `net`) -> ab, bilinear (align_corners=False)
+ * back to the frame size -> Lab(L_frame, ab) -> RGB u8.  PARITY UNPINNED: vsddcolor is an external wheel that is not part of the
+ * reference tree (oracle/ddcolor.py).  rgb_in / rgb_out: host u8 interleaved RGB, n frames of width*height*3. */
+int havc_ddcolor_frames(havc_ctx* ctx, havc_net* net, const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames, int width, int height);
 /* Pillow Image.resize (BILINEAR = 2, BICUBIC = 3), 8 bits per channel, bit-exact (libImaging/Resample.c) */
 int havc_pil_resize(havc_ctx* ctx, const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int resample);
 

@@ -177,15 +177,23 @@ def forward(sd, img, depths=DEPTHS, dec_layers=DEC_LAYERS, return_parts=False):
     return ab
 
 
-def colorize_frame(sd, frame_u8, depths=DEPTHS, dec_layers=DEC_LAYERS):
-    """The inference wrapper for a SQUARE frame whose side is the network input size (the HAVC configurations with an even
-    render_factor: frame = rf * 16 = input_size): L of the frame, gray RGB from Lab(L, 0, 0), network, Lab(L, ab) -> RGB u8
-    (truncating cast of clip(x, 0, 1) * 255 as in colorizers/util.py:52-55)."""
-    lab = Z.rgb2lab(frame_u8)
-    L = lab[..., :1]
-    gray = Z.lab2rgb(np.concatenate([L, np.zeros_like(L), np.zeros_like(L)], -1))                  # float64 [H, W, 3] in [0, 1]
+def colorize_frame(sd, frame_u8, depths=DEPTHS, dec_layers=DEC_LAYERS, input_size=None):
+    """The inference wrapper (the BUILD's restatement; the reference pins none of it): L of the frame; the frame squashed to
+    input_size^2 with Pillow BILINEAR when it has another size; gray RGB from Lab(L_small, 0, 0); network; ab stretched back
+    (bilinear, align_corners=False); Lab(L_frame, ab) -> RGB u8, truncating cast of clip(x, 0, 1) * 255 (colorizers/util.py:52-55)."""
+    from PIL import Image
+    frame_u8 = np.asarray(frame_u8)
+    h, w = frame_u8.shape[:2]
+    S = h if input_size is None else input_size
+    small = frame_u8 if (h, w) == (S, S) else np.asarray(Image.fromarray(frame_u8).resize((S, S), resample=2))
+    L = Z.rgb2lab(frame_u8)[..., :1]
+    Ls = Z.rgb2lab(small)[..., :1]
+    gray = Z.lab2rgb(np.concatenate([Ls, np.zeros_like(Ls), np.zeros_like(Ls)], -1))              # float64 [S, S, 3] in [0, 1]
     x = torch.from_numpy(gray.astype(np.float32)).permute(2, 0, 1)[None]
     with torch.no_grad():
-        ab = forward(sd, x, depths, dec_layers)[0].permute(1, 2, 0).numpy().astype(np.float64)
+        ab = forward(sd, x, depths, dec_layers)
+        if (h, w) != (S, S):
+            ab = F.interpolate(ab, size=(h, w), mode="bilinear")
+    ab = ab[0].permute(1, 2, 0).numpy().astype(np.float64)
     rgb = Z.lab2rgb(np.concatenate([L, ab], -1))
     return (np.clip(rgb, 0, 1) * 255).astype(np.uint8)

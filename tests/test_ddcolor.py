@@ -135,8 +135,14 @@ def test_gpu_ddcolor_full_depth_end_to_end(ctx):
         d = np.abs(got.astype(int) - want.astype(int))
         assert (d <= 2).mean() > 0.98 and d.max() <= 16, (float((d <= 2).mean()), int(d.max()))
         assert (got[..., 0] != got[..., 2]).mean() > 0.5                      # a coloured frame, not the gray input
+        # a frame that is not input_size x input_size: squashed in, ab stretched back (odd render factors / 16:9 sources)
+        wide = np.clip(r.normal(120, 60, (80, 144, 1)), 0, 255).astype(np.uint8).repeat(3, -1)
+        got2 = dd.colorize_frame(wide)
+        want2 = D.colorize_frame(sd, wide, input_size=S)
+        d2 = np.abs(got2.astype(int) - want2.astype(int))
+        assert got2.shape == wide.shape and (d2 <= 2).mean() > 0.98 and d2.max() <= 16, (float((d2 <= 2).mean()), int(d2.max()))
         with pytest.raises(ValueError):
-            dd.colorize_frame(frame[:64, :64])
+            dd.colorize_frame(frame[..., 0])
     finally:
         dd.rt.close()
     with pytest.raises(ValueError):

@@ -79,7 +79,7 @@ SYMBOLS = [
     ("havc_net_profile", _I, [_P, _I, _P, _I]),
     ("havc_deoldify_frames", _I, [_P, _P, _P, _F, _I, _P, _P, _I]),
     ("havc_zhang_frames", _I, [_P, _P, _P, _P, _I, _I, _I]),
-    ("havc_ddcolor_frames", _I, [_P, _P, _P, _P, _I]),
+    ("havc_ddcolor_frames", _I, [_P, _P, _P, _P, _I, _I, _I]),
     ("havc_pil_resize", _I, [_P, _P, _I, _I, _P, _I, _I, _I]),
     ("havc_blend", _I, [_P, _P, _P, _F, _P, _I, _I]),
     ("havc_chroma_post_process", _I, [_P, _P, _P, _P, _I, _I]),

@@ -885,27 +885,34 @@ int havc_zhang_frames(havc_ctx* c, havc_net* net, const uint8_t* rgb_in, uint8_t
     return t.finish();
 }
 
-int havc_ddcolor_frames(havc_ctx* c, havc_net* net, const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames) {
-    if (!c || !net || !rgb_in || !rgb_out || n_frames < 0) return fail(c, HAVC_E_INVALID, "ddcolor_frames: bad args");
+int havc_ddcolor_frames(havc_ctx* c, havc_net* net, const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames, int width, int height) {
+    if (!c || !net || !rgb_in || !rgb_out || n_frames < 0 || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "ddcolor_frames: bad args");
     if (net->ctx != c || net->bufdesc[net->out_buf].elem_bytes != 2) return fail(c, HAVC_E_INVALID, "ddcolor_frames: not a DDColor net of this ctx");
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(c, hipSetDevice(c->dev));
     const int S = net->S, maxb = net->max_batch;
-    const size_t fb = (size_t)S * S * 3;
+    const size_t fb = (size_t)width * height * 3, sq = (size_t)S * S * 3;
     const int ab_pitch = (int)(net->bufdesc[net->out_buf].elems_per_frame / ((size_t)S * S));
+    const bool squash = width != S || height != S;
     int rc;
     if ((rc = ensure_scratch(c, 0, fb * maxb)) || (rc = ensure_scratch(c, 3, fb * maxb))) return rc;
+    if (squash && ((rc = ensure_scratch(c, 1, (size_t)height * S * 3 * maxb)) || (rc = ensure_scratch(c, 2, sq * maxb)))) return rc;
     uint8_t *d_in = (uint8_t*)c->scratch[0], *d_out = (uint8_t*)c->scratch[3];
     Timer t(c);
     for (int f0 = 0; f0 < n_frames; f0 += maxb) {
         const int b = std::min(maxb, n_frames - f0);
         HIP_TRY(c, hipMemcpyAsync(d_in, rgb_in + (size_t)f0 * fb, fb * b, hipMemcpyHostToDevice, c->stream));
-        net->in_override = d_in;
+        uint8_t* d_net_in = d_in;
+        if (squash) {                                       // frame != input_size: Pillow BILINEAR to S x S (build's choice)
+            d_net_in = (uint8_t*)c->scratch[2];
+            if ((rc = pil_resize_dev(c, d_in, width, height, (uint8_t*)c->scratch[1], d_net_in, S, S, b, 2))) return rc;
+        }
+        net->in_override = d_net_in;
         rc = run_ops_locked(net, 0, (int)net->ops.size(), b);
         net->in_override = nullptr;
         if (rc) return rc;
         c->stats.total_flops += net->flops_per_frame * b;
-        int e = launch_ddcolor_post(d_in, (const half_t*)net->bufs[net->out_buf], ab_pitch, 0, d_out, (int64_t)b * S * S, c->stream);
+        int e = launch_ddcolor_post(d_in, (const half_t*)net->bufs[net->out_buf], ab_pitch, 0, S, S, d_out, b, width, height, c->stream);
         c->stats.launches++;
         if (e) return hip_fail(c, (hipError_t)e, "ddcolor post");
         HIP_TRY(c, hipMemcpyAsync(rgb_out + (size_t)f0 * fb, d_out, fb * b, hipMemcpyDeviceToHost, c->stream));

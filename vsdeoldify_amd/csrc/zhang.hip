@@ -141,18 +141,39 @@ int launch_prep_ddcolor(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff,
     hipLaunchKernelGGL(prep_ddcolor_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, y, y_cpitch, y_coff, y2, y2_cpitch, y2_coff, npix);
     return (int)hipGetLastError();
 }
-// Lab(L of the original frame, ab from the network: fp16 NHWC channels 0, 1) -> RGB u8, truncating cast of clip(x, 0, 1) * 255
-__global__ void ddcolor_post_kernel(const uint8_t* __restrict__ orig, const half_t* __restrict__ ab, int ab_cpitch, int ab_coff,
-                                    uint8_t* __restrict__ out, int64_t npix) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+// Lab(L of the original frame, ab from the network: fp16 NHWC channels 0, 1 at abH x abW, bilinear align_corners=False to the
+// frame size when that differs) -> RGB u8, truncating cast of clip(x, 0, 1) * 255
+__global__ void ddcolor_post_kernel(const uint8_t* __restrict__ orig, const half_t* __restrict__ ab, int ab_cpitch, int ab_coff, int abH,
+                                    int abW, uint8_t* __restrict__ out, int n_frames, int w, int h, float sh, float sw) {
+    const int64_t total = (int64_t)n_frames * w * h;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % w), y = (int)((i / w) % h), f = (int)(i / ((int64_t)w * h));
         const double L = rgb_to_L(orig[i * 3], orig[i * 3 + 1], orig[i * 3 + 2]);
+        const half_t* base = ab + (int64_t)f * abH * abW * ab_cpitch + ab_coff;
+        float a, bb;
+        if (abH == h && abW == w) {
+            a = (float)base[((int64_t)y * abW + x) * ab_cpitch];
+            bb = (float)base[((int64_t)y * abW + x) * ab_cpitch + 1];
+        } else {
+            int y0, y1, x0, x1;
+            float ly, lx;
+            bilin_src_f(y, sh, abH, y0, y1, ly);
+            bilin_src_f(x, sw, abW, x0, x1, lx);
+            const half_t *p00 = base + ((int64_t)y0 * abW + x0) * ab_cpitch, *p01 = base + ((int64_t)y0 * abW + x1) * ab_cpitch,
+                         *p10 = base + ((int64_t)y1 * abW + x0) * ab_cpitch, *p11 = base + ((int64_t)y1 * abW + x1) * ab_cpitch;
+            const float hy = 1.f - ly, hx = 1.f - lx;
+            a = hy * (hx * (float)p00[0] + lx * (float)p01[0]) + ly * (hx * (float)p10[0] + lx * (float)p11[0]);
+            bb = hy * (hx * (float)p00[1] + lx * (float)p01[1]) + ly * (hx * (float)p10[1] + lx * (float)p11[1]);
+        }
         double r, g, b;
-        lab_to_rgb01(L, (double)(float)ab[i * ab_cpitch + ab_coff], (double)(float)ab[i * ab_cpitch + ab_coff + 1], r, g, b);
+        lab_to_rgb01(L, (double)a, (double)bb, r, g, b);
         out[i * 3] = (uint8_t)(int)(r * 255.0); out[i * 3 + 1] = (uint8_t)(int)(g * 255.0); out[i * 3 + 2] = (uint8_t)(int)(b * 255.0);
     }
 }
-int launch_ddcolor_post(const uint8_t* orig, const half_t* ab, int ab_cpitch, int ab_coff, uint8_t* out, int64_t npix, hipStream_t s) {
-    hipLaunchKernelGGL(ddcolor_post_kernel, dim3(grid_for(npix)), dim3(256), 0, s, orig, ab, ab_cpitch, ab_coff, out, npix);
+int launch_ddcolor_post(const uint8_t* orig, const half_t* ab, int ab_cpitch, int ab_coff, int abH, int abW, uint8_t* out, int n_frames, int w,
+                        int h, hipStream_t s) {
+    hipLaunchKernelGGL(ddcolor_post_kernel, dim3(grid_for((int64_t)n_frames * w * h)), dim3(256), 0, s, orig, ab, ab_cpitch, ab_coff, abH, abW, out,
+                       n_frames, w, h, (float)abH / (float)h, (float)abW / (float)w);
     return (int)hipGetLastError();
 }
 

@@ -1,8 +1,8 @@
 """DDColor on the MI355X behind the call shape of `vsddcolor.ddcolor` as vs-deoldify uses it (vsslib/vsmodels.py:298-363).
 
 PARITY UNPINNED (external wheel, not in the reference tree; oracle/ddcolor.py).  `DDColorRender.colorize_frame` takes / returns
-u8 HWC frames that are already input_size x input_size (input_size = trunc(render_factor / 2) * 32, vsmodels.py:302); the RGBH /
-RGBS <-> RGB24 casts around the call stay in VapourSynth.  No CPU fallback: everything runs through libhavc_mi355.
+u8 HWC frames; the network runs at input_size = trunc(render_factor / 2) * 32 (vsmodels.py:302) and frames of another size are
+squashed / the ab map stretched back inside the library.  The RGBH / RGBS <-> RGB24 casts around the call stay in VapourSynth.  No CPU fallback: everything runs through libhavc_mi355.
 """
 import numpy as np
 
@@ -33,13 +33,17 @@ class DDColorRuntime:
             self.nets[key] = n
         return self.nets[key]
 
-    def colorize(self, frames):
-        """frames: uint8 [N, S, S, 3] -> uint8 [N, S, S, 3]."""
+    def colorize(self, frames, input_size=None):
+        """frames: uint8 [N, H, W, 3] -> uint8 [N, H, W, 3]; the network runs at input_size (default: the frame size, which
+        must then be square and a multiple of 32)."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)
-        assert frames.ndim == 4 and frames.shape[1] == frames.shape[2] and frames.shape[3] == 3 and frames.shape[1] % 32 == 0
-        net = self.net(frames.shape[1], min(len(frames), 8))
+        assert frames.ndim == 4 and frames.shape[3] == 3
+        S = frames.shape[1] if input_size is None else input_size
+        assert S % 32 == 0 and (input_size is not None or frames.shape[1] == frames.shape[2])
+        net = self.net(S, min(len(frames), 8))
         out = np.empty_like(frames)
-        nat.check(self.ctx.lib.havc_ddcolor_frames(self.ctx.h, net.h, nat.as_ptr(frames), nat.as_ptr(out), len(frames)), self.ctx.h)
+        nat.check(self.ctx.lib.havc_ddcolor_frames(self.ctx.h, net.h, nat.as_ptr(frames), nat.as_ptr(out), len(frames), frames.shape[2],
+                                                   frames.shape[1]), self.ctx.h)
         return out
 
     def close(self):
@@ -78,7 +82,8 @@ class DDColorRender:
         self.rt = DDColorRuntime(get_context(device_index), state_dict, depths, dec_layers)
 
     def colorize_frame(self, frame):
+        """u8 HWC in -> u8 HWC out, any frame size (the network runs at input_size)."""
         f = np.asarray(frame)
-        if f.shape[:2] != (self.input_size, self.input_size):
-            raise ValueError(f"ddcolor: frame {f.shape[:2]} is not input_size x input_size ({self.input_size})")
-        return self.rt.colorize(f[None])[0]
+        if f.ndim != 3 or f.shape[2] != 3:
+            raise ValueError("ddcolor: frame must be HWC RGB")
+        return self.rt.colorize(f[None], self.input_size)[0]
