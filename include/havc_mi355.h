@@ -222,6 +222,14 @@ int havc_image_luma(havc_ctx* ctx, const uint8_t* img, int width, int height, do
  * the n_ranges [lo, hi] degree ranges keep the tweaked value.  n_ranges <= 8. */
 int havc_image_tweak(havc_ctx* ctx, const uint8_t* img, uint8_t* out, int width, int height, int hue_offset, float brightness,
                      float contrast, float color, const double* hue_ranges /* lo0, hi0, lo1, hi1, ... */, int n_ranges);
+/* image_chroma_tweak (vsslib/imfilters.py:540-548 -> np_image_chroma_tweak, vsslib/restcolor.py:288-350), the body of the
+ * HAVC_stabilizer filters vs_chroma_bright_tweak / vs_colormap (vsslib/vsfilters.py:525-590): cv2 HSV, H += hue/2 (wrapped to
+ * [0,180]), S *= clamp(sat,0,10), V *= clamp(1+bright,0,10), back to RGB.  With has_adjust != 0 the parsed "hue_adjust" stage
+ * follows: pixels whose tweaked hue lies strictly inside one of the n_ranges degree ranges take the colour re-tweaked by
+ * (adj_sat, adj_hue), all others the ORIGINAL pixel; adj_weight > 0 merges towards the re-tweaked colour (adj_hue == 0) or the
+ * original (adj_hue != 0), < 0 towards the original. */
+int havc_image_chroma_tweak(havc_ctx* ctx, const uint8_t* img, uint8_t* out, int width, int height, double sat, double bright, int hue,
+                            int has_adjust, const double* hue_ranges, int n_ranges, double adj_sat, int adj_hue, double adj_weight);
 /* the per-pixel half of luma_adjusted_levels (vsslib/imfilters.py:335-372): cv2 RGB->YUV, Y' = lut[Y], YUV->RGB.  The caller
  * derives the 256-entry table from havc_image_luma exactly like the reference (vsdeoldify_amd/imfilters.py). */
 int havc_luma_lut(havc_ctx* ctx, const uint8_t* img, const uint8_t* lut256, uint8_t* out, int width, int height);

@@ -212,3 +212,100 @@ def restore_color_gradient(img_color, img_gray, sat=1.0, tht=50, weight=0.0, alp
     if weight < 0:
         res = (np.multiply(res, 1 + weight) + np.multiply(np_gray, -weight)).clip(0, 255).astype(np.uint8)
     return res
+
+
+# ---- image_chroma_tweak (vsslib/imfilters.py:540-548 -> restcolor.py:288-350) and the HAVC_stabilizer frame bodies ------
+def np_hue_add(h, hue):
+    """nputils.py:330-340 (the float result is cast back to uint8 by the caller's slice assignment)."""
+    if hue == 0:
+        return h
+    hue_half = 0.5 * min(max(int(hue), -360), 360)
+    h = h + hue_half
+    h = np.where(h > 180, h - 180, h)
+    return np.where(h < 0, h + 180, h)
+
+
+def parse_hue_adjust(hue_adjust):
+    """restcolor.py:379-414 -> (hue_range, sat, hue, weight) or None."""
+    p = hue_adjust.split("|")
+    sat, hue, weight = 1.0, 0, 0
+    if len(p) < 1 or len(p) > 2:
+        return None
+    if len(p) == 1:
+        return p[0], sat, hue, weight
+    sw = p[1].split(",")
+
+    def isfloat(t):
+        try:
+            float(t)
+            return True
+        except ValueError:
+            return False
+    if len(sw) != 2 or not isfloat(sw[0]) or not isfloat(sw[1]):
+        return None
+    if sw[0][0] in ("-", "+"):
+        hue = int(sw[0])
+    else:
+        sat = float(sw[0])
+    if sat > 10:
+        hue, sat = int(sat), 1.0
+    return p[0], sat, hue, float(sw[1])
+
+
+def _wmerge(a, b, w):
+    return (np.multiply(a, 1 - w) + np.multiply(b, w)).clip(0, 255).astype(np.uint8)
+
+
+def np_image_chroma_tweak(img, sat=1, bright=0, hue=0, hue_adjust="none"):
+    """restcolor.py:288-350."""
+    img = np.asarray(img)
+    if sat == 1 and bright == 0 and hue == 0 and hue_adjust == "none":
+        return img
+    hsv = cvcolor.rgb2hsv_u8(img)
+    hsv[:, :, 0] = np_hue_add(hsv[:, :, 0], hue)
+    hsv[:, :, 1] = hsv[:, :, 1] * min(max(sat, 0), 10)
+    hsv[:, :, 2] = hsv[:, :, 2] * min(max(1 + bright, 0), 10)
+    color = cvcolor.hsv2rgb_u8(hsv)
+    if hue_adjust in ("none", ""):
+        return color
+    param = parse_hue_adjust(hue_adjust)
+    if param is None:
+        return color
+    hue_range, sat2, hue2, weight = param
+    g = cvcolor.rgb2hsv_u8(color)
+    if hue2 != 0:
+        g[:, :, 0] = np_hue_add(g[:, :, 0], hue2)
+    if sat2 != 1:
+        g[:, :, 1] = g[:, :, 1] * min(max(sat2, 0), 10)
+    gray_rgb = cvcolor.hsv2rgb_u8(g)
+    cond = hue_conditions(hsv[:, :, 0], hue_range)
+    restored = np.where(cond[..., None], gray_rgb, img).astype(np.uint8)
+    if weight > 0:
+        restored = _wmerge(restored, gray_rgb if hue2 == 0 else img, weight)
+    if weight < 0:
+        restored = _wmerge(restored, img, -weight)
+    return restored
+
+
+def _luma_merge(img2, img1, lo, hi):
+    from .pipeline import image_luma_merge
+    return image_luma_merge(img2, img1, lo) if lo == hi else w_image_luma_merge(img2, img1, lo, hi)
+
+
+def dark_tweak_frame(img, dark_threshold=0.3, dark_amount=0.8, dark_hue_adjust="none"):
+    """vs_sc_dark_tweak's merge_frame (vsfilters.py:600-632)."""
+    white = min(max(dark_threshold, 0.1), 0.50)
+    d_sat = min(max(1.1 - dark_amount, 0.10), 0.80)
+    d_bright = -min(max(dark_amount, 0.20), 0.90)
+    return _luma_merge(image_tweak(img, bright=d_bright, sat=d_sat, hue_range=dark_hue_adjust), np.asarray(img), 0.1, white)
+
+
+def chroma_bright_tweak_frame(img, black_threshold=0.3, white_threshold=0.6, dark_sat=0.8, dark_bright=-0.10, chroma_adjust="none"):
+    """vs_sc_chroma_bright_tweak's merge_frame (vsfilters.py:525-547)."""
+    return _luma_merge(np_image_chroma_tweak(img, bright=dark_bright, sat=dark_sat, hue_adjust=chroma_adjust), np.asarray(img),
+                       black_threshold, white_threshold)
+
+
+def colormap_frame(img, colormap="none"):
+    """_vs_sc_colormap's merge_frame (vsfilters.py:575-590)."""
+    return np_image_chroma_tweak(img, hue_adjust=colormap)

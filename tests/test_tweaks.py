@@ -125,3 +125,30 @@ def test_gpu_red_fix_and_chroma_retention(ctx):
         w, al = (0.0, 2.0) if 0.22 <= luma <= 0.78 else (-0.5, 4.0)
         ref = tweaks.restore_color_gradient(col, a, 0.8, 30, w, al)
         assert np.array_equal(mcomb.chroma_retention_frame(a, col, 0.8, 30, 0.0, 2.0), ref), (scale, luma)
+
+
+def test_oracle_chroma_tweak_and_stabilizer_bodies_match_reference_vectors():
+    base = G["base"]
+    for i, c in _cases("ctweak_cases"):
+        assert np.array_equal(tweaks.np_image_chroma_tweak(base, **c), G[f"ctweak_{i}"]), c
+    assert np.array_equal(tweaks.chroma_bright_tweak_frame(base, 0.3, 0.6, 0.8, -0.10, "none"), G["bright_tweak_0"])
+    assert np.array_equal(tweaks.chroma_bright_tweak_frame(base, 0.4, 0.4, 0.6, -0.25, "red|0.5,0.0"), G["bright_tweak_1"])
+    assert np.array_equal(tweaks.dark_tweak_frame(base, 0.3, 0.8, "none"), G["dark_tweak_0"])
+    assert np.array_equal(tweaks.dark_tweak_frame(base, 0.45, 0.5, "280:360,0:30"), G["dark_tweak_1"])
+
+
+@pytest.mark.gpu
+def test_gpu_chroma_tweak_and_stabilizer_frames(ctx):
+    from vsdeoldify_amd import imfilters as F, stabilizer
+    base, _, _ = _imgs(11)
+    for i, c in _cases("ctweak_cases"):
+        assert np.array_equal(F.image_chroma_tweak_np(ctx, G["base"], **c), G[f"ctweak_{i}"]), c
+        assert np.array_equal(F.image_chroma_tweak_np(ctx, base, **c), tweaks.np_image_chroma_tweak(base, **c)), c
+    for c in (dict(sat=3.0, bright=0.8), dict(hue=360), dict(hue=-360, sat=0.0), dict(bright=-1.5), dict(hue_adjust="rose,red|-90,0.5"),
+              dict(hue_adjust="bogus|x,y")):
+        assert np.array_equal(F.image_chroma_tweak_np(ctx, base, **c), tweaks.np_image_chroma_tweak(base, **c)), c
+    assert np.array_equal(stabilizer.chroma_bright_tweak_frame(G["base"], 0.3, 0.6, 0.8, -0.10, "none"), G["bright_tweak_0"])
+    assert np.array_equal(stabilizer.chroma_bright_tweak_frame(G["base"], 0.4, 0.4, 0.6, -0.25, "red|0.5,0.0"), G["bright_tweak_1"])
+    assert np.array_equal(stabilizer.dark_tweak_frame(G["base"], 0.3, 0.8, "none"), G["dark_tweak_0"])
+    assert np.array_equal(stabilizer.dark_tweak_frame(G["base"], 0.45, 0.5, "280:360,0:30"), G["dark_tweak_1"])
+    assert np.array_equal(stabilizer.colormap_frame(base, "blue|+40,0.2"), tweaks.colormap_frame(base, "blue|+40,0.2"))

@@ -90,6 +90,7 @@ SYMBOLS = [
     ("havc_image_luma_merge", _I, [_P, _P, _P, _I, _D, _D, _P, _I, _I]),
     ("havc_image_luma", _I, [_P, _P, _I, _I, C.POINTER(C.c_double)]),
     ("havc_image_tweak", _I, [_P, _P, _P, _I, _I, _I, _F, _F, _F, C.POINTER(C.c_double), _I]),
+    ("havc_image_chroma_tweak", _I, [_P, _P, _P, _I, _I, _D, _D, _I, _I, C.POINTER(C.c_double), _I, _D, _I, _D]),
     ("havc_luma_lut", _I, [_P, _P, _P, _P, _I, _I]),
     ("havc_restore_color_gradient", _I, [_P, _P, _P, _P, _I, _I, _D, _I, _D, _D, _I, _I]),
     ("havc_colorize_clip", _I, [_P, _P, _P, _F, _P, _P, _I, _I, _I]),

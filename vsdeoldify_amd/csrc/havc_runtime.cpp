@@ -1040,6 +1040,29 @@ int havc_image_tweak(havc_ctx* c, const uint8_t* img, uint8_t* out, int width, i
     return host_filter_epilogue(c, out, dout, nb, launch_image_tweak(din, dout, npix, a, (unsigned long long*)c->scratch[6], false, c->stream));
 }
 
+int havc_image_chroma_tweak(havc_ctx* c, const uint8_t* img, uint8_t* out, int width, int height, double sat, double bright, int hue,
+                            int has_adjust, const double* hue_ranges, int n_ranges, double adj_sat, int adj_hue, double adj_weight) {
+    if (!c || !img || !out || width <= 0 || height <= 0 || n_ranges < 0 || n_ranges > HAVC_MAX_HUE_RANGES || (has_adjust && (!hue_ranges || n_ranges < 1)))
+        return fail(c, HAVC_E_INVALID, "image_chroma_tweak: bad args (1..8 hue ranges with an adjust stage)");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t nb = (size_t)width * height * 3;
+    int rc;
+    if ((rc = ensure_scratch(c, 0, nb)) || (rc = ensure_scratch(c, 2, nb))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->scratch[0], img, nb, hipMemcpyHostToDevice, c->stream));
+    auto clampd = [](double v, double lo, double hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    ChromaTweakArgs a{};
+    a.has_hue = hue != 0; a.hue_half = 0.5 * (double)std::min(std::max(hue, -360), 360);
+    a.satc = clampd(sat, 0.0, 10.0); a.brightc = clampd(1.0 + bright, 0.0, 10.0);
+    a.has_adjust = has_adjust != 0; a.n_ranges = has_adjust ? n_ranges : 0;
+    for (int k = 0; k < a.n_ranges; ++k) { a.range_lo[k] = hue_ranges[2 * k]; a.range_hi[k] = hue_ranges[2 * k + 1]; }
+    a.has_hue2 = adj_hue != 0; a.hue_half2 = 0.5 * (double)std::min(std::max(adj_hue, -360), 360);
+    a.has_sat2 = adj_sat != 1.0; a.sat2c = clampd(adj_sat, 0.0, 10.0);
+    a.weight = adj_weight;
+    return host_filter_epilogue(c, out, (uint8_t*)c->scratch[2], nb,
+                                launch_chroma_tweak((const uint8_t*)c->scratch[0], (uint8_t*)c->scratch[2], (int64_t)width * height, a, c->stream));
+}
+
 int havc_luma_lut(havc_ctx* c, const uint8_t* img, const uint8_t* lut256, uint8_t* out, int width, int height) {
     if (!c || !img || !lut256 || !out || width <= 0 || height <= 0) return fail(c, HAVC_E_INVALID, "luma_lut: bad args");
     std::lock_guard<std::mutex> lk(c->mu);

@@ -109,6 +109,12 @@ struct TweakArgs {
 };
 int launch_image_tweak(const uint8_t* img, uint8_t* out, int64_t npix, const TweakArgs& a, unsigned long long* d_sum, bool sum_only,
                        hipStream_t s);
+struct ChromaTweakArgs {
+    int has_hue, has_adjust, has_hue2, has_sat2, n_ranges;
+    double hue_half, satc, brightc, hue_half2, sat2c, weight;
+    double range_lo[HAVC_MAX_HUE_RANGES], range_hi[HAVC_MAX_HUE_RANGES];
+};
+int launch_chroma_tweak(const uint8_t* img, uint8_t* out, int64_t npix, const ChromaTweakArgs& a, hipStream_t s);
 int launch_luma_lut(const uint8_t* img, const uint8_t* d_lut, uint8_t* out, int64_t npix, hipStream_t s);
 int launch_restore_color_gradient(const uint8_t* color, const uint8_t* gray, uint8_t* out, int64_t npix, double sat, int tht, double alpha,
                                   double weight, int algo, int return_mask, hipStream_t s);

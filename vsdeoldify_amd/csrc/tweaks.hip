@@ -233,3 +233,49 @@ int launch_restore_color_gradient(const uint8_t* color, const uint8_t* gray, uin
                        algo, return_mask);
     return (int)hipGetLastError();
 }
+
+// ---- image_chroma_tweak (imfilters.py:540-548 -> restcolor.py:288-350): cv2 HSV hue / saturation / value tweak, then the optional
+// "hue_adjust" stage (hue range on the TWEAKED hue -> re-tweaked colour, everything else the ORIGINAL pixel, weighted merges) ----
+__device__ __forceinline__ int cv_hue_add(int h, double hue_half) {          // nputils.py:330-340 + the uint8 slice assignment
+    double t = (double)h + hue_half;
+    t = t > 180.0 ? t - 180.0 : t;
+    t = t < 0.0 ? t + 180.0 : t;
+    return (int)(uint8_t)(long long)t;
+}
+__device__ __forceinline__ int wmerge1(int a, int b, double w) {
+    const double m = (double)a * (1.0 - w) + (double)b * w;
+    return (int)(m < 0.0 ? 0.0 : (m > 255.0 ? 255.0 : m));
+}
+__global__ void chroma_tweak_kernel(const uint8_t* __restrict__ img, uint8_t* __restrict__ out, int64_t npix, ChromaTweakArgs a) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int r0 = img[i * 3], g0 = img[i * 3 + 1], b0 = img[i * 3 + 2];
+        int h, s, v;
+        cv_rgb2hsv(r0, g0, b0, h, s, v);
+        if (a.has_hue) h = cv_hue_add(h, a.hue_half);
+        s = (int)(uint8_t)(long long)((double)s * a.satc);
+        v = (int)(uint8_t)(long long)((double)v * a.brightc);
+        int r, g, b;
+        cv_hsv2rgb(h, s, v, r, g, b);
+        if (a.has_adjust) {
+            int hg, sg, vg;
+            cv_rgb2hsv(r, g, b, hg, sg, vg);
+            if (a.has_hue2) hg = cv_hue_add(hg, a.hue_half2);
+            if (a.has_sat2) sg = (int)(uint8_t)(long long)((double)sg * a.sat2c);
+            int gr, gg, gb;
+            cv_hsv2rgb(hg, sg, vg, gr, gg, gb);
+            bool cond = false;
+            for (int k = 0; k < a.n_ranges; ++k) cond |= ((double)h > a.range_lo[k] * 0.5) && ((double)h < a.range_hi[k] * 0.5);
+            r = cond ? gr : r0; g = cond ? gg : g0; b = cond ? gb : b0;
+            if (a.weight > 0.0) {
+                const bool to_gray = !a.has_hue2;
+                r = wmerge1(r, to_gray ? gr : r0, a.weight); g = wmerge1(g, to_gray ? gg : g0, a.weight); b = wmerge1(b, to_gray ? gb : b0, a.weight);
+            }
+            if (a.weight < 0.0) { r = wmerge1(r, r0, -a.weight); g = wmerge1(g, g0, -a.weight); b = wmerge1(b, b0, -a.weight); }
+        }
+        out[i * 3] = (uint8_t)r; out[i * 3 + 1] = (uint8_t)g; out[i * 3 + 2] = (uint8_t)b;
+    }
+}
+int launch_chroma_tweak(const uint8_t* img, uint8_t* out, int64_t npix, const ChromaTweakArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(chroma_tweak_kernel, dim3(grid_for_px(npix)), dim3(256), 0, s, img, out, npix, a);
+    return (int)hipGetLastError();
+}

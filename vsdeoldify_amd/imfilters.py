@@ -239,3 +239,53 @@ def restore_color_gradient(img_color, img_gray, sat=1.0, tht=50, weight=0, alpha
     from PIL import Image
     return Image.fromarray(restore_color_gradient_np(get_context(device_index), np.asarray(img_color), np.asarray(img_gray), sat, tht,
                                                      weight, alpha, return_mask, algo))
+
+
+def parse_hue_adjust(hue_adjust):
+    """restcolor.py:379-414: 'ranges|adjust,weight' -> (hue_range, sat, hue, weight) or None."""
+    p = hue_adjust.split("|")
+    sat, hue, weight = 1.0, 0, 0
+    if len(p) < 1 or len(p) > 2:
+        return None
+    if len(p) == 1:
+        return p[0], sat, hue, weight
+    sw = p[1].split(",")
+
+    def isfloat(t):
+        try:
+            float(t)
+            return True
+        except ValueError:
+            return False
+    if len(sw) != 2 or not isfloat(sw[0]) or not isfloat(sw[1]):
+        return None
+    if sw[0][0] in ("-", "+"):
+        hue = int(sw[0])
+    else:
+        sat = float(sw[0])
+    if sat > 10:
+        hue, sat = int(sat), 1.0
+    return p[0], sat, hue, float(sw[1])
+
+
+def image_chroma_tweak_np(ctx, img, sat=1, bright=0, hue=0, hue_adjust="none"):
+    import ctypes as C
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    if sat == 1 and bright == 0 and hue == 0 and hue_adjust == "none":
+        return a                                                          # restcolor.py:290-291
+    param = None if hue_adjust in ("none", "") else parse_hue_adjust(hue_adjust)
+    rng = parse_hue_ranges(param[0]) if param else []
+    arr = (C.c_double * max(len(rng), 1))(*rng)
+    out = np.empty_like(a)
+    nat.check(ctx.lib.havc_image_chroma_tweak(ctx.h, nat.as_ptr(a), nat.as_ptr(out), a.shape[1], a.shape[0], float(sat), float(bright), int(hue),
+                                              1 if param else 0, arr, len(rng) // 2, float(param[1]) if param else 1.0,
+                                              int(param[2]) if param else 0, float(param[3]) if param else 0.0), ctx.h)
+    return out
+
+
+def image_chroma_tweak(img, sat=1, bright=0, hue=0, hue_adjust="none", device_index=0):
+    """imfilters.py:540-548."""
+    from PIL import Image
+    if sat == 1 and bright == 0 and hue == 0 and hue_adjust == "none":
+        return img
+    return Image.fromarray(image_chroma_tweak_np(get_context(device_index), np.asarray(img), sat, bright, hue, hue_adjust))
