@@ -210,3 +210,17 @@ def test_color_filters_bit_exact(ctx):
     g = np.stack(np.meshgrid(np.arange(0, 256, 5), np.arange(0, 256, 5), np.arange(0, 256, 5)), -1).reshape(-1, 1, 3).astype(np.uint8)
     h = g[::-1].copy()
     assert np.array_equal(imfilters.chroma_post_process_np(ctx, g, h), pipeline.chroma_post_process(g, h))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(259, 259, 48, 80, 2, True), (64, 256, 33, 47, 3, False), (768, 512, 32, 32, 1, False)])
+def test_halo_conv_kernel_identical_to_pipe_kernel(ctx, shape):
+    """conv_halo_kernel (cfg 80 / 81: 16x16 tiles, halo staged once per 64-channel group; experimental, not selected by default)
+    runs the same stage order and MFMA sequence as conv_pipe_kernel: outputs must be bit-identical, incl. the 259-channel
+    remainder segment, partial edge tiles and the residual epilogue."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("halo_check", os.path.join(os.path.dirname(__file__), "..", "tools", "halo_check.py"))
+    hc = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(hc)
+    ref, got = hc.check(shape)
+    assert np.isfinite(got).all() and np.array_equal(ref, got)

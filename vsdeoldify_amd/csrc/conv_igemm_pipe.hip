@@ -242,245 +242,253 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
     if (KT >= 2) { stage(kt, std::integral_constant<int, 1>{}); ++kt; }
     stage(kt, std::integral_constant<int, 0>{});
 
-    // ---- epilogue ----
-    if (ABL == 5 || ABL == 9 || ABL == 10) {
-        float t = 0.f;
-#pragma unroll
-        for (int mi = 0; mi < FM; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < FN; ++ni) t += acc[ni][mi][0] + acc[ni][mi][1] + acc[ni][mi][2] + acc[ni][mi][3];
-        if (t == 123.456f) reinterpret_cast<half_t*>(p.y)[0] = (half_t)t;
-        return;
+    auto gm = [&](int local_row) -> int { return m0 + local_row; };
+    const int lp = lr;                                     // MFMA column lr carries pixel lr of its fragment
+#include "conv_pipe_epilogue.inc"
+}
+
+// =====================================================================================================================
+// conv_halo_kernel: 3x3 stride-1 pad-1 convolutions on 16x16-pixel tiles with HALO REUSE.
+// The im2col main loop above fetches every pixel row once per tap: 9 x (256 + 272) rows per 64-channel group, 8.25 LDS-DMA
+// pieces per wave per K-64 stage, and it is the ISSUE cost of those pieces that keeps the MFMA pipe at ~50 %
+// (profiles/r1_conv_ablation.txt).  Here the 18x18 halo of a 16x16 output tile is staged ONCE per 64-channel group
+// (46 pieces) and the nine taps read their pixel fragments from it at shifted row offsets: 4.25 weight pieces + 0.65 halo
+// pieces per wave per stage.  Halo rows have a 144-byte pitch (8 data slots + 1 pad slot): 16 consecutive rows then cover all
+// sixteen 16-byte slots of a 256-byte bank line for ANY starting row, so every tap's ds_read_b128 is conflict-free with plain
+// immediate offsets and no XOR.  LDS: 2 halo buffers (2 x 46 KiB) + 2 weight stages (2 x 34 KiB) = exactly 160 KiB.
+// Weights, stage order (group-major, tap inside), barrier placement, fragment rings and the epilogue are those of
+// conv_pipe_kernel<2,4,8,EXTRA>; the 1-chunk remainder segment (259 = 256 + 3 channels) is served from a halo tile of the
+// remainder channels, each lane group reading the tap its K chunk belongs to.
+template <int EXTRA, int ABL = 0>
+__global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs p) {
+    constexpr int WM = 2, WN = 4, FM = 8, NW = 8, BM = 256, BN = 256, B_IT = BN / 8 / NW, NS = 16;
+    constexpr int HB = 46 * 1024, WB = (BN + 16 * EXTRA) * 128, H_IT = 6, HP = 144;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const Wbase = smem + 2 * HB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 15, lg = lane >> 4;
+
+    const int nwg = gridDim.x;
+    int pid;
+    {
+        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    // Main 256 columns: transpose through LDS so every lane stores 16 B and 8 lanes cover one 128-byte line of a pixel
-    // (the direct fragment layout gives 8-byte stores in 32-byte runs: 0.29 ms of a 1.6 ms launch, fully exposed at one
-    // block per CU).  Phase 1: bias -> ReLU -> affine in registers, fp16, ds_write_b64 into a wave-private
-    // [8 fragments][16 pixels][128 B] image (16-byte slots XOR-swizzled by pixel).  Phase 2: ds_read_b128, residual +
-    // ReLU, global store.  TRANSPOSED / RGB8 / odd pixel-shuffle widths keep the per-fragment path.
-    const bool lds_epi = !(p.flags & (HAVC_F_OUT_TRANSPOSED | HAVC_F_OUT_RGB8)) &&
-                         (!(p.flags & HAVC_F_OUT_PIXSHUF) || (p.Co & 63) == 0);
-    bool fused_done = false;
-    if (!lds_epi) {
+    const int NT = (p.Npad - 16 * EXTRA + BN - 1) / BN;
+    const int tile = pid / NT;
+    const int m0 = tile * BM;
+    const int n0 = (pid % NT) * BN;
+    const bool has_extra = EXTRA && (n0 + BN + 16 == p.Npad);
+    const int HoWo = p.Ho * p.Wo;
+    const int tt = p.tiles_y * p.tiles_x;
+    const int tb = tile / tt, trem = tile - tb * tt, ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.w), 0, p.w_bytes, 0x00020000);
+
+    // ---- weight DMA role (as conv_pipe_kernel): row lane>>3 of an 8-row piece, LDS position lane&7, source chunk c ----
+    const int r8 = lane >> 3;
+    const int c = (lane & 7) ^ ((((wave & 1) << 2) + (r8 >> 1)) & 7);
+    unsigned b_voff[B_IT];
 #pragma unroll
-        for (int mi = 0; mi < FM; ++mi) {
-            const int m = m0 + wm * (FM * 16) + mi * 16 + lr;
+    for (int it = 0; it < B_IT; ++it) {
+        const int n = n0 + (wave + it * NW) * 8 + r8;
+        b_voff[it] = n < p.Npad ? (unsigned)((n * p.Kc + c) * 16) : OOB;
+    }
+    const unsigned x_voff = (unsigned)(((n0 + BN + (wave & 1) * 8 + r8) * p.Kc + c) * 16);
+    const bool extra_wave = has_extra && wave >= 6;
+
+    // ---- halo DMA role: 16-byte slot s = piece * 64 + lane of the halo buffer -> halo row s / 9, slot s % 9 (8 = pad) ----
+    // h_voff: byte offset of (pixel, channel chunk = slot) in the input, OOB outside the image / pad; bit 0 marks slot 0
+    // (the only slot the remainder group fetches).
+    unsigned h_voff[H_IT];
 #pragma unroll
-            for (int ni = 0; ni < FN; ++ni) epilogue_frag(p, acc[ni][mi], m, n0 + wn * 64 + ni * 16 + lg * 4, HoWo);
-        }
-    } else if (EXTRA && has_extra && (p.flags & HAVC_F_FUSE_RGB8)) {
-        // ---- fused layers.11 (1x1 conv -> 3 channels) + SigmoidRange + denormalise + trunc u8 (HAVC_F_FUSE_RGB8) ----
-        // r2 = fp16(ReLU(acc + bias) + residual) never leaves the registers: an accumulator fragment (lane = pixel lr,
-        // channels lg*4..+3) IS the B operand of v_mfma_f32_16x16x16_f16, so the 1x1 conv is FN MFMAs per pixel
-        // fragment with the (3 real of 16) output rows as A.  The 259-channel row of a pixel is spread over the four
-        // N-waves and the extra-column fragments; the five partial sums go through LDS and are added in a FIXED
-        // order, so a frame colours identically in any batch.
-        fused_done = true;
-        const bool leaky = p.flags & HAVC_F_LEAKY;
-        const int nw0 = n0 + wn * 64;
-        half4 wa[FN];
-        float4 bvs[FN];
+    for (int it = 0; it < H_IT; ++it) {
+        const int piece = wave + it * NW;
+        const int sl = piece * 64 + lane;
+        const int row = sl / 9, col = sl - row * 9;
+        const int hy = row / 18, hx = row - hy * 18;
+        const int iy = ty * 16 - 1 + hy, ix = tx * 16 - 1 + hx;
+        const bool ok = piece < 46 && row < 324 && col < 8 && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+        const int chunk = (col & 4) | ((col & 1) << 1) | ((col >> 1) & 1);               // LDS position col holds source chunk pi(col)
+        const unsigned off = (unsigned)((((int64_t)(tb * p.Hi + iy) * p.Wi + ix) * p.x_cpitch + p.x_coff) * 2) + (unsigned)chunk * 16u;
+        h_voff[it] = ok ? (off | (col == 0 ? 1u : 0u)) : OOB;
+    }
+    const int G = p.C8a >> 3;                                                        // full 64-channel groups of the main K segment
+    const int KT = p.Kc >> 3;
+    const bool has_rem = KT > 9 * G;                                                 // the 1-chunk remainder segment: 2 stages
+
+    // ---- fragment read addresses ----
+    const int fsw = (lr >> 1) & 7;
+    const int b_l0 = (wn * 64 + lr) * 128 + ((lg ^ fsw) << 4), b_l1 = b_l0 ^ 64;
+    const int x_l0 = (BN + lr) * 128 + ((lg ^ fsw) << 4), x_l1 = x_l0 ^ 64;
+    // Bank conflicts: a ds_read_b128 is served in lane groups {lr 0-3, 12-15 of lg} + {lr 4-11 of lg+1}.  With a 9-slot row pitch
+    // the slot of (row, chunk position) is 9 row + pos (mod 16); MFMA column lr therefore carries pixel lp = sigma(lr) -- even
+    // pixels for lr in {0-3, 12-15}, odd ones for lr in {4-11} -- and chunk c sits at position pi(c) = {0,2,1,3,4,6,5,7}[c], so
+    // that the two halves of a lane group land on slots of different parity for ANY starting row: conflict-free at every tap.
+    const int lp = lr < 4 ? 2 * lr : (lr < 12 ? 2 * (lr - 4) + 1 : 2 * (lr - 8));
+    const int a_row = (wm * 8 * 18 + lp) * HP;                                       // tile row wm*8, pixel lp (tap / mi via immediates)
+    int a_cur = a_row + (((lg & 1) << 1) | (lg >> 1)) * 16, a_nxt = a_cur + HB;      // halo buffers 0 / 1; position pi(lg)
+    auto tap_off = [](int t) { return ((t / 3) * 18 + (t % 3)) * HP; };            // (1 + dh) * 18 + (1 + dw), in bytes
+    // remainder stages: K chunk j of the segment is tap j (chunk 8 = tap 8, chunks 9..15 zero weights): per-lane tap
+    const int rem_buf = (G & 1) * HB;
+    const int a_rem0 = rem_buf + a_row + tap_off(lg), a_rem1 = rem_buf + a_row + tap_off(4 + lg), a_rem8 = rem_buf + a_row + tap_off(8);
+
+    float4v acc[FN][FM];
+    float4v accx[2];
 #pragma unroll
-        for (int ni = 0; ni < FN; ++ni) {
-            const int n = nw0 + ni * 16 + lg * 4;
-            wa[ni] = half4{0, 0, 0, 0};
-            if (lr < 3) {
-                const float4 w4 = *reinterpret_cast<const float4*>(p.fuse_w + lr * p.Npad + n);
-                wa[ni] = half4{(half_t)w4.x, (half_t)w4.y, (half_t)w4.z, (half_t)w4.w};
+    for (int ni = 0; ni < FN; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) acc[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
+    accx[0] = accx[1] = float4v{0.f, 0.f, 0.f, 0.f};
+
+    auto w_piece = [&](int q, char* wbuf, int kstage) {
+        dma16(rw, wbuf + (wave + q * NW) * 1024, ABL == 6 ? OOB : b_voff[q], (unsigned)kstage * 128u);     // ABL 6: DMA issued, nothing fetched
+    };
+    auto h_piece = [&](int it, int hoff, int group, bool rem) {
+        const unsigned v = h_voff[it];
+        const unsigned vo = ABL == 6 ? OOB : rem ? ((v & 1u) ? (v & ~1u) : OOB) : (v & ~1u);          // (OOB has bit 0 clear)
+        dma16(rx, smem + hoff + (wave + it * NW) * 1024, vo, (unsigned)group * 128u);
+    };
+
+    // ---- prologue: halo of group 0, weight stage 0, two early pieces of stage 1 ----
+#pragma unroll
+    for (int it = 0; it < H_IT; ++it) if (wave + it * NW < 46) h_piece(it, 0, 0, G == 0);
+#pragma unroll
+    for (int q = 0; q < B_IT; ++q) w_piece(q, Wbase, 0);
+    if (EXTRA && extra_wave) dma16(rw, Wbase + BN * 128 + (wave & 1) * 1024, x_voff, 0);
+    if (KT > 1) {
+#pragma unroll
+        for (int q = 0; q < B_IT; ++q) w_piece(q, Wbase + WB, 1);
+        if (EXTRA && extra_wave) dma16(rw, Wbase + WB + BN * 128 + (wave & 1) * 1024, x_voff, 128u);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    half8 bf[2][FN];
+    half8 xb[2];
+    half8 af[4];
+#pragma unroll
+    for (int ni = 0; ni < FN; ++ni) bf[0][ni] = *reinterpret_cast<const half8*>(Wbase + b_l0 + ni * 2048);
+    if (EXTRA) xb[0] = *reinterpret_cast<const half8*>(Wbase + x_l0);
+    {
+        const int a0 = G > 0 ? a_cur : a_rem0;                                       // stage 0 is tap 0 (same immediates either way)
+        af[0] = *reinterpret_cast<const half8*>(smem + a0);
+        af[1] = *reinterpret_cast<const half8*>(smem + a0 + 18 * HP);
+    }
+    int h_cur_off = 0;                                                               // byte offset of the halo buffer being read
+
+    // One K-64 stage.  T: tap (0..8) of a main group, 9 / 10: the two remainder stages.  a_next: per-lane base of the NEXT
+    // stage's first two pixel fragments (its tile rows 0, 1 are at +0 and +18 rows).
+    auto stage = [&](int kt, int group, auto t_tag, int a_next) {
+        constexpr int T = decltype(t_tag)::value;
+        constexpr bool DMA_ON = ABL != 1;
+        const char* wcur = Wbase + (kt & 1) * WB;
+        char* wnxt = Wbase + ((kt & 1) ^ 1) * WB;
+        const bool more2 = kt + 2 < KT;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int ks = s / FM, mi = s % FM;
+            if (s + 2 < NS) {                              // (1) pixel fragment two steps ahead
+                const int s2 = s + 2, k2 = s2 / FM, m2 = s2 % FM;
+                int addr;
+                if (T < 9) addr = a_cur + tap_off(T) + m2 * 18 * HP + k2 * 64;
+                else if (T == 9) addr = (k2 ? a_rem1 : a_rem0) + m2 * 18 * HP;
+                else addr = a_rem8 + m2 * 18 * HP;
+                af[s2 % 4] = *reinterpret_cast<const half8*>(smem + addr);
             }
-            bvs[ni] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        float4v facc[FM];
-#pragma unroll
-        for (int mh = 0; mh < FM; mh += 4) {               // four pixel fragments at a time: 16 residual loads in flight
-            half4 rr[4][FN];
-#pragma unroll
-            for (int mj = 0; mj < 4; ++mj) {
-                const int m = m0 + wm * (FM * 16) + (mh + mj) * 16 + lr;
-#pragma unroll
-                for (int ni = 0; ni < FN; ++ni) {
-                    rr[mj][ni] = half4{0, 0, 0, 0};
-                    if ((p.flags & HAVC_F_RESIDUAL) && m < p.M)
-                        rr[mj][ni] = *reinterpret_cast<const half4*>(p.res + out_pixel(p, m, HoWo) * p.res_cpitch + p.res_coff + nw0 + ni * 16 + lg * 4);
-                }
+            if (s == NS - 3) {                             // (B) the barrier of this stage
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
             }
+            if (s >= NS - 2) {                             // first fragments of the next stage
+                const int j = s - (NS - 2);
+                af[(s + 2) % 4] = *reinterpret_cast<const half8*>(smem + a_next + j * 18 * HP);
 #pragma unroll
-            for (int mj = 0; mj < 4; ++mj) {
-                const int mi = mh + mj;
-                facc[mi] = float4v{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int ni = 0; ni < FN; ++ni) {
-                    const float bb[4] = {bvs[ni].x, bvs[ni].y, bvs[ni].z, bvs[ni].w};
-                    half4 o;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float v = acc[ni][mi][r] + bb[r];
-                        if (p.flags & HAVC_F_RELU_PRE) v = v > 0.f ? v : (leaky ? v * p.f2 : 0.f);
-                        o[r] = (half_t)(v + (float)rr[mj][ni][r]);    // one rounding, as epilogue_frag
-                    }
-                    facc[mi] = __builtin_amdgcn_mfma_f32_16x16x16f16(wa[ni], o, facc[mi], 0, 0, 0);
-                }
+                for (int ni = 2 * j; ni < 2 * j + 2; ++ni) bf[0][ni] = *reinterpret_cast<const half8*>(wnxt + b_l0 + ni * 2048);
+                if (EXTRA && j == 1) xb[0] = *reinterpret_cast<const half8*>(wnxt + x_l0);
             }
-        }
-        __syncthreads();                                   // every wave is done reading the last stage
-        float* part = reinterpret_cast<float*>(smem);      // [5][BM][3]
-        if (lg == 0) {
-#pragma unroll
-            for (int mi = 0; mi < FM; ++mi) {
-                float* q = part + (wn * BM + wm * (FM * 16) + mi * 16 + lr) * 3;
-                q[0] = facc[mi][0]; q[1] = facc[mi][1]; q[2] = facc[mi][2];
-            }
-            const int nx = n0 + BN;                        // extra columns: channels nx .. nx+2 are real (x0's RGB)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int pl = wm * (FM * 16) + (wn * 2 + i) * 16 + lr;
-                const int m = m0 + pl;
-                float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = accx[i][r] + (p.bias ? p.bias[nx + r] : 0.f);
-                    if (p.flags & HAVC_F_RELU_PRE) v = v > 0.f ? v : (leaky ? v * p.f2 : 0.f);
-                    if ((p.flags & HAVC_F_RESIDUAL) && m < p.M && nx + r < p.Co)      // as epilogue_frag: one rounding
-                        v += (float)p.res[out_pixel(p, m, HoWo) * p.res_cpitch + p.res_coff + nx + r];
-                    const float f = (float)(half_t)v;
-                    d0 += f * (float)(half_t)p.fuse_w[nx + r];
-                    d1 += f * (float)(half_t)p.fuse_w[p.Npad + nx + r];
-                    d2 += f * (float)(half_t)p.fuse_w[2 * p.Npad + nx + r];
-                }
-                float* q = part + (4 * BM + pl) * 3;
-                q[0] = d0; q[1] = d1; q[2] = d2;
-            }
-        }
-        __syncthreads();
-        for (int pl = threadIdx.x; pl < BM; pl += NW * 64) {
-            const int m = m0 + pl;
-            if (m >= p.M) continue;
-            uint8_t* y = p.fuse_rgb + out_pixel(p, m, HoWo) * 3;
-#pragma unroll
-            for (int jo = 0; jo < 3; ++jo) {
-                float t = p.fuse_b[jo];
-#pragma unroll
-                for (int w = 0; w < 5; ++w) t += part[(w * BM + pl) * 3 + jo];
-                float sg = 1.f / (1.f + __expf(-t));
-                sg = sg * (p.f1 - p.f0) + p.f0;
-                sg = sg * p.istd[jo] + p.mean[jo];
-                sg = fminf(fmaxf(sg, 0.f), 1.f);
-                y[jo] = (uint8_t)(int)(sg * 255.f);
-            }
-        }
-    } else {
-        __syncthreads();                                   // every wave is done reading the last stage
-        char* img = smem + wave * (FM * 2048);
-        const bool leaky = p.flags & HAVC_F_LEAKY;
-        const int nw0 = n0 + wn * 64;                      // first channel of this wave's 64-channel slice
-#pragma unroll
-        for (int ni = 0; ni < FN; ++ni) {
-            const int n = nw0 + ni * 16 + lg * 4;
-            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = bv;
-            const bool n_ok = n < p.Npad;
-            if (p.bias && n_ok) bv = *reinterpret_cast<const float4*>(p.bias + n);
-            if ((p.flags & HAVC_F_AFFINE) && n_ok) {
-                sc = *reinterpret_cast<const float4*>(p.scale + n);
-                sh = *reinterpret_cast<const float4*>(p.shift + n);
-            }
-            const float bb[4] = {bv.x, bv.y, bv.z, bv.w}, ss[4] = {sc.x, sc.y, sc.z, sc.w}, hh[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-            for (int mi = 0; mi < FM; ++mi) {
-                half4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float v = acc[ni][mi][r] + bb[r];
-                    if (p.flags & HAVC_F_RELU_PRE) v = v > 0.f ? v : (leaky ? v * p.f2 : 0.f);
-                    if (p.flags & HAVC_F_GELU) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
-                    if (p.flags & HAVC_F_AFFINE) v = v * ss[r] + hh[r];
-                    o[r] = (half_t)v;
-                }
-                const int slot = (ni * 2 + (lg >> 1)) ^ (lr & 7);
-                *reinterpret_cast<half4*>(img + mi * 2048 + lr * 128 + slot * 16 + (lg & 1) * 8) = o;
-            }
-        }
-        if ((p.flags & HAVC_F_PS_BLUR) && WM == 2 && WN == 4 && FM == 8) {
-            // ---- HAVC_F_PS_BLUR: PixelShuffle(2) + ReplicationPad(1,0,1,0) + AvgPool2d(2,1) straight out of the LDS images ----
-            // The block holds the 16x16 low-res tile x (4 sub-pixels x 64 channels); wave (wm, q) owns rows wm*8..+7 of
-            // sub-pixel q.  Output = the 30x30 hi-res pixels whose 2x2 source window lies inside the tile.  Same fp16
-            // rounding of the shuffled values and the same summation order as elementwise.hip blur_resize_kernel.
-            __syncthreads();
-            const int tile = m0 / BM, tt = p.tiles_y * p.tiles_x;
-            const int b = tile / tt, t = tile - b * tt, ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-            const int h0 = ty * 15 - 1, w0 = tx * 15 - 1, H2 = 2 * p.Ho, W2 = 2 * p.Wo;
-            half_t* y = reinterpret_cast<half_t*>(p.y) + p.y_coff + (n0 >> 2);          // 64 output channels per 256-column tile
-            for (int it = tid; it < 30 * 30 * 8; it += NW * 64) {
-                const int ch = it & 7, pxl = it >> 3, Yl = pxl / 30, Xl = pxl - Yl * 30;
-                const int Y = 2 * (h0 + 1) + Yl, X = 2 * (w0 + 1) + Xl;
-                if (Y >= H2 || X >= W2) continue;
-                const int ay0 = max(Y - 1, 0), ax0 = max(X - 1, 0);
-                auto ld = [&](int ay, int ax) -> half8 {
-                    const int dy = (ay >> 1) - h0, dx = (ax >> 1) - w0, q = (ay & 1) * 2 + (ax & 1);
-                    return *reinterpret_cast<const half8*>(smem + ((dy >> 3) * WN + q) * (FM * 2048) + (dy & 7) * 2048 + dx * 128 + ((ch ^ (dx & 7)) << 4));
-                };
-                const half8 v00 = ld(ay0, ax0), v01 = ld(ay0, X), v10 = ld(Y, ax0), v11 = ld(Y, X);
-                half8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)v00[e] + (float)v01[e] + (float)v10[e] + (float)v11[e]) * 0.25f);
-                *reinterpret_cast<half8*>(y + ((int64_t)(b * H2 + Y) * W2 + X) * p.y_cpitch + ch * 8) = o;
-            }
-            return;
-        }
-        // phase 2: lane -> (pixel row lane>>3 (+8), 16-byte channel slot lane&7).  All residual vectors are requested
-        // up front (the accumulators are dead by now) so their latency overlaps instead of serialising 16 load->store pairs.
-        const int ch = lane & 7;
-        const int n = nw0 + ch * 8;
-        const bool do_res = (p.flags & HAVC_F_RESIDUAL) && !(p.flags & HAVC_F_OUT_PIXSHUF) && n < p.Co;
-        half8 rres[FM][2];
-        if (p.flags & HAVC_F_RESIDUAL) {
-#pragma unroll
-            for (int mi = 0; mi < FM; ++mi)
-#pragma unroll
-                for (int hp = 0; hp < 2; ++hp) {
-                    const int m = m0 + wm * (FM * 16) + mi * 16 + (lane >> 3) + hp * 8;
-                    rres[mi][hp] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-                    if (do_res && m < p.M) rres[mi][hp] = *reinterpret_cast<const half8*>(p.res + out_pixel(p, m, HoWo) * p.res_cpitch + p.res_coff + n);
-                }
-        }
-#pragma unroll
-        for (int mi = 0; mi < FM; ++mi) {
-#pragma unroll
-            for (int hp = 0; hp < 2; ++hp) {
-                const int px = (lane >> 3) + hp * 8;
-                const int m = m0 + wm * (FM * 16) + mi * 16 + px;
-                const half8 v = *reinterpret_cast<const half8*>(img + mi * 2048 + px * 128 + ((ch ^ (px & 7)) << 4));
-                if (m >= p.M) continue;
-                half_t* y = reinterpret_cast<half_t*>(p.y);
-                int64_t off;
-                if (p.flags & HAVC_F_OUT_PIXSHUF) {
-                    const int q = n / p.Co, cc = n - q * p.Co;
-                    if (q >= 4) continue;
-                    const int b = m / HoWo, rem = m - b * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                    off = ((int64_t)(b * 2 * p.Ho + 2 * ho + (q >> 1)) * (2 * p.Wo) + 2 * wo + (q & 1)) * p.y_cpitch + p.y_coff + cc;
-                } else {
-                    if (n >= p.Co) continue;
-                    off = out_pixel(p, m, HoWo) * p.y_cpitch + p.y_coff + n;
-                }
-                half8 o = v;
-                if (p.flags & (HAVC_F_RESIDUAL | HAVC_F_RELU_POST)) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float f = (float)v[e];
-                        if (p.flags & HAVC_F_RESIDUAL) f += (float)rres[mi][hp][e];
-                        if (p.flags & HAVC_F_RELU_POST) f = f > 0.f ? f : (leaky ? f * p.f2 : 0.f);
-                        o[e] = (half_t)f;
+            if (ks == 0 && mi >= FM - FN)                  // (2) weight fragments of the second K half
+                bf[1][mi - (FM - FN)] = *reinterpret_cast<const half8*>(wcur + b_l1 + (mi - (FM - FN)) * 2048);
+            if (EXTRA && s == 3) xb[1] = *reinterpret_cast<const half8*>(wcur + x_l1);
+            if (DMA_ON) {                                  // (3) DMA.  Behind the barrier (steps 13..15) the buffer just drained takes
+                //     ALL weight pieces of stage kt+2: they have a whole stage to land.  One halo piece of the next group per tap.
+                if (s >= NS - 3 && more2) {
+                    char* wc = const_cast<char*>(wcur);
+                    if (s == NS - 3) w_piece(0, wc, kt + 2);
+                    if (s == NS - 2) { w_piece(1, wc, kt + 2); w_piece(2, wc, kt + 2); }
+                    if (s == NS - 1) {
+                        w_piece(3, wc, kt + 2);
+                        if (EXTRA && extra_wave) dma16(rw, wc + BN * 128 + (wave & 1) * 1024, x_voff, (unsigned)(kt + 2) * 128u);
                     }
                 }
-                *reinterpret_cast<half8*>(y + off) = o;
+                if (T < H_IT && s == 6 && wave + T * NW < 46) {
+                    if (group + 1 < G) h_piece(T, h_cur_off ^ HB, group + 1, false);
+                    else if (has_rem) h_piece(T, h_cur_off ^ HB, G, true);
+                }
             }
-        }
-    }
-    if (EXTRA && has_extra && !(fused_done)) {
+            const half8 a = af[s % 4];                     // (4) the MFMAs of this step
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = m0 + wm * (FM * 16) + (wn * 2 + i) * 16 + lr;
-            epilogue_frag(p, accx[i], m, n0 + BN + lg * 4, HoWo);
+            for (int ni = 0; ni < FN; ++ni) {
+                if (ABL == 4) asm volatile("" ::"v"(bf[ks][ni]), "v"(a));
+                else acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][ni], a, acc[ni][mi], 0, 0, 0);
+            }
+            if (EXTRA && has_extra) {
+                if (wn == (mi >> 1)) accx[mi & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], a, accx[mi & 1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
+    };
+    int kt = 0;
+    for (int g = 0; g < G; ++g) {
+        stage(kt++, g, std::integral_constant<int, 0>{}, a_cur + tap_off(1));
+        stage(kt++, g, std::integral_constant<int, 1>{}, a_cur + tap_off(2));
+        stage(kt++, g, std::integral_constant<int, 2>{}, a_cur + tap_off(3));
+        stage(kt++, g, std::integral_constant<int, 3>{}, a_cur + tap_off(4));
+        stage(kt++, g, std::integral_constant<int, 4>{}, a_cur + tap_off(5));
+        stage(kt++, g, std::integral_constant<int, 5>{}, a_cur + tap_off(6));
+        stage(kt++, g, std::integral_constant<int, 6>{}, a_cur + tap_off(7));
+        stage(kt++, g, std::integral_constant<int, 7>{}, a_cur + tap_off(8));
+        stage(kt++, g, std::integral_constant<int, 8>{}, g + 1 < G ? a_nxt : a_rem0);       // next: tap 0 of the next group / remainder
+        const int t = a_cur; a_cur = a_nxt; a_nxt = t;
+        h_cur_off ^= HB;
     }
+    if (has_rem) {
+        stage(kt++, G, std::integral_constant<int, 9>{}, a_rem8);
+        stage(kt++, G, std::integral_constant<int, 10>{}, a_rem8);
+    }
+
+    auto gm = [&](int local_row) -> int {                  // tile row -> linear output pixel (out_pixel is the identity here)
+        const int y = ty * 16 + (local_row >> 4), x = tx * 16 + (local_row & 15);
+        return (y < p.Ho && x < p.Wo) ? (tb * p.Ho + y) * p.Wo + x : 0x7fffffff;
+    };
+#include "conv_pipe_epilogue.inc"
+}
+
+template <int EXTRA, int ABL = 0>
+static int launch_halo(const ConvArgs& a0, hipStream_t s) {
+    ConvArgs a = a0;
+    if ((a.Kc & 7) || a.x_bytes == 0 || a.x_bytes >= OOB || a.w_bytes >= OOB || a.kh != 3 || a.kw != 3 || a.stride != 1 || a.pad != 1 ||
+        a.pad_w != 1 || a.dil != 1 || a.oss != 1 || a.Hi != a.Ho || a.Wi != a.Wo)
+        return (int)hipErrorInvalidValue;
+    const int frames = a.M / (a.Ho * a.Wo);
+    a.tiles_y = (a.Ho + 15) / 16;
+    a.tiles_x = (a.Wo + 15) / 16;
+    const int MT = frames * a.tiles_y * a.tiles_x, NT = (a.Npad - 16 * EXTRA + 255) / 256;
+    a.M = MT * 256;
+    constexpr int LDS = 2 * 46 * 1024 + 2 * (256 + 16 * EXTRA) * 128;
+    static_assert(LDS <= 160 * 1024, "LDS budget");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<EXTRA, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_halo_kernel<EXTRA, ABL>), dim3(MT * NT), dim3(512), LDS, s, a);
+    return (int)hipGetLastError();
 }
 
 template <int WM, int WN, int FM, int EXTRA, int ABL = 0>
@@ -512,6 +520,12 @@ int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
         case 69: return launch_pipe<2, 4, 8, 0, 9>(a, s);
         case 73: return launch_pipe<2, 4, 8, 0, 10>(a, s);
         case 65: return launch_pipe<2, 4, 8, 0, 5>(a, s);
+        case 80: return launch_halo<0>(a, s);                 // 3x3 s1 p1, 16x16-pixel tiles with halo reuse
+        case 81: return launch_halo<1>(a, s);
+        case 82: return launch_halo<0, 1>(a, s);              // ablations (profiling only)
+        case 84: return launch_halo<0, 4>(a, s);
+        case 85: return launch_halo<0, 5>(a, s);
+        case 86: return launch_halo<0, 6>(a, s);
         case 70: return launch_pipe<2, 2, 4, 0>(a, s);        // 128 x 128, 4 waves
         case 71: return launch_pipe<1, 4, 8, 0>(a, s);        // 128 x 256, 4 waves
         case 72: return launch_pipe<1, 2, 4, 0>(a, s);        // 64 x 128, 2 waves

@@ -292,6 +292,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             a.M = batch * op.Ho * op.Wo;   // (PS_BLUR: set below)
             a.flags = op.flags;
             a.pix_pitch = op.aux0;
+            a.C8a = (op.aux1 > 0 && op.aux1 < op.Ci / 8) ? op.aux1 : op.Ci / 8;
             a.f0 = op.f0; a.f1 = op.f1; a.f2 = op.f2;
             a.cfg = op.reserved;
             {

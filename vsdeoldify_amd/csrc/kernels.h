@@ -30,7 +30,8 @@ struct ConvArgs {
     int cfg;               // 0 = heuristic; otherwise forced tile configuration (tools/conv_bench.py A/B runs)
     const int2* ktab;      // [Kc] per 16-byte K chunk: .x = byte offset of (tap, cin chunk) from the tap-0 pixel,
                            //      .y = dh | dw << 16 (input-pixel displacement of the tap; pad entries: dh = 0x7fff)
-    int tiles_y, tiles_x;  // PS_BLUR: 16x16-pixel GEMM-row tiles per frame (stride 15: one row / column of halo)
+    int C8a;               // chunks of the main K segment (plan.py pack_conv); == C8 when there is no remainder segment
+    int tiles_y, tiles_x;  // PS_BLUR / halo conv: 16x16-pixel GEMM-row tiles per frame (stride 15: one row / column of halo)
     const float* fuse_w;   // FUSE_RGB8: fp32 [3][Npad] weights of the fused 1x1 conv, fuse_b: its 3 biases
     const float* fuse_b;
     uint8_t* fuse_rgb;     // FUSE_RGB8: u8 RGB output [M][3]
