@@ -346,12 +346,13 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs p) {
         for (int mi = 0; mi < FM; ++mi) acc[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
     accx[0] = accx[1] = float4v{0.f, 0.f, 0.f, 0.f};
 
-    auto w_piece = [&](int q, char* wbuf, int kstage) {
-        dma16(rw, wbuf + (wave + q * NW) * 1024, ABL == 6 ? OOB : b_voff[q], (unsigned)kstage * 128u);     // ABL 6: DMA issued, nothing fetched
+    auto w_piece = [&](int q, char* wbuf, int kstage, bool live = true) {
+        dma16(rw, wbuf + (wave + q * NW) * 1024, (ABL == 6 || !live) ? OOB : b_voff[q], (unsigned)kstage * 128u);     // ABL 6: DMA issued, nothing fetched
     };
-    auto h_piece = [&](int it, int hoff, int group, bool rem) {
+    auto h_piece = [&](int it, int hoff, int group, bool rem, bool live = true) {
         const unsigned v = h_voff[it];
-        const unsigned vo = ABL == 6 ? OOB : rem ? ((v & 1u) ? (v & ~1u) : OOB) : (v & ~1u);          // (OOB has bit 0 clear)
+        const unsigned vr = (v & 1u) ? (v & ~1u) : OOB;                              // remainder group: slot 0 only (OOB has bit 0 clear)
+        const unsigned vo = (ABL == 6 || !live) ? OOB : (rem ? vr : (v & ~1u));
         dma16(rx, smem + hoff + (wave + it * NW) * 1024, vo, (unsigned)group * 128u);
     };
 
@@ -417,18 +418,18 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs p) {
             if (EXTRA && s == 3) xb[1] = *reinterpret_cast<const half8*>(wcur + x_l1);
             if (DMA_ON) {                                  // (3) DMA.  Behind the barrier (steps 13..15) the buffer just drained takes
                 //     ALL weight pieces of stage kt+2: they have a whole stage to land.  One halo piece of the next group per tap.
-                if (s >= NS - 3 && more2) {
+                //     No branches: past the last stage / group the pieces are issued with out-of-range offsets (zero fill, no fetch).
+                if (s >= NS - 3) {
                     char* wc = const_cast<char*>(wcur);
-                    if (s == NS - 3) w_piece(0, wc, kt + 2);
-                    if (s == NS - 2) { w_piece(1, wc, kt + 2); w_piece(2, wc, kt + 2); }
+                    if (s == NS - 3) w_piece(0, wc, kt + 2, more2);
+                    if (s == NS - 2) { w_piece(1, wc, kt + 2, more2); w_piece(2, wc, kt + 2, more2); }
                     if (s == NS - 1) {
-                        w_piece(3, wc, kt + 2);
-                        if (EXTRA && extra_wave) dma16(rw, wc + BN * 128 + (wave & 1) * 1024, x_voff, (unsigned)(kt + 2) * 128u);
+                        w_piece(3, wc, kt + 2, more2);
+                        if (EXTRA) { if (extra_wave) dma16(rw, wc + BN * 128 + (wave & 1) * 1024, more2 ? x_voff : OOB, (unsigned)(kt + 2) * 128u); }
                     }
                 }
-                if (T < H_IT && s == 6 && wave + T * NW < 46) {
-                    if (group + 1 < G) h_piece(T, h_cur_off ^ HB, group + 1, false);
-                    else if (has_rem) h_piece(T, h_cur_off ^ HB, G, true);
+                if (T < H_IT && s == 6) {
+                    if (T < H_IT - 1 || wave + T * NW < 46) h_piece(T, h_cur_off ^ HB, group + 1, group + 1 >= G, group + 1 < G || has_rem);
                 }
             }
             const half8 a = af[s % 4];                     // (4) the MFMAs of this step
