@@ -267,8 +267,8 @@ int launch_chroma_temporal_limiter(const uint8_t* cur, const uint8_t* prv, doubl
 // texture = clip(|Laplacian(Y_stable)| / 255, 0, 1) (cv2.Laplacian CV_32F, aperture 1: [[0,1,0],[1,-4,1],[0,1,0]],
 // BORDER_REFLECT_101), on signed chroma (U-128, V-128); float32 like the numpy code ----
 __device__ __forceinline__ float y_at(const uint8_t* __restrict__ img, int x, int y, int w, int h) {
-    x = x < 0 ? -x : (x >= w ? 2 * w - 2 - x : x);
-    y = y < 0 ? -y : (y >= h ? 2 * h - 2 - y : y);
+    x = w == 1 ? 0 : (x < 0 ? -x : (x >= w ? 2 * w - 2 - x : x));          // BORDER_REFLECT_101; a 1-pixel axis reflects onto itself
+    y = h == 1 ? 0 : (y < 0 ? -y : (y >= h ? 2 * h - 2 - y : y));          // (cv::borderInterpolate returns 0 when len == 1)
     const uint8_t* p = img + ((int64_t)y * w + x) * 3;
     int yy, u, v;
     rgb2yuv(p[0], p[1], p[2], yy, u, v);
