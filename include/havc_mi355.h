@@ -60,7 +60,9 @@ enum havc_op_type {
     HAVC_OP_LAYERNORM = 13,  /* LayerNorm over the Ci channels of every pixel / token: scale_off gamma, shift_off beta, f0 eps */
     HAVC_OP_MHA = 14,        /* multi-head attention, head dim 32: Q = src view (Hi = queries, Wi = tokens per frame), K / V =
                                 buffer src2 (pitch res_cpitch, K at res_coff, V at aux0; Ho = keys, Wo = tokens per frame),
-                                kh = heads, f0 = softmax scale; dst view has the Q token stride                      */
+                                kh = heads, f0 = softmax scale; dst view has the Q token stride; aux1 = fp32 buffer of
+                                heads * ceil(keys / 256) * queries * 34 floats per frame for the key-split form (-1: one wave
+                                per query)                                                                          */
     HAVC_OP_PIXSHUF4_BLUR = 15, /* PixelShuffle(4) of a [Hi][Wi][16 Co] tensor whose channels are ordered (dy*4+dx)*Co + c,
                                 then the ICNR blur -> dst [4Hi][4Wi][Co]                                              */
     HAVC_OP_PREP_DDCOLOR = 16,  /* u8 RGB -> Lab L -> RGB of Lab(L,0,0) -> imagenet normalise -> fp16 C8 (dst) and a 3-channel

@@ -184,6 +184,118 @@ int launch_mha32(const half_t* q, int q_cpitch, int q_coff, int q_tok, const hal
     return (int)hipGetLastError();
 }
 
+// ---- the same attention, split over the keys (flash-decoding form): what DDColor's cross-attention needs (100 queries against up
+// to 16 384 keys: one wave per query re-reads every K / V row 100 times).  Block (split c, head h, frame b), one thread per query:
+// the block stages KC keys of K and V in LDS once (every thread then reads the SAME row: LDS broadcast), each thread runs its
+// query over them with an online softmax (rescaled once per 8 keys) and writes {m, l, acc[32]}; mha32_merge_kernel folds the splits.
+constexpr int MHA_KC = 256;
+__global__ void __launch_bounds__(128) mha32_split_kernel(const half_t* __restrict__ q, int q_cpitch, int q_coff, int q_tok,
+                                                          const half_t* __restrict__ kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,
+                                                          float* __restrict__ part, int heads, int Lq, int Lk, float scale) {
+    __shared__ __attribute__((aligned(16))) half_t Ks[MHA_KC][32];
+    __shared__ __attribute__((aligned(16))) half_t Vs[MHA_KC][32];
+    const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z, nsplit = gridDim.x;
+    const int k0 = c * MHA_KC, nk = min(MHA_KC, Lk - k0);
+    const half_t* kb = kv + ((int64_t)b * kv_tok + k0) * kv_cpitch + h * 32;
+    for (int i = threadIdx.x; i < nk * 8; i += blockDim.x) {                // 8 16-byte chunks per key: 4 of K, 4 of V
+        const int key = i >> 3, ch = i & 7;
+        const half8 t = *reinterpret_cast<const half8*>(kb + (int64_t)key * kv_cpitch + (ch < 4 ? k_coff + ch * 8 : v_coff + (ch - 4) * 8));
+        *reinterpret_cast<half8*>(ch < 4 ? &Ks[key][ch * 8] : &Vs[key][(ch - 4) * 8]) = t;
+    }
+    __syncthreads();
+    for (int iq = threadIdx.x; iq < Lq; iq += blockDim.x) {
+        float qv[32], acc[32];
+        const half_t* qp = q + ((int64_t)b * q_tok + iq) * q_cpitch + q_coff + h * 32;
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) {
+            const half8 t = *reinterpret_cast<const half8*>(qp + cc * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { qv[cc * 8 + e] = (float)t[e] * scale; acc[cc * 8 + e] = 0.f; }
+        }
+        float m = -INFINITY, l = 0.f;
+        for (int j0 = 0; j0 < nk; j0 += 8) {
+            float sc[8];
+            float gmax = m;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float d = -INFINITY;
+                if (j0 + j < nk) {
+                    d = 0.f;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const half8 t = *reinterpret_cast<const half8*>(&Ks[j0 + j][cc * 8]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) d += qv[cc * 8 + e] * (float)t[e];
+                    }
+                }
+                sc[j] = d;
+                gmax = fmaxf(gmax, d);
+            }
+            const float corr = __expf(m - gmax);                              // m = -inf on the first group: corr = 0, acc is 0 anyway
+            l *= corr;
+#pragma unroll
+            for (int e = 0; e < 32; ++e) acc[e] *= corr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (j0 + j < nk) {
+                    const float pj = __expf(sc[j] - gmax);
+                    l += pj;
+#pragma unroll
+                    for (int cc = 0; cc < 4; ++cc) {
+                        const half8 t = *reinterpret_cast<const half8*>(&Vs[j0 + j][cc * 8]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[cc * 8 + e] += pj * (float)t[e];
+                    }
+                }
+            }
+            m = gmax;
+        }
+        float* o = part + ((((int64_t)b * heads + h) * nsplit + c) * Lq + iq) * 34;
+        o[0] = m; o[1] = l;
+#pragma unroll
+        for (int e = 0; e < 32; ++e) o[2 + e] = acc[e];
+    }
+}
+__global__ void mha32_merge_kernel(const float* __restrict__ part, half_t* __restrict__ o, int o_cpitch, int o_coff, int o_tok, int B, int heads,
+                                   int Lq, int nsplit) {
+    const int64_t total = (int64_t)B * heads * Lq * 4;                       // 4 threads per (frame, head, query): 8 channels each
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cc = (int)(i & 3);
+        int64_t r = i >> 2;
+        const int iq = (int)(r % Lq);
+        r /= Lq;
+        const int h = (int)(r % heads), b = (int)(r / heads);
+        const float* p0 = part + (((int64_t)b * heads + h) * nsplit * Lq + iq) * 34;
+        float M = -INFINITY;
+        for (int c = 0; c < nsplit; ++c) M = fmaxf(M, p0[(int64_t)c * Lq * 34]);
+        float L = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < nsplit; ++c) {
+            const float* pc = p0 + (int64_t)c * Lq * 34;
+            const float w = __expf(pc[0] - M);
+            L += pc[1] * w;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += pc[2 + cc * 8 + e] * w;
+        }
+        half8 t;
+        const float inv = 1.f / L;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (half_t)(acc[e] * inv);
+        *reinterpret_cast<half8*>(o + ((int64_t)b * o_tok + iq) * o_cpitch + o_coff + h * 32 + cc * 8) = t;
+    }
+}
+int mha32_nsplit(int Lk) { return (Lk + MHA_KC - 1) / MHA_KC; }
+int launch_mha32_split(const half_t* q, int q_cpitch, int q_coff, int q_tok, const half_t* kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,
+                       half_t* o, int o_cpitch, int o_coff, int o_tok, float* part, int B, int heads, int Lq, int Lk, float scale, hipStream_t s) {
+    const int nsplit = mha32_nsplit(Lk);
+    hipLaunchKernelGGL(mha32_split_kernel, dim3(nsplit, heads, B), dim3(128), 0, s, q, q_cpitch, q_coff, q_tok, kv, kv_cpitch, k_coff, v_coff, kv_tok,
+                       part, heads, Lq, Lk, scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(mha32_merge_kernel, dim3(grid_for_dd((int64_t)B * heads * Lq * 4)), dim3(256), 0, s, part, o, o_cpitch, o_coff, o_tok, B, heads,
+                       Lq, nsplit);
+    return (int)hipGetLastError();
+}
+
 // ---- PixelShuffle(4) + ReplicationPad(1,0,1,0) + AvgPool2d(2,1) (decoder.last_shuf).  Input channel order (dy*4+dx)*C + c ----
 __global__ void pixshuf4_blur_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int B, int Hi, int Wi, int C8, int x_cpitch, int x_coff,
                                      int y_cpitch, int y_coff) {

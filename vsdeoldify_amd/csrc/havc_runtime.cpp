@@ -397,6 +397,16 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             break;
         case HAVC_OP_MHA:
             if (op.src2 < 0 || op.Ci != op.kh * 32) return fail(c, HAVC_E_INVALID, "mha op: K/V buffer, head dim 32");
+            if (op.aux1 >= 0 && op.aux1 < (int)n->bufs.size() && n->bufdesc[op.aux1].elem_bytes == 4) {
+                // keys split over blocks (K / V staged in LDS once per block), partial softmax states in the fp32 buffer aux1
+                if ((size_t)n->bufdesc[op.aux1].elems_per_frame < (size_t)op.kh * mha32_nsplit(op.Ho) * op.Hi * 34)
+                    return fail(c, HAVC_E_INVALID, "mha op: partial-state buffer too small");
+                e = launch_mha32_split((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, op.Wi, (const half_t*)bufptr(n, op.src2),
+                                       op.res_cpitch, op.res_coff, op.aux0, op.Wo, (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff, op.Wi,
+                                       (float*)bufptr(n, op.aux1), batch, op.kh, op.Hi, op.Ho, op.f0, s);
+                c->stats.launches += 1;
+                break;
+            }
             e = launch_mha32((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, op.Wi, (const half_t*)bufptr(n, op.src2), op.res_cpitch,
                              op.res_coff, op.aux0, op.Wo, (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff, op.Wi, batch, op.kh, op.Hi,
                              op.Ho, op.f0, s);

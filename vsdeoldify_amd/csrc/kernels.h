@@ -96,6 +96,9 @@ int launch_layernorm_c(const half_t* x, half_t* y, const float* gamma, const flo
                        int x_coff, int y_cpitch, int y_coff, hipStream_t s);
 int launch_mha32(const half_t* q, int q_cpitch, int q_coff, int q_tok, const half_t* kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,
                  half_t* o, int o_cpitch, int o_coff, int o_tok, int B, int heads, int Lq, int Lk, float scale, hipStream_t s);
+int mha32_nsplit(int Lk);
+int launch_mha32_split(const half_t* q, int q_cpitch, int q_coff, int q_tok, const half_t* kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,
+                       half_t* o, int o_cpitch, int o_coff, int o_tok, float* part, int B, int heads, int Lq, int Lk, float scale, hipStream_t s);
 int launch_pixshuf4_blur(const half_t* x, half_t* y, int B, int Hi, int Wi, int C, int x_cpitch, int x_coff, int y_cpitch, int y_coff,
                          hipStream_t s);
 // tweaks.hip: image_tweak chain (Pillow hue shift, ImageEnhance Brightness / Contrast / Color, hue-range mask), Y table of

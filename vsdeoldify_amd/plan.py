@@ -303,7 +303,8 @@ class PlanBuilder:
         """q / y: token views [1, tokens_per_frame, E] of which the first n_q rows are queries; kv: view over the K/V buffer
         [*, tokens, >= E] with K at channel k_coff and V at v_coff, n_k keys."""
         assert q.H == 1 and y.H == 1 and q.W == y.W and q.C == heads * 32
-        return self._op(name, type=nat.OP_MHA, src=q.buf, src_coff=q.coff, src_cpitch=q.cpitch, src2=kv.buf, res_cpitch=kv.cpitch,
+        part = self.buf(heads * ((n_k + 255) // 256) * n_q * 34, 4)          # partial softmax states of the key-split kernel
+        return self._op(name, type=nat.OP_MHA, aux1=part, src=q.buf, src_coff=q.coff, src_cpitch=q.cpitch, src2=kv.buf, res_cpitch=kv.cpitch,
                         res_coff=kv.coff + k_coff, aux0=kv.coff + v_coff, dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=n_q, Wi=q.W,
                         Ci=q.C, Ho=n_k, Wo=kv.H * kv.W, Co=q.C, kh=heads, f0=scale, flops=4 * n_q * n_k * q.C)
 
