@@ -150,3 +150,38 @@ def test_two_rank_timing_protocol_gloo(tmp_path):
     elapsed, total = float(line[1]), float(line[2])
     assert total == 10.0                       # (1 warm-up + 4 timed) x 2 ranks
     assert 0.075 <= elapsed < 1.0              # >= 4 x 20 ms of the slow rank (max over ranks), not rank 0's 40 ms
+
+
+def test_hue_string_parsers_mirror_the_reference():
+    """vsslib/restcolor.py:379-470 parsing rules restated in vsdeoldify_amd.imfilters (host side of havc_image_tweak / _chroma_tweak)"""
+    from vsdeoldify_amd import imfilters as F
+    assert F.parse_hue_ranges("280:360,0:30") == [280.0, 360.0, 0.0, 30.0]
+    assert F.parse_hue_ranges("red,blue-violet") == [0.0, 30.0, 240.0, 270.0]
+    assert F.parse_hue_adjust("red,orange|0.5,0.2") == ("red,orange", 0.5, 0, 0.2)
+    assert F.parse_hue_adjust("200:260|-60,0.3") == ("200:260", 1.0, -60, 0.3)          # signed first token = hue shift
+    assert F.parse_hue_adjust("green|30,0") == ("green", 1.0, 30, 0.0)                  # > 10 is a hue, not a saturation
+    assert F.parse_hue_adjust("cyan") == ("cyan", 1.0, 0, 0)
+    assert F.parse_hue_adjust("a|b|c") is None and F.parse_hue_adjust("red|x,y") is None
+    # luma_adjusted_levels' table: the uint8 wrap of np.add is part of the reference behaviour
+    lut = F.luma_levels_lut(0.2, luma_min=0.6)
+    i_alpha = int(255 * (0.6 - 0.2))
+    assert lut.dtype == np.uint8 and lut[0] == i_alpha and lut[200] == (200 + i_alpha) % 256 and lut[100] == 100 + i_alpha
+    assert np.array_equal(F.luma_levels_lut(0.5), np.arange(256, dtype=np.uint8))
+
+
+def test_ddcolor_plan_shapes_and_flops():
+    """the DDColor plan at input 512: op count, algorithmic FLOPs, einsum conv reading its weights from the token buffer"""
+    from vsdeoldify_amd import _native as nat
+    from vsdeoldify_amd.ddcolor_net import DDColorGenerator, TOK
+    from vsdeoldify_amd.synth import synth_ddcolor_state_dict
+    g = DDColorGenerator(synth_ddcolor_state_dict(1, depths=(1, 1, 1, 1), dec_layers=3), depths=(1, 1, 1, 1), dec_layers=3)
+    ops, bufs, i, o, names, consts = g.plan(128)
+    assert names[0] == "prep" and names[-1] == "refine_net.0.0"
+    e = ops[names.index("decoder.color_decoder.einsum")]
+    assert e["flags"] & nat.F_W_FROM_BUF and e["Npad"] == TOK and e["Kc"] == 32 and e["src2"] >= 0
+    mh = [op for op, n in zip(ops, names) if n.endswith(".attn")]
+    assert len(mh) == 6 and all(op["type"] == nat.OP_MHA and op["aux1"] >= 0 for op in mh)
+    assert {int(op["Ho"]) for op in mh} == {100, 8 * 8, 16 * 16, 32 * 32}                 # self-attention + the three feature levels
+    assert len(consts) == 1 + 3 * 3                                                       # query_feat + per layer: q, kv, qkv maps
+    for buf, arr, pitch, rows in consts:
+        assert arr.shape[0] <= rows and arr.shape[1] <= pitch and np.isfinite(arr).all()
