@@ -251,6 +251,11 @@ int havc_restore_color_gradient(havc_ctx* ctx, const uint8_t* img_color, const u
 int havc_colorize_clip(havc_ctx* ctx, havc_net* video, havc_net* second, float video_weight, const uint8_t* d_src,
                        uint8_t* d_dst, int n_frames, int width, int height);
 /* device memory helpers for callers that keep clips resident (bench.py, sharded runner) */
+/* The harness stand-in for the zimg `resize.Spline64` calls around the models (`__init__.py:2504`, `_clip_chroma_resize`
+ * `__init__.py:3545-3554`): separable 8-tap Spline64 on u8 RGB; with luma_from != NULL (a dw x dh frame) the result keeps only its
+ * chroma and takes the luma of that frame (vs_recover_clip_luma = chroma_post_process, vsslib/vsfilters.py:863-899), fused into the
+ * vertical pass.  zimg itself is outside the parity contract: production keeps zimg. */
+int havc_spline64_resize(havc_ctx* ctx, const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, const uint8_t* luma_from);
 int havc_dev_alloc(havc_ctx* ctx, size_t nbytes, void** out);
 int havc_dev_free(havc_ctx* ctx, void* p);
 int havc_dev_upload(havc_ctx* ctx, void* d_dst, const void* h_src, size_t nbytes);

@@ -170,6 +170,24 @@ def constrained_chroma_merge(img1, img2, level=0.2, weight=0.5, red_fix=True):
     return image_tweak(st, sat=0.7)
 
 
+def _red_fix(st):
+    luma = get_image_luma(st, 255)
+    if luma > 0.3:
+        return st
+    if luma > 0.2:
+        return w_image_luma_merge(image_tweak(st, sat=0.9, hue_range="280:360,0:30"), st, 0.2, 0.3)
+    if luma > 0.1:
+        return w_image_luma_merge(image_tweak(st, sat=0.8, hue_range="280:360,0:30"), st, 0.1, 0.2)
+    return image_tweak(st, sat=0.7)
+
+
+def chroma_bound_adaptive_merge(img1, img2, base_tol=14, max_extra=18, weight=0.5, red_fix=True):
+    """ChromaBoundAdaptiveMerge's merge_frame (vsslib/mcomb.py:370-437): adaptive chroma limiter + the same dark-frame red fix."""
+    from .pipeline import chroma_stabilizer_adaptive
+    st = chroma_stabilizer_adaptive(img1, img2, base_tol, max_extra, weight)
+    return _red_fix(st) if red_fix else st
+
+
 # ---- ChromaRetentionMerge core: restore_color_gradient (vsslib/restcolor.py:98-217) ---------------------------------
 def gradient_mask(sat_u8, tht=15, alpha=2.0, algo=0):
     """restcolor.py:137-217."""

@@ -94,6 +94,7 @@ SYMBOLS = [
     ("havc_luma_lut", _I, [_P, _P, _P, _P, _I, _I]),
     ("havc_restore_color_gradient", _I, [_P, _P, _P, _P, _I, _I, _D, _I, _D, _D, _I, _I]),
     ("havc_colorize_clip", _I, [_P, _P, _P, _F, _P, _P, _I, _I, _I]),
+    ("havc_spline64_resize", _I, [_P, _P, _I, _I, _P, _I, _I, _P]),
     ("havc_dev_alloc", _I, [_P, _SZ, C.POINTER(_P)]),
     ("havc_dev_free", _I, [_P, _P]),
     ("havc_dev_upload", _I, [_P, _P, _P, _SZ]),

@@ -1152,6 +1152,24 @@ int havc_colorize_clip(havc_ctx* c, havc_net* video, havc_net* second, float vid
     return t.finish();
 }
 
+int havc_spline64_resize(havc_ctx* c, const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, const uint8_t* luma_from) {
+    if (!c || !src || !dst || sw <= 0 || sh <= 0 || dw <= 0 || dh <= 0) return fail(c, HAVC_E_INVALID, "spline64_resize: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t sb = (size_t)sw * sh * 3, db = (size_t)dw * dh * 3;
+    int rc;
+    if ((rc = ensure_scratch(c, 0, sb)) || (rc = ensure_scratch(c, 2, db)) || (luma_from && (rc = ensure_scratch(c, 3, db)))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->scratch[0], src, sb, hipMemcpyHostToDevice, c->stream));
+    if (luma_from) HIP_TRY(c, hipMemcpyAsync(c->scratch[3], luma_from, db, hipMemcpyHostToDevice, c->stream));
+    if (sw == dw && sh == dh && !luma_from) {
+        HIP_TRY(c, hipMemcpyAsync(c->scratch[2], c->scratch[0], sb, hipMemcpyDeviceToDevice, c->stream));
+    } else if ((rc = resize_rgb8(c, (const uint8_t*)c->scratch[0], sw, sh, (uint8_t*)c->scratch[2], dw, dh, 1, luma_from ? (const uint8_t*)c->scratch[3] : nullptr)))
+        return rc;
+    HIP_TRY(c, hipMemcpyAsync(dst, c->scratch[2], db, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return HAVC_OK;
+}
+
 int havc_dev_alloc(havc_ctx* c, size_t nbytes, void** out) {
     if (!c || !out) return HAVC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
