@@ -1,16 +1,22 @@
 """-m gpu: whole DeOldify generators and the ModelImageRender drop-in against the CPU oracle.
 
 Floating-point path (fp16 storage, fp32 MFMA accumulation vs the fp32 oracle).  Stated tolerance
-(BASELINE.json north_star: CIEDE2000 < 1.0 vs the reference path):
-  * raw colour (u8 out of the network, before the YUV merge): >= 98 % of bytes within +-1 LSB, >= 99.5 %
-    within +-2 LSB, mean CIEDE2000 < 0.5, p99 < 1.5.  The reference TRUNCATES x*255 (filters.py:65-68), so
-    +-1 LSB flips are inherent to any arithmetic that is not bit-identical to fp32 torch;
-  * final image (chroma of the colour on the luma of the source): mean CIEDE2000 < 0.5 (measured 0.06-0.21),
-    p99 < 2.5: a single-LSB U/V flip on a DARK source pixel is worth 1-3 dE00 units, so the tail of the
-    distribution is set by the truncation, not by the network arithmetic.
+(BASELINE.json north_star: CIEDE2000 < 1.0 vs the reference path), justified by profiles/r2_precision_study.txt:
+  * raw colour (u8 out of the network, before the YUV merge): >= 99.5 % of bytes within +-1 LSB, >= 99.9 %
+    within +-2 LSB, mean CIEDE2000 < 0.25, p99 < 1.0 (measured 0.90-0.96).  The reference TRUNCATES x*255
+    (filters.py:65-68), so +-1 LSB flips are inherent to any arithmetic that is not bit-identical to fp32 torch:
+    two fp32 CPU evaluations that differ only in summation order already flip 0.01-0.03 % of the pixels by up to
+    dE00 2.5 (the noise floor; its p99 is 0);
+  * final image of ONE model at the net size (chroma of the colour on the luma of the source): mean CIEDE2000
+    < 0.25 (measured 0.05-0.17), p99 < 2.1 (measured 1.6-1.93): a single-LSB U/V flip on a DARK source pixel is
+    worth 1-3 dE00 units, so the tail of the distribution is set by the truncation.  The CPU simulation of the HIP
+    rounding points (tests/precision_study.py) reproduces these figures and shows that they are intrinsic to fp16
+    MFMA inputs: with the whole encoder, the network input and the last layer in fp32 the p99 moves 1.91 -> 1.75;
+  * the 1080p output of the HAVC flow (two-model blend + Spline64 up-pass + luma re-attach) is covered by
+    tests/test_gpu_fullsize.py: mean 0.11-0.12, p99 1.2, 97 % of the pixels below 1.0.
 """
-RAW_TOL = dict(within1=0.98, within2=0.995, mean=0.5, p99=1.5)
-FINAL_TOL = dict(mean=0.5, p99=2.5)
+RAW_TOL = dict(within1=0.995, within2=0.999, mean=0.25, p99=1.0)
+FINAL_TOL = dict(mean=0.25, p99=2.1)
 
 
 def check_final(got, ref):

@@ -40,7 +40,10 @@ SHAPES = {  # name: (Cin, Cout, k, stride, pad, H, W, flags)
 
 
 def bench(ctx, name, batch, reps, cfg=0):
-    Cin, Cout, k, s, p, H, W, flags = SHAPES[name]
+    with_res = name.endswith("+res")
+    Cin, Cout, k, s, p, H, W, flags = SHAPES[name[:-4] if with_res else name]
+    if with_res:
+        flags |= nat.F_RESIDUAL
     r = np.random.default_rng(0)
     pack, b = WeightPack(), PlanBuilder()
     x = b.tensor(H, W, Cin)
@@ -51,7 +54,8 @@ def bench(ctx, name, batch, reps, cfg=0):
     pc = pack_conv(pack, Wt, x.cmap, x.span, pixshuf=bool(flags & nat.F_OUT_PIXSHUF), **kw)
     Ho = (H + 2 * p - k) // s + 1
     y = b.tensor(2 * Ho, 2 * Ho, Cout // 4) if flags & nat.F_OUT_PIXSHUF else b.tensor(Ho, Ho, Cout)
-    b.conv(name, pc, x, y, stride=s, pad=p, flags=flags)
+    res = b.tensor(Ho, Ho, Cout) if with_res else None
+    b.conv(name, pc, x, y, stride=s, pad=p, flags=flags, res=res)
     ops, bufs = b.finish()
     ops["reserved"] = cfg
     w = nat.Weights(ctx, pack.blob())
@@ -59,6 +63,8 @@ def bench(ctx, name, batch, reps, cfg=0):
     xin = (r.standard_normal((batch, H, W, x.span)) * 0.5).astype(np.float16)
     xin[..., Cin:] = 0
     net.upload(x.buf, xin)
+    if with_res:
+        net.upload(res.buf, (r.standard_normal((batch, Ho, Ho, res.cpitch)) * 0.5).astype(np.float16))
     for _ in range(2):
         net.profile(batch)
     ms = float(np.median([net.profile(batch)[0] for _ in range(reps)]))
@@ -73,8 +79,10 @@ if __name__ == "__main__":
     filt = sys.argv[3] if len(sys.argv) > 3 else ""
     cfgs = [int(c) for c in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
     ctx = get_context(0)
-    for name in SHAPES:
-        if filt and filt not in name:
+    names = list(SHAPES) + [n + "+res" for n in SHAPES if n.startswith("e") and "c3" in n]
+    filts = [f for f in filt.split(",") if f]
+    for name in names:
+        if filts and not any(f in name for f in filts):
             continue
         for cfg in cfgs:
             try:

@@ -109,57 +109,96 @@ int launch_chroma_stabilizer(const uint8_t* stable, const uint8_t* inew, double 
 }
 
 // ---- separable polyphase resample (Spline64 taps computed on the host; harness stand-in for zimg) ----
-// pass 1 (horizontal): u8 [n][sh][sw][3] -> float [n][sh][dw][3]
-__global__ void resize_h_kernel(const uint8_t* __restrict__ src, float* __restrict__ tmp, const int* __restrict__ start,
-                                const float* __restrict__ wts, int taps, int sw, int dw, int64_t rows) {
-    const int64_t total = rows * dw;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % dw);
-        const int64_t row = i / dw;
+// Arithmetic contract (oracle/resample.py is the CPU twin): horizontal pass first, fp32, taps accumulated in ascending order,
+// product rounded before the add (no FMA: this file is built with -ffp-contract=off); vertical pass the same; round half up.
+// pass 1 (horizontal): u8 [rows][sw][3] -> float [rows][dw][3].  One block per source row: the row is staged in LDS with
+// aligned dword loads (a 1920-pixel row is read 29 times by the 560 outputs of the squash), then every thread produces
+// outputs x = tid, tid + 256, ...
+__global__ void __launch_bounds__(256) resize_h_kernel(const uint8_t* __restrict__ src, float* __restrict__ tmp, const int* __restrict__ start,
+                                                       const float* __restrict__ wts, int taps, int sw, int dw, int64_t rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rowbuf[];
+    for (int64_t row = blockIdx.x; row < rows; row += gridDim.x) {
         const uint8_t* sp = src + row * sw * 3;
-        const int s0 = start[x];
-        const float* w = wts + (int64_t)x * taps;
-        float r = 0.f, g = 0.f, b = 0.f;
-        for (int t = 0; t < taps; ++t) {
-            int sx = s0 + t;
-            sx = sx < 0 ? 0 : (sx >= sw ? sw - 1 : sx);
-            const float wt = w[t];
-            r += wt * sp[sx * 3]; g += wt * sp[sx * 3 + 1]; b += wt * sp[sx * 3 + 2];
+        const int a0 = (int)(reinterpret_cast<uintptr_t>(sp) & 3);
+        const uint32_t* wp = reinterpret_cast<const uint32_t*>(sp - a0);
+        const int nwords = (a0 + sw * 3 + 3) >> 2;            // an over-read stays inside the last aligned dword of the row
+        __syncthreads();
+        for (int i = threadIdx.x; i < nwords; i += 256) reinterpret_cast<uint32_t*>(rowbuf)[i] = wp[i];
+        __syncthreads();
+        const unsigned char* rb = rowbuf + a0;
+        for (int x = threadIdx.x; x < dw; x += 256) {
+            const int s0 = start[x];
+            const float* w = wts + (int64_t)x * taps;
+            float r = 0.f, g = 0.f, b = 0.f;
+            for (int t = 0; t < taps; ++t) {
+                int sx = s0 + t;
+                sx = sx < 0 ? 0 : (sx >= sw ? sw - 1 : sx);
+                const float wt = w[t];
+                r += wt * rb[sx * 3]; g += wt * rb[sx * 3 + 1]; b += wt * rb[sx * 3 + 2];
+            }
+            float* o = tmp + (row * dw + x) * 3;
+            o[0] = r; o[1] = g; o[2] = b;
         }
-        float* o = tmp + i * 3;
-        o[0] = r; o[1] = g; o[2] = b;
     }
 }
 
 // pass 2 (vertical): float [n][sh][dw][3] -> u8 [n][dh][dw][3]; if orig != null, fuse chroma_post_process
 // (vsfilters.py:863-899 -> imfilters.py:312-321): keep luma of orig, take U,V of the resampled colour.
-__global__ void resize_v_kernel(const float* __restrict__ tmp, uint8_t* __restrict__ dst, const uint8_t* __restrict__ orig,
-                                const int* __restrict__ start, const float* __restrict__ wts, int taps, int sh, int dh,
-                                int dw, int n_frames) {
-    const int64_t total = (int64_t)n_frames * dh * dw;
+// A thread produces VR consecutive output rows of one column: their tap windows overlap almost entirely (the window start
+// advances by src/dst rows per output), so the column of the intermediate image is read once for the group instead of once
+// per output -- the pass was L2-bandwidth bound (9 or 29 row reads per output pixel).  Every output still accumulates its
+// own taps in ascending order, edge rows replicated, exactly as one thread per output did.
+constexpr int VR = 4;
+__global__ void __launch_bounds__(256) resize_v_kernel(const float* __restrict__ tmp, uint8_t* __restrict__ dst, const uint8_t* __restrict__ orig,
+                                                       const int* __restrict__ start, const float* __restrict__ wts, int taps, int sh, int dh,
+                                                       int dw, int n_frames) {
+    const int groups = (dh + VR - 1) / VR;
+    const int64_t total = (int64_t)n_frames * groups * dw;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % dw);
-        const int y = (int)((i / dw) % dh);
-        const int f = (int)(i / ((int64_t)dw * dh));
-        const int s0 = start[y];
-        const float* w = wts + (int64_t)y * taps;
+        const int gy = (int)((i / dw) % groups);
+        const int f = (int)(i / ((int64_t)dw * groups));
+        const int y0 = gy * VR;
+        int s0[VR];
+        float acc[VR][3];
+        int lo = 0x7fffffff, hi = -0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < VR; ++k) {
+            const int y = y0 + k < dh ? y0 + k : dh - 1;
+            s0[k] = start[y];
+            lo = s0[k] < lo ? s0[k] : lo;
+            hi = s0[k] + taps - 1 > hi ? s0[k] + taps - 1 : hi;
+            acc[k][0] = acc[k][1] = acc[k][2] = 0.f;
+        }
         const float* base = tmp + (int64_t)f * sh * dw * 3 + (int64_t)x * 3;
-        float r = 0.f, g = 0.f, b = 0.f;
-        for (int t = 0; t < taps; ++t) {
-            int sy = s0 + t;
-            sy = sy < 0 ? 0 : (sy >= sh ? sh - 1 : sy);
-            const float wt = w[t];
+        for (int su = lo; su <= hi; ++su) {
+            const int sy = su < 0 ? 0 : (su >= sh ? sh - 1 : su);
             const float* p = base + (int64_t)sy * dw * 3;
-            r += wt * p[0]; g += wt * p[1]; b += wt * p[2];
+            const float pr = p[0], pg = p[1], pb = p[2];
+#pragma unroll
+            for (int k = 0; k < VR; ++k) {
+                const int t = su - s0[k];
+                if (t >= 0 && t < taps) {
+                    const int y = y0 + k < dh ? y0 + k : dh - 1;
+                    const float wt = wts[(int64_t)y * taps + t];
+                    acc[k][0] += wt * pr; acc[k][1] += wt * pg; acc[k][2] += wt * pb;
+                }
+            }
         }
-        int ri = sat8((int)floorf(r + 0.5f)), gi = sat8((int)floorf(g + 0.5f)), bi = sat8((int)floorf(b + 0.5f));
-        if (orig) {
-            int yy, u, v, y2, u2, v2;
-            rgb2yuv(ri, gi, bi, yy, u, v);
-            rgb2yuv(orig[i * 3], orig[i * 3 + 1], orig[i * 3 + 2], y2, u2, v2);
-            yuv2rgb(y2, u, v, ri, gi, bi);
+#pragma unroll
+        for (int k = 0; k < VR; ++k) {
+            const int y = y0 + k;
+            if (y >= dh) break;
+            int ri = sat8((int)floorf(acc[k][0] + 0.5f)), gi = sat8((int)floorf(acc[k][1] + 0.5f)), bi = sat8((int)floorf(acc[k][2] + 0.5f));
+            const int64_t o = ((int64_t)(f * dh + y) * dw + x) * 3;
+            if (orig) {
+                int yy, u, v, y2, u2, v2;
+                rgb2yuv(ri, gi, bi, yy, u, v);
+                rgb2yuv(orig[o], orig[o + 1], orig[o + 2], y2, u2, v2);
+                yuv2rgb(y2, u, v, ri, gi, bi);
+            }
+            dst[o] = (uint8_t)ri; dst[o + 1] = (uint8_t)gi; dst[o + 2] = (uint8_t)bi;
         }
-        dst[i * 3] = (uint8_t)ri; dst[i * 3 + 1] = (uint8_t)gi; dst[i * 3 + 2] = (uint8_t)bi;
     }
 }
 
@@ -167,9 +206,12 @@ int launch_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* dst, int d
                          const int* h_start, const float* h_w, int h_taps, const int* v_start, const float* v_w,
                          int v_taps, const uint8_t* orig, hipStream_t s) {
     const int64_t rows = (int64_t)n_frames * sh;
-    hipLaunchKernelGGL(resize_h_kernel, dim3(grid_for(rows * dw)), dim3(256), 0, s, src, tmp, h_start, h_w, h_taps, sw, dw,
-                       rows);
-    hipLaunchKernelGGL(resize_v_kernel, dim3(grid_for((int64_t)n_frames * dh * dw)), dim3(256), 0, s, tmp, dst, orig,
+    const size_t lds = (size_t)(sw * 3 + 8 + 15) & ~(size_t)15;
+    if (lds > 64 * 1024) return (int)hipErrorInvalidValue;            // rows beyond 21 800 pixels: not a video frame
+    hipLaunchKernelGGL(resize_h_kernel, dim3((unsigned)(rows < 65535 * 16 ? rows : 65535 * 16)), dim3(256), lds, s, src, tmp, h_start, h_w,
+                       h_taps, sw, dw, rows);
+    const int groups = (dh + VR - 1) / VR;
+    hipLaunchKernelGGL(resize_v_kernel, dim3(grid_for((int64_t)n_frames * groups * dw)), dim3(256), 0, s, tmp, dst, orig,
                        v_start, v_w, v_taps, sh, dh, dw, n_frames);
     return (int)hipGetLastError();
 }

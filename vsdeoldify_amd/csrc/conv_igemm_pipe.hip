@@ -20,6 +20,7 @@
 // involution is applied to the SOURCE chunk each DMA lane fetches.
 // EXTRA = 1: 16 extra output columns (the 259-channel tail: Npad = 256 + 16) as 2 more MFMAs per wave per K half.
 #include "conv_common.h"
+#include <atomic>
 #include <type_traits>
 
 namespace {
@@ -470,6 +471,20 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs p) {
 #include "conv_pipe_epilogue.inc"
 }
 
+// Opt a kernel in to > 64 KiB of dynamic LDS.  The attribute is per DEVICE (a process may hold contexts on several GPUs:
+// render.get_context caches one per device_index), so the "done" state is a bit per device ordinal, set with an atomic OR
+// (VapourSynth worker threads may race here; setting the attribute twice is harmless).
+template <auto Kernel>
+static void ensure_lds_optin(int lds_bytes) {
+    static std::atomic<uint64_t> done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    done.fetch_or(bit, std::memory_order_release);
+}
+
 template <int EXTRA, int ABL = 0>
 static int launch_halo(const ConvArgs& a0, hipStream_t s) {
     ConvArgs a = a0;
@@ -483,11 +498,7 @@ static int launch_halo(const ConvArgs& a0, hipStream_t s) {
     a.M = MT * 256;
     constexpr int LDS = 2 * 46 * 1024 + 2 * (256 + 16 * EXTRA) * 128;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_halo_kernel<EXTRA, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    ensure_lds_optin<conv_halo_kernel<EXTRA, ABL>>(LDS);
     hipLaunchKernelGGL((conv_halo_kernel<EXTRA, ABL>), dim3(MT * NT), dim3(512), LDS, s, a);
     return (int)hipGetLastError();
 }
@@ -499,11 +510,7 @@ static int launch_pipe(const ConvArgs& a, hipStream_t s) {
     const int MT = (a.M + G::BM - 1) / G::BM, NT = (a.Npad - 16 * EXTRA + G::BN - 1) / G::BN;
     constexpr int LDS = G::LDS_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_pipe_kernel<WM, WN, FM, EXTRA, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        attr_set = true;
-    }
+    ensure_lds_optin<conv_pipe_kernel<WM, WN, FM, EXTRA, ABL>>(LDS);
     hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, ABL>), dim3(MT * NT), dim3(G::NW * 64), LDS, s, a);
     return (int)hipGetLastError();
 }

@@ -87,6 +87,50 @@ int launch_blur_resize(const half_t* x, half_t* y, int B, int Hi, int Wi, int Ho
 }
 
 // ---- y = [relu](x*scale + shift): skip-connection BatchNorm + the block ReLU (unet.py:204), layers.1/2 ----
+// HBM-bound: 16 B in, 16 B out per thread-item.  Fast form (C8 divides 256): a thread keeps ONE channel chunk for the whole
+// launch, so its 8 scale / 8 shift values are loaded once (4 x float4) instead of 16 dword loads per item, and pixel
+// indices need no 64-bit division; 4 pixels per iteration keep 4 loads in flight per lane.
+template <int RELU, int HAS_SS>
+__global__ void __launch_bounds__(256) affine_fast_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int64_t npix, int C8, int x_cpitch, int x_coff,
+                                                          int y_cpitch, int y_coff) {
+    const int c8 = threadIdx.x % C8, pl = threadIdx.x / C8, ppb = 256 / C8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = 1.f; sh[e] = 0.f; }
+    if (HAS_SS) {
+        const float4 a0 = *reinterpret_cast<const float4*>(scale + c8 * 8), a1 = *reinterpret_cast<const float4*>(scale + c8 * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(shift + c8 * 8), b1 = *reinterpret_cast<const float4*>(shift + c8 * 8 + 4);
+        sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+        sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+    }
+    const half_t* xp = x + x_coff + c8 * 8;
+    half_t* yp = y + y_coff + c8 * 8;
+    const int64_t step = (int64_t)gridDim.x * ppb;
+    for (int64_t p0 = (int64_t)blockIdx.x * ppb + pl; p0 < npix; p0 += 4 * step) {
+        half8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t pix = p0 + u * step;
+            if (pix < npix) v[u] = *reinterpret_cast<const half8*>(xp + pix * x_cpitch);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t pix = p0 + u * step;
+            if (pix >= npix) continue;
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v[u][e];
+                if (HAS_SS) f = f * sc[e] + sh[e];
+                if (RELU) f = fmaxf(f, 0.f);
+                o[e] = (half_t)f;
+            }
+            *reinterpret_cast<half8*>(yp + pix * y_cpitch) = o;
+        }
+    }
+}
+
 __global__ void affine_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ scale,
                               const float* __restrict__ shift, int relu, int64_t npix, int C8, int x_cpitch, int x_coff,
                               int y_cpitch, int y_coff) {
@@ -110,6 +154,16 @@ __global__ void affine_kernel(const half_t* __restrict__ x, half_t* __restrict__
 int launch_affine(const half_t* x, half_t* y, const float* scale, const float* shift, int relu, int64_t npix, int C,
                   int x_cpitch, int x_coff, int y_cpitch, int y_coff, hipStream_t s) {
     const int C8 = C / 8;
+    if (C8 >= 1 && C8 <= 256 && 256 % C8 == 0) {
+        const int ppb = 256 / C8;
+        int64_t blocks = (npix + (int64_t)ppb * 4 - 1) / ((int64_t)ppb * 4);       // ~4 pixels per thread
+        const int grid = (int)(blocks < 1 ? 1 : (blocks > 16384 ? 16384 : blocks));
+#define AFF_LAUNCH(R, S_) hipLaunchKernelGGL((affine_fast_kernel<R, S_>), dim3(grid), dim3(256), 0, s, x, y, scale, shift, npix, C8, x_cpitch, x_coff, y_cpitch, y_coff)
+        if (scale) { if (relu) AFF_LAUNCH(1, 1); else AFF_LAUNCH(0, 1); }
+        else { if (relu) AFF_LAUNCH(1, 0); else AFF_LAUNCH(0, 0); }
+#undef AFF_LAUNCH
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(affine_kernel, dim3(grid_for(npix * C8)), dim3(256), 0, s, x, y, scale, shift, relu, npix, C8,
                        x_cpitch, x_coff, y_cpitch, y_coff);
     return (int)hipGetLastError();

@@ -32,6 +32,8 @@ struct havc_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_main_done = nullptr;
     hipStream_t cur = nullptr;            // stream the plan executor launches on (stream or stream2)
     bool two_streams = true;              // HAVC_TWO_STREAMS=0 serialises the two generators (A/B measurements)
+    uint64_t desc_limit = 0xE0000000ull;  // bytes one conv launch may address per operand (32-bit buffer descriptors);
+                                          // HAVC_DESC_LIMIT_BYTES lowers it so tests reach the frame-chunking path at small sizes
     std::mutex mu;
     std::string err;
     havc_stats stats{};
@@ -88,10 +90,17 @@ int hip_fail(havc_ctx* c, hipError_t e, const char* what) {
         if (_e != hipSuccess) return hip_fail((ctx), _e, #expr);   \
     } while (0)
 
+// Both streams idle: required before anything either of them may still touch is freed or re-allocated.
+hipError_t sync_streams(havc_ctx* c) {
+    hipError_t a = hipStreamSynchronize(c->stream);
+    hipError_t b = c->stream2 ? hipStreamSynchronize(c->stream2) : hipSuccess;
+    return a != hipSuccess ? a : b;
+}
+
 int ensure_scratch(havc_ctx* c, int slot, size_t nbytes) {
     if (c->scratch_sz[slot] >= nbytes) return HAVC_OK;
     if (c->scratch[slot]) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, sync_streams(c));
         (void)hipFree(c->scratch[slot]);
         c->stats.bytes_resident -= (int64_t)c->scratch_sz[slot];
         c->scratch[slot] = nullptr;
@@ -310,7 +319,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             {
                 // frames per launch: keep every operand within the 32-bit range of a buffer descriptor (and of the
                 // kernels' int pixel indices); big batches of the 560x560 tail run as several launches.
-                const uint64_t lim = 0xE0000000ull;
+                const uint64_t lim = c->desc_limit;
                 const uint64_t xf = (uint64_t)n->bufdesc[op.src].elems_per_frame * n->bufdesc[op.src].elem_bytes;
                 const uint64_t yf = (uint64_t)n->bufdesc[op.dst].elems_per_frame * n->bufdesc[op.dst].elem_bytes;
                 const uint64_t rf = a.res ? (uint64_t)n->bufdesc[op.src2].elems_per_frame * n->bufdesc[op.src2].elem_bytes : 0;
@@ -511,18 +520,30 @@ int run_generators(havc_ctx* c, havc_net* video, havc_net* second, const uint8_t
         n->in_override = nullptr; n->out_override = nullptr; c->cur = nullptr;
         return r;
     };
-    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
-    if ((rc = part(video, d_in, d_v, 0, ta, nullptr))) return rc;
-    if ((rc = part(second, d_in, d_s, 0, tb, c->stream2))) return rc;
-    HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));                        // B.small done
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    if ((rc = part(video, d_in, d_v, ta, (int)video->ops.size() - ta, nullptr))) return rc;
-    HIP_TRY(c, hipEventRecord(c->ev_main_done, c->stream));                    // A.tail done
-    HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_main_done, 0));
-    if ((rc = part(second, d_in, d_s, tb, (int)second->ops.size() - tb, c->stream2))) return rc;
-    HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));                        // B.tail done
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    // After the fork stream2 holds kernels that use the caller's scratch and the second net's buffers: on ANY failure both
+    // streams are drained before the error is returned, so a later realloc / free cannot race with queued work.
+    auto body = [&]() -> int {
+        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+        if ((rc = part(video, d_in, d_v, 0, ta, nullptr))) return rc;
+        if ((rc = part(second, d_in, d_s, 0, tb, c->stream2))) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));                        // B.small done
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        if ((rc = part(video, d_in, d_v, ta, (int)video->ops.size() - ta, nullptr))) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_main_done, c->stream));                    // A.tail done
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_main_done, 0));
+        if ((rc = part(second, d_in, d_s, tb, (int)second->ops.size() - tb, c->stream2))) return rc;
+        HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));                        // B.tail done
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        return HAVC_OK;
+    };
+    if ((rc = body())) {
+        const std::string keep = c->err;
+        (void)sync_streams(c);
+        (void)hipGetLastError();
+        c->err = keep;
+        return rc;
+    }
     c->stats.total_flops += (video->flops_per_frame + second->flops_per_frame) * b;
     return HAVC_OK;
 }
@@ -552,6 +573,10 @@ int havc_create(havc_ctx** out, int device_id) {
     havc_ctx* c = new havc_ctx();
     c->dev = device_id;
     if (const char* e = getenv("HAVC_TWO_STREAMS")) c->two_streams = atoi(e) != 0;
+    if (const char* e = getenv("HAVC_DESC_LIMIT_BYTES")) {
+        const unsigned long long v = strtoull(e, nullptr, 0);
+        if (v >= 4096 && v <= 0xE0000000ull) c->desc_limit = v;
+    }
     if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -589,7 +614,7 @@ const char* havc_last_error(const havc_ctx* c) { return c ? c->err.c_str() : g_c
 int havc_synchronize(havc_ctx* c) {
     if (!c) return HAVC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     return HAVC_OK;
 }
 
@@ -628,7 +653,7 @@ int havc_weights_load(havc_ctx* c, const void* blob, size_t nbytes, havc_weights
 void havc_weights_free(havc_weights* w) {
     if (!w) return;
     std::lock_guard<std::mutex> lk(w->ctx->mu);
-    (void)hipStreamSynchronize(w->ctx->stream);
+    (void)sync_streams(w->ctx);
     (void)hipFree(w->d_blob);
     w->ctx->stats.bytes_resident -= (int64_t)w->nbytes;
     delete w;
@@ -646,6 +671,8 @@ int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops,
         auto bad = [&](int id) { return id < -1 || id >= n_bufs; };
         if (bad(o.src) || bad(o.src2) || bad(o.dst) || o.src < 0 || o.dst < 0) return fail(c, HAVC_E_INVALID, "net_create: op buffer id out of range");
         if (o.type == HAVC_OP_ATTENTION && (o.aux1 < 0 || o.aux1 >= n_bufs)) return fail(c, HAVC_E_INVALID, "net_create: attention V^T buffer id");
+        if (o.type == HAVC_OP_CONV && (o.flags & (HAVC_F_RESIDUAL | HAVC_F_W_FROM_BUF)) && o.src2 < 0)
+            return fail(c, HAVC_E_INVALID, "net_create: conv op with RESIDUAL / W_FROM_BUF needs a buffer in src2");
         for (int64_t off : {o.w_off, o.bias_off, o.scale_off, o.shift_off})
             if (off >= 0 && ((size_t)off >= w->nbytes || (off & 15))) return fail(c, HAVC_E_INVALID, "net_create: weight offset out of range / unaligned");
     }
@@ -658,6 +685,7 @@ int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops,
     for (int i = 0; i < n_ops; ++i) n->flops_per_frame += (double)ops[i].flops;
     for (int i = 0; i < n_ops; ++i)
         if (ops[i].tag == 1) { n->tail_first = i; break; }
+    size_t ktab_bytes = 0;
     // ---- per-conv K tables: chunk kidx -> (byte offset from the tap-0 pixel, tap displacement) -----------------
     // K order (must match plan.py pack_conv): main segment = chunks [0, C8a) of every tap, then chunks [C8a, C8), each
     // segment padded to a multiple of 8 chunks.  A main segment with C8a % 8 == 0 is CHANNEL-GROUP MAJOR (group of 8
@@ -701,8 +729,13 @@ int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops,
         if (!host.empty()) {
             hipError_t e = hipMalloc((void**)&n->d_ktab, host.size() * sizeof(int2));
             if (e == hipSuccess) e = hipMemcpy(n->d_ktab, host.data(), host.size() * sizeof(int2), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { delete n; return hip_fail(c, e, "K table upload"); }
-            c->stats.bytes_resident += (int64_t)(host.size() * sizeof(int2));
+            if (e != hipSuccess) {
+                if (n->d_ktab) (void)hipFree(n->d_ktab);
+                delete n;
+                return hip_fail(c, e, "K table upload");
+            }
+            ktab_bytes = host.size() * sizeof(int2);
+            c->stats.bytes_resident += (int64_t)ktab_bytes;
         }
     }
     for (int i = 0; i < n_bufs; ++i) {
@@ -711,7 +744,15 @@ int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops,
         hipError_t e = hipMalloc(&n->bufs[i], nb);
         if (e == hipSuccess && bufs[i].zero_init) e = hipMemset(n->bufs[i], 0, nb);
         if (e != hipSuccess) {
-            for (int k = 0; k <= i; ++k) if (n->bufs[k]) (void)hipFree(n->bufs[k]);
+            for (int k = 0; k <= i; ++k) {
+                if (!n->bufs[k]) continue;
+                (void)hipFree(n->bufs[k]);
+                if (k < i) c->stats.bytes_resident -= (int64_t)((size_t)bufs[k].elems_per_frame * bufs[k].elem_bytes * max_batch + 256);
+            }
+            if (n->d_ktab) {
+                (void)hipFree(n->d_ktab);
+                c->stats.bytes_resident -= (int64_t)ktab_bytes;
+            }
             delete n;
             return hip_fail(c, e, "activation buffer allocation");
         }
@@ -724,8 +765,13 @@ int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops,
 void havc_net_free(havc_net* n) {
     if (!n) return;
     std::lock_guard<std::mutex> lk(n->ctx->mu);
-    (void)hipStreamSynchronize(n->ctx->stream);
-    if (n->d_ktab) (void)hipFree(n->d_ktab);
+    (void)sync_streams(n->ctx);
+    if (n->d_ktab) {
+        (void)hipFree(n->d_ktab);
+        size_t chunks = 0;
+        for (const havc_op& o : n->ops) if (o.type == HAVC_OP_CONV) chunks += (size_t)o.Kc;
+        n->ctx->stats.bytes_resident -= (int64_t)(chunks * sizeof(int2));
+    }
     for (size_t i = 0; i < n->bufs.size(); ++i) {
         if (n->bufs[i]) (void)hipFree(n->bufs[i]);
         n->ctx->stats.bytes_resident -= (int64_t)((size_t)n->bufdesc[i].elems_per_frame * n->bufdesc[i].elem_bytes * n->max_batch + 256);
@@ -1181,7 +1227,7 @@ int havc_dev_free(havc_ctx* c, void* p) {
     if (!c) return HAVC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(c, hipSetDevice(c->dev));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, sync_streams(c));
     HIP_TRY(c, hipFree(p));
     return HAVC_OK;
 }
