@@ -9,6 +9,13 @@
  * torch / numpy / PIL types.  All functions return 0 (HAVC_OK) or a negative HAVC_E_* code;
  * havc_last_error() returns a human-readable message for the calling thread's context.
  *
+ * Pointers: every image operand of the frame / filter entry points may be a HOST pointer or a DEVICE pointer of the
+ * ctx's GPU (havc_dev_alloc, or any hipMalloc of that device; unified addressing tells them apart per operand).  Host
+ * operands are staged through the ctx workspace and the call returns when the result is back in host memory.  Device
+ * operands are used in place: nothing is copied and a call whose OUTPUT is a device pointer only enqueues work on the ctx
+ * stream (havc_synchronize, havc_dev_download or any later call with a host output orders against it).  A whole HAVC merge
+ * graph therefore runs without leaving HBM (vsdeoldify_amd/device.py).  Outputs must not alias inputs unless stated.
+ *
  * Threading: a havc_ctx owns one GPU, one HIP stream and one workspace arena.  Calls on the same
  * ctx are serialised by an internal mutex (ctypes releases the GIL, VapourSynth has several worker
  * threads); create one ctx per GPU (and per worker if concurrency on one GPU is wanted).
@@ -38,9 +45,9 @@ typedef struct havc_net havc_net;
 /* ------------------------------------------------------------------------------------------------
  * Execution plan.  A network is a flat list of ops over numbered activation buffers (NHWC fp16,
  * channel count padded to a multiple of 8, pad channels always zero).  The plan is emitted by the
- * host-side model builder (vsdeoldify_amd/deoldify_plan.py) from the reference topology
+ * host-side model builder (vsdeoldify_amd/deoldify_net.py) from the reference topology
  * (deoldify/unet.py:94-285, Appendix B of SURVEY.md) for one input size S; weights are packed once
- * per model (vsdeoldify_amd/packing.py) with spectral/weight norm and conv->BN folded.
+ * per model (vsdeoldify_amd/plan.py) with spectral/weight norm and conv->BN folded.
  * ---------------------------------------------------------------------------------------------- */
 enum havc_op_type {
     HAVC_OP_CONV = 1,        /* implicit-GEMM convolution on MFMA with fused epilogue                     */
@@ -143,7 +150,7 @@ int havc_reset_stats(havc_ctx* ctx);
 const char* havc_version(void);
 
 /* ---- weights (replaces: Learner.load -> torch.load(models/<name>.pth) + load_state_dict,
- *      fastai/basic_train.py:264-286; the blob is produced by vsdeoldify_amd/packing.py) ---- */
+ *      fastai/basic_train.py:264-286; the blob is produced by vsdeoldify_amd/plan.py) ---- */
 int havc_weights_load(havc_ctx* ctx, const void* blob, size_t nbytes, havc_weights** out);
 void havc_weights_free(havc_weights* w);
 
@@ -164,6 +171,13 @@ int havc_net_download(havc_net* net, int buf, void* host, size_t nbytes);
 int havc_net_run_ops(havc_net* net, int first_op, int n_ops, int batch);  /* run a slice of the plan */
 /* per-op GPU time of one run (ms, n_ops entries), measured with HIP events around every op */
 int havc_net_profile(havc_net* net, int batch, float* ms_per_op, int n_ops);
+
+/* Measure the conv tile configurations of every conv op of the plan at `batch` frames and keep the fastest per op (stored in the
+ * op's `reserved` field; identical shapes are measured once).  All configurations produce the same bytes, so this only changes
+ * speed.  Costs about a second per net; *n_changed (may be NULL) = ops whose configuration differs from the heuristic's.
+ * havc_net_get_cfg returns the configuration id an op will run with (0 = heuristic). */
+int havc_net_autotune(havc_net* net, int batch, int* n_changed);
+int havc_net_get_cfg(havc_net* net, int op_index);
 
 /* ---- frame-in / frame-out entry points (host buffers, blocking) ---------------------------------
  * havc_deoldify_frames replaces ModelImageRender.get_transformed_image (deoldify/visualize.py:118-137)
@@ -188,6 +202,22 @@ int havc_zhang_frames(havc_ctx* ctx, havc_net* net, const uint8_t* rgb_in, uint8
  * back to the frame size -> Lab(L_frame, ab) -> RGB u8.  PARITY UNPINNED: vsddcolor is an external wheel that is not part of the
  * reference tree (oracle/ddcolor.py).  rgb_in / rgb_out: host u8 interleaved RGB, n frames of width*height*3. */
 int havc_ddcolor_frames(havc_ctx* ctx, havc_net* net, const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames, int width, int height);
+/* The SHAPE the reference calls vsddcolor.ddcolor with (vsslib/vsmodels.py:353-363): one frame as three planar float32 (RGBS,
+ * is_half = 0) or float16 (RGBH, is_half = 1) planes, full range [0, 1], in and out (host or device planes, row stride in bytes).
+ * The planes are the RGB24 frame cast by zimg (k / 255): they are brought back to u8 with round(x * 255), run through the same
+ * path as havc_ddcolor_frames, and the Lab -> RGB result is written as float / half planes WITHOUT the u8 quantisation (the
+ * reference quantises afterwards with resize.Bicubic(format=RGB24), vsmodels.py:363).  PARITY UNPINNED like havc_ddcolor_frames. */
+int havc_ddcolor_frame_planar_f(havc_ctx* ctx, havc_net* net, const void* const in_planes[3], int in_stride_bytes,
+                                void* const out_planes[3], int out_stride_bytes, int is_half, int width, int height);
+/* One VapourSynth RGB24 frame (three u8 planes with a row stride, S x S = the nets' render size) through ModelImageRender: the
+ * selector body of vs_sc_deoldify (vsslib/vsmodels.py:214-230 = frame_to_image -> get_transformed_image -> image_to_frame,
+ * vsslib/vsutils.py:60-110) with the planar <-> interleaved shuffles on the GPU.  Planes may be host or device memory. */
+int havc_deoldify_frame_planar(havc_ctx* ctx, havc_net* video, havc_net* second, float video_weight, int post_process,
+                               const uint8_t* const in_planes[3], int in_stride, uint8_t* const out_planes[3], int out_stride);
+/* frame_to_image / frame_to_np_array and image_to_frame / np_array_to_frame (vsslib/vsutils.py:60-110): three u8 planes with a
+ * row stride <-> interleaved RGB, w x h */
+int havc_planar_to_rgb8(havc_ctx* ctx, const uint8_t* const planes[3], int stride, uint8_t* rgb, int width, int height);
+int havc_rgb8_to_planar(havc_ctx* ctx, const uint8_t* rgb, uint8_t* const planes[3], int stride, int width, int height);
 /* Pillow Image.resize (BILINEAR = 2, BICUBIC = 3), 8 bits per channel, bit-exact (libImaging/Resample.c) */
 int havc_pil_resize(havc_ctx* ctx, const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int resample);
 
@@ -250,16 +280,27 @@ int havc_restore_color_gradient(havc_ctx* ctx, const uint8_t* img_color, const u
  * Frames are processed in batches of the nets' max_batch. */
 int havc_colorize_clip(havc_ctx* ctx, havc_net* video, havc_net* second, float video_weight, const uint8_t* d_src,
                        uint8_t* d_dst, int n_frames, int width, int height);
+/* The same flow for HOST frames, pipelined: batch i+1 is uploaded and batch i-1 downloaded on two copy streams while batch i
+ * is on the compute stream (double-buffered device staging).  h_src / h_dst should be pinned (havc_host_alloc) for the copies
+ * to overlap; pageable memory works but serialises.  Blocks until every result is in h_dst. */
+int havc_colorize_clip_host(havc_ctx* ctx, havc_net* video, havc_net* second, float video_weight, const uint8_t* h_src,
+                            uint8_t* h_dst, int n_frames, int width, int height);
+int havc_host_alloc(havc_ctx* ctx, size_t nbytes, void** out);    /* pinned host memory (hipHostMalloc) */
+int havc_host_free(havc_ctx* ctx, void* p);
 /* device memory helpers for callers that keep clips resident (bench.py, sharded runner) */
 /* The harness stand-in for the zimg `resize.Spline64` calls around the models (`__init__.py:2504`, `_clip_chroma_resize`
  * `__init__.py:3545-3554`): separable 8-tap Spline64 on u8 RGB; with luma_from != NULL (a dw x dh frame) the result keeps only its
  * chroma and takes the luma of that frame (vs_recover_clip_luma = chroma_post_process, vsslib/vsfilters.py:863-899), fused into the
  * vertical pass.  zimg itself is outside the parity contract: production keeps zimg. */
 int havc_spline64_resize(havc_ctx* ctx, const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, const uint8_t* luma_from);
+/* n_frames tightly packed frames per operand in one call (device-resident clips) */
+int havc_spline64_resize_n(havc_ctx* ctx, const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, const uint8_t* luma_from,
+                           int n_frames);
 int havc_dev_alloc(havc_ctx* ctx, size_t nbytes, void** out);
 int havc_dev_free(havc_ctx* ctx, void* p);
 int havc_dev_upload(havc_ctx* ctx, void* d_dst, const void* h_src, size_t nbytes);
 int havc_dev_download(havc_ctx* ctx, void* h_dst, const void* d_src, size_t nbytes);
+int havc_dev_copy(havc_ctx* ctx, void* d_dst, const void* d_src, size_t nbytes);      /* device -> device, enqueued on the ctx stream */
 
 /* timing of the dominant kernel for bench.py's roofline object: average duration (ms) and launch count
  * of HAVC_OP_CONV ops with the given tag over the launches since havc_reset_stats (HIP events on the

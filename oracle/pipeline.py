@@ -170,3 +170,59 @@ def color_temporal_stabilizer(img_f, weight_list):
     yuv_new[:, :, 1] = yuv_m[:, :, 1]
     yuv_new[:, :, 2] = yuv_m[:, :, 2]
     return cvcolor.yuv2rgb_u8(yuv_new)
+
+
+# ---- model-combination graph (vsslib/mcomb.py) restated on uint8 frames ---------------------------------------------
+def luma_masked_merge(a, b, luma_mask_limit=0.4, luma_white_limit=0.7, clipm_weight=0.5):
+    """LumaMaskedMerge.merge_frame with luma_mask_sat >= 1 (clipc == clipa), vsslib/mcomb.py:238-271."""
+    if luma_mask_limit == luma_white_limit:
+        masked = image_luma_merge(a, b, luma_mask_limit)
+    else:
+        masked = w_image_luma_merge(a, b, luma_mask_limit, luma_white_limit)
+    return imaging.pil_blend(a, masked, clipm_weight) if clipm_weight < 1.0 else masked
+
+
+def adaptive_luma_merge(a, b, luma_threshold=0.6, alpha=1.0, clipb_weight=0.5, min_weight=0.15):
+    """AdaptiveLumaMerge.merge_frame, vsslib/mcomb.py:289-314."""
+    luma = get_image_luma(b)
+    w = max(clipb_weight * pow(luma / luma_threshold, alpha), min_weight) if luma < luma_threshold else clipb_weight
+    return imaging.pil_blend(a, b, w)
+
+
+def chroma_retention_merge(a, b, sat=0.8, tht=30, clipb_weight=0.9, alpha=2.0, mask_weight=0.0, algo=0):
+    """ChromaRetentionMerge with chroma_resize=False (vsslib/mcomb.py:450-516): color_grad_frame (vsslib/vsfilters.py:391-412)
+    then vs_simple_merge(clip_a, restored, clipb_weight) = std.Merge, restated as the float32 truncating blend of Image.blend
+    (std.Merge of 8-bit clips rounds instead: outside the parity contract like every VapourSynth core filter)."""
+    from . import tweaks
+    alpha = max(min(alpha, 10.0), 1.0)                                     # DEF_MIN/MAX_COLOR_ALPHA, vsslib/constants.py:80-81
+    luma = get_image_luma(a)
+    if not (0.22 <= luma <= 0.78):                                         # DEF_STANDARD_DARK / BRIGHT, constants.py:28-29
+        mask_weight, alpha = min(mask_weight, -0.5), max(alpha, 4.0)
+    restored = tweaks.restore_color_gradient(b, a, sat, tht, mask_weight, alpha, False, algo)
+    if clipb_weight == 0.0:
+        return a
+    if clipb_weight == 1.0:
+        return restored
+    return imaging.pil_blend(a, restored, clipb_weight)
+
+
+def combine_models(a, b, method, w, cmc_p=(0.15, True, 20, 24), lmm_p=(0.15, 0.65, 1.0), alm_p=(0.8, 1.0, 0.15), crt_p=(0.8, 30, 2, False, 0, 0)):
+    """vs_sc_combine_models (vsslib/mcomb.py:125-192) on one pair of uint8 frames, sat = [1, 1], hue = [0, 0]."""
+    from . import tweaks
+    red_fix, base_tol, max_extra = (cmc_p[1], cmc_p[2], cmc_p[3]) if len(cmc_p) > 1 else (True, 20, 24)
+    if a is None or b is None:
+        return a if b is None else b
+    if method == 2:
+        return imaging.pil_blend(a, b, w)
+    if method == 3:
+        ccm = tweaks.constrained_chroma_merge(a, b, cmc_p[0], w, red_fix)
+        return imaging.pil_blend(ccm, imaging.pil_blend(a, b, min(w, 0.6)), 0.3)
+    if method == 4:
+        return luma_masked_merge(a, b, lmm_p[0], lmm_p[1], w)
+    if method == 5:
+        return adaptive_luma_merge(a, b, alm_p[0], alm_p[1], w, alm_p[2])
+    if method == 6:
+        return chroma_retention_merge(a, b, crt_p[0], crt_p[1], w, crt_p[2], crt_p[4], crt_p[5])
+    if method == 7:
+        return tweaks.chroma_bound_adaptive_merge(a, b, base_tol, max_extra, w, red_fix)
+    raise ValueError("HAVC: only dd_method in (0,6) is supported")

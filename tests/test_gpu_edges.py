@@ -86,19 +86,24 @@ def test_bad_arguments_are_refused_not_crashed(ctx):
 
 
 def test_oom_returns_gray_input_like_the_reference(ctx, monkeypatch):
-    """deoldify/filters.py:55-63: on an out-of-memory error the filter logs a warning and returns the (squared, gray) input"""
+    """deoldify/filters.py:55-63: on an out-of-memory error _model_process logs a warning and returns the (squared, gray) model
+    image -- and filter() CONTINUES with it (un-square to the source size, post-process), so the caller still gets an image of
+    the source size."""
     from PIL import Image
+    from oracle import pipeline
     from vsdeoldify_amd import render
     from vsdeoldify_amd.synth import synth_state_dict
     mir = render.ModelImageRender("", "video", render_factor=4, state_dicts={"video": synth_state_dict("wide", 1)})
     img = Image.fromarray(_rgb(48, 80, 3))
     assert mir.get_transformed_image(img).size == img.size
 
-    def boom(sq):
+    def boom(S, max_batch=1):
         raise nat.HavcOutOfMemory("simulated HAVC_E_OOM")
-    monkeypatch.setattr(mir, "_raw_colors", boom)
-    got = mir.get_transformed_image(img)
-    want = img.resize((64, 64), resample=Image.BILINEAR).convert("LA").convert("RGB")
-    assert got.size == (64, 64) and np.array_equal(np.asarray(got), np.asarray(want))
+    monkeypatch.setattr(mir._video, "net", boom)
+    for im in (img, img.resize((64, 64))):                       # non-square source, and a source already at the render size
+        got = mir.get_transformed_image(im)
+        gray = im.resize((64, 64), resample=Image.BILINEAR).convert("LA").convert("RGB")
+        want = pipeline.post_process(np.asarray(gray.resize(im.size, resample=Image.BILINEAR)), np.asarray(im))
+        assert got.size == im.size and np.array_equal(np.asarray(got), want)
     with pytest.raises(FileNotFoundError):
         render.ModelImageRender("/nonexistent", "video", render_factor=4)

@@ -86,6 +86,48 @@ def test_conv_glds_configs(ctx, case):
     assert (raw[..., Cout:] == 0).all(), "pad channels must stay zero"
 
 
+@pytest.mark.parametrize("flags,with_res", [(nat.F_RELU_POST, True), (nat.F_RELU_PRE, True), (nat.F_RELU_PRE | nat.F_AFFINE, False)])
+def test_conv_tile_configurations_are_bit_identical(ctx, flags, with_res):
+    """The autotuner (havc_net_autotune) and the batch-size dependent heuristic may run an op with ANY tile configuration: all of
+    them must produce the same bytes (same packed K order, same MFMA sequence per output, same rounding points in the epilogue),
+    so a frame colours identically in every batch size."""
+    r = np.random.default_rng(11)
+    x = h16(r.standard_normal((2, 256, 20, 23)))
+    Wt = h16(r.standard_normal((256, 256, 3, 3)) / 48)
+    bias, sc, sh = (r.standard_normal(256).astype(np.float32) for _ in range(3))
+    res = h16(r.standard_normal((2, 256, 20, 23))) if with_res else None
+    kw = dict(bias=bias, pad=1, flags=flags, res=res)
+    if flags & nat.F_AFFINE:
+        kw.update(scale=sc, shift=sh)
+    outs = {cfg: gu.conv_op(ctx, x, Wt, cfg=cfg, **kw)[1] for cfg in (0, 1, 2, 3, 7, 60, 70, 71, 72)}
+    base = outs[0]
+    for cfg, o in outs.items():
+        assert np.array_equal(o.view(np.uint16), base.view(np.uint16)), f"cfg {cfg} differs from the heuristic's choice"
+
+
+def test_autotune_keeps_the_bytes(ctx):
+    """a whole generator before / after havc_net_autotune: identical raw colour"""
+    from tests.test_gpu_deoldify import make_frame, raw_gpu
+    from vsdeoldify_amd.render import GeneratorRuntime
+    from vsdeoldify_amd.synth import synth_state_dict
+    import os
+    frames = np.stack([make_frame(96, 3), make_frame(96, 4)])
+    outs = []
+    for tune in ("0", "1"):
+        os.environ["HAVC_AUTOTUNE"] = tune
+        try:
+            rt = GeneratorRuntime(ctx, synth_state_dict("wide", 1), "wide")
+            try:
+                net = rt.net(96, 2)
+                outs.append((raw_gpu(ctx, rt, frames), net.cfgs()))
+            finally:
+                rt.close()
+        finally:
+            os.environ.pop("HAVC_AUTOTUNE", None)
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert all(c == 0 for c in outs[0][1]) and any(c != 0 for c in outs[1][1])
+
+
 def test_conv_epilogue_relu_affine_residual(ctx):
     r = np.random.default_rng(1)
     x = h16(r.standard_normal((2, 72, 13, 15)))
@@ -143,7 +185,7 @@ def test_maxpool_blur_affine(ctx):
     assert_close(nchw(af), ref.numpy(), "affine+relu", 1e-3, 1e-3)
 
 
-@pytest.mark.parametrize("C,H,W,B", [(512, 6, 6, 1), (512, 13, 11, 2), (768, 9, 9, 1)])
+@pytest.mark.parametrize("C,H,W,B", [(512, 6, 6, 1), (512, 13, 11, 2), (768, 9, 9, 1), (512, 24, 23, 2), (768, 17, 19, 1), (256, 10, 10, 1)])
 def test_self_attention(ctx, C, H, W, B):
     """fastai SelfAttention (fastai/layers.py:81-96) via two 1x1 convs + the flash kernel."""
     from oracle import unet as ou

@@ -185,3 +185,51 @@ def test_ddcolor_plan_shapes_and_flops():
     assert len(consts) == 1 + 3 * 3                                                       # query_feat + per layer: q, kv, qkv maps
     for buf, arr, pitch, rows in consts:
         assert arr.shape[0] <= rows and arr.shape[1] <= pitch and np.isfinite(arr).all()
+
+
+def _sharded_clip_worker(rank, world, port, n, q):
+    import os
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vsdeoldify_amd import sharded
+    calls = []
+
+    def stub(t):                                     # a "colorizer" whose output identifies frame content AND the rank that ran it
+        calls.append(int(t.shape[0]))
+        return (255 - t) // 2 + rank
+    frames = None
+    if rank == 0:
+        r = np.random.default_rng(0)
+        frames = torch.from_numpy(r.integers(0, 256, (n, 6, 8, 3), dtype=np.uint8))
+    out = sharded.colorize_clip_sharded(frames, stub, dist, rank, world, "cpu")
+    if rank == 0:
+        want = torch.stack([(255 - frames[i]) // 2 + (i % world) for i in range(n)]) if n else frames
+        q.put((bool(torch.equal(out, want)), tuple(out.shape), calls))
+    else:
+        q.put((out is None, None, calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [7, 4, 1])
+def test_sharded_clip_runner_returns_the_clip_in_frame_order_gloo(n):
+    """world_size 2, gloo: ONE scatter + ONE gather, frame i coloured by rank i mod 2, result in frame order on rank 0 (odd clip
+    length, even, and fewer frames than ranks)."""
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    port = 29650 + n
+    ps = [ctxm.Process(target=_sharded_clip_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[0] for r in res), res
+    shapes = [r[1] for r in res if r[1] is not None]
+    assert shapes == [(n, 6, 8, 3)]
+    assert sorted(sum(r[2]) for r in res) == sorted([len(range(0, n, 2)), len(range(1, n, 2))])

@@ -77,6 +77,8 @@ SYMBOLS = [
     ("havc_net_download", _I, [_P, _I, _P, _SZ]),
     ("havc_net_run_ops", _I, [_P, _I, _I, _I]),
     ("havc_net_profile", _I, [_P, _I, _P, _I]),
+    ("havc_net_autotune", _I, [_P, _I, C.POINTER(_I)]),
+    ("havc_net_get_cfg", _I, [_P, _I]),
     ("havc_deoldify_frames", _I, [_P, _P, _P, _F, _I, _P, _P, _I]),
     ("havc_zhang_frames", _I, [_P, _P, _P, _P, _I, _I, _I]),
     ("havc_ddcolor_frames", _I, [_P, _P, _P, _P, _I, _I, _I]),
@@ -95,10 +97,19 @@ SYMBOLS = [
     ("havc_restore_color_gradient", _I, [_P, _P, _P, _P, _I, _I, _D, _I, _D, _D, _I, _I]),
     ("havc_colorize_clip", _I, [_P, _P, _P, _F, _P, _P, _I, _I, _I]),
     ("havc_spline64_resize", _I, [_P, _P, _I, _I, _P, _I, _I, _P]),
+    ("havc_spline64_resize_n", _I, [_P, _P, _I, _I, _P, _I, _I, _P, _I]),
+    ("havc_colorize_clip_host", _I, [_P, _P, _P, _F, _P, _P, _I, _I, _I]),
+    ("havc_host_alloc", _I, [_P, _SZ, C.POINTER(_P)]),
+    ("havc_host_free", _I, [_P, _P]),
+    ("havc_ddcolor_frame_planar_f", _I, [_P, _P, C.POINTER(_P), _I, C.POINTER(_P), _I, _I, _I, _I]),
+    ("havc_deoldify_frame_planar", _I, [_P, _P, _P, _F, _I, C.POINTER(_P), _I, C.POINTER(_P), _I]),
+    ("havc_planar_to_rgb8", _I, [_P, C.POINTER(_P), _I, _P, _I, _I]),
+    ("havc_rgb8_to_planar", _I, [_P, _P, C.POINTER(_P), _I, _I, _I]),
     ("havc_dev_alloc", _I, [_P, _SZ, C.POINTER(_P)]),
     ("havc_dev_free", _I, [_P, _P]),
     ("havc_dev_upload", _I, [_P, _P, _P, _SZ]),
     ("havc_dev_download", _I, [_P, _P, _P, _SZ]),
+    ("havc_dev_copy", _I, [_P, _P, _P, _SZ]),
     ("havc_tag_timing_enable", _I, [_P, _I, _I]),
     ("havc_tag_timing_read", _I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 ]
@@ -190,6 +201,23 @@ class Context:
         host = np.ascontiguousarray(host)
         check(self.lib.havc_dev_upload(self.h, d, as_ptr(host), host.nbytes), self.h)
 
+    def dev_copy(self, d_dst, d_src, nbytes):
+        check(self.lib.havc_dev_copy(self.h, d_dst, d_src, int(nbytes)), self.h)
+
+    def host_alloc(self, nbytes):
+        """pinned host memory as a uint8 numpy array (freed with host_free(arr))"""
+        p = C.c_void_p()
+        check(self.lib.havc_host_alloc(self.h, int(nbytes), C.byref(p)), self.h)
+        arr = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(int(nbytes),))
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[arr.ctypes.data] = p
+        return arr
+
+    def host_free(self, arr):
+        p = getattr(self, "_pinned", {}).pop(arr.ctypes.data, None)
+        if p is not None:
+            check(self.lib.havc_host_free(self.h, p), self.h)
+
     def dev_download(self, host, d):
         assert host.flags.c_contiguous
         check(self.lib.havc_dev_download(self.h, as_ptr(host), d, host.nbytes), self.h)
@@ -253,6 +281,18 @@ class Net:
 
     def run_rgb8_dev(self, d_in, d_out, batch):
         check(self.ctx.lib.havc_net_run_rgb8(self.h, d_in, d_out, batch), self.ctx.h)
+
+    def autotune(self, batch=None):
+        """measure the conv tile configurations once and keep the fastest per op (same bytes, only speed changes)"""
+        if getattr(self, "_tuned", False):
+            return 0
+        n = C.c_int(0)
+        check(self.ctx.lib.havc_net_autotune(self.h, int(batch or self.max_batch), C.byref(n)), self.ctx.h)
+        self._tuned = True
+        return n.value
+
+    def cfgs(self):
+        return [self.ctx.lib.havc_net_get_cfg(self.h, i) for i in range(len(self.ops))]
 
     def profile(self, batch=1):
         ms = np.zeros(len(self.ops), dtype=np.float32)

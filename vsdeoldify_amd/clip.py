@@ -47,6 +47,17 @@ class ClipColorizer:
         nat.check(self.ctx.lib.havc_colorize_clip(self.ctx.h, self.video.h, self.second.h if self.second else None,
                                                   self.video_weight, d_src, d_dst, n_frames, width, height), self.ctx.h)
 
+    def colorize_host(self, frames, out=None):
+        """uint8 [n,h,w,3] host array -> coloured host array through havc_colorize_clip_host: uploads, U-Net passes and downloads of
+        consecutive batches overlap on three streams.  Pass arrays living in pinned memory (ctx.host_alloc) for true async copies."""
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        n, h, w, _ = frames.shape
+        out = np.empty_like(frames) if out is None else out
+        assert out.shape == frames.shape and out.dtype == np.uint8 and out.flags.c_contiguous
+        nat.check(self.ctx.lib.havc_colorize_clip_host(self.ctx.h, self.video.h, self.second.h if self.second else None, self.video_weight,
+                                                       nat.as_ptr(frames), nat.as_ptr(out), n, w, h), self.ctx.h)
+        return out
+
     def colorize(self, frames):
         """uint8 [n,h,w,3] host array -> coloured uint8 [n,h,w,3] (H2D, device pipeline, D2H)."""
         frames = np.ascontiguousarray(frames, dtype=np.uint8)

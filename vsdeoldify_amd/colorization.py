@@ -52,6 +52,8 @@ class ModelColorization:
         ops, bufs, i, o, names = self.gen.plan(NET_SIZE)
         self.net = nat.Net(self.ctx, self.weights, ops, bufs, i, o, NET_SIZE, max_batch)
         self.net.names = names
+        if os.environ.get("HAVC_AUTOTUNE", "1") != "0":
+            self.net.autotune(max_batch)
 
     def close(self):
         if getattr(self, "net", None):

@@ -59,6 +59,26 @@ int launch_blend_u8(const uint8_t* a, const uint8_t* b, float w, uint8_t* out, i
     return (int)hipGetLastError();
 }
 
+// ---- frame_to_image / image_to_frame (vsslib/vsutils.py:60-110): three u8 planes [3][npix] <-> interleaved RGB ----
+__global__ void planar_to_rgb8_kernel(const uint8_t* __restrict__ planes, uint8_t* __restrict__ rgb, int64_t npix) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        rgb[i * 3] = planes[i]; rgb[i * 3 + 1] = planes[npix + i]; rgb[i * 3 + 2] = planes[2 * npix + i];
+    }
+}
+__global__ void rgb8_to_planar_kernel(const uint8_t* __restrict__ rgb, uint8_t* __restrict__ planes, int64_t npix) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        planes[i] = rgb[i * 3]; planes[npix + i] = rgb[i * 3 + 1]; planes[2 * npix + i] = rgb[i * 3 + 2];
+    }
+}
+int launch_planar_to_rgb8(const uint8_t* planes, uint8_t* rgb, int64_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(planar_to_rgb8_kernel, dim3(grid_for(npix)), dim3(256), 0, s, planes, rgb, npix);
+    return (int)hipGetLastError();
+}
+int launch_rgb8_to_planar(const uint8_t* rgb, uint8_t* planes, int64_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(rgb8_to_planar_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, planes, npix);
+    return (int)hipGetLastError();
+}
+
 // ---- chroma_post_process / ColorizerFilter._post_process: Y from orig, U,V from colour ----
 __global__ void yuv_merge_kernel(const uint8_t* __restrict__ color, const uint8_t* __restrict__ orig,
                                  uint8_t* __restrict__ out, int64_t npix) {

@@ -67,9 +67,12 @@ __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v a
     if (n >= p.Co) return;
     const int64_t mo = out_pixel(p, m, HoWo);
     if (p.flags & HAVC_F_RESIDUAL) {
+        // Same rounding points as the LDS epilogue of the pipelined kernels (conv_pipe_epilogue.inc): the conv result is rounded
+        // to fp16 BEFORE the residual is added (and once more after), so every tile configuration produces the same bytes and a
+        // frame colours identically whatever configuration the heuristic / autotuner picks for a batch size.
         const half4 rv = *reinterpret_cast<const half4*>(p.res + mo * p.res_cpitch + p.res_coff + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        for (int r = 0; r < 4; ++r) v[r] = (float)(half_t)v[r] + (float)rv[r];
     }
     if (p.flags & HAVC_F_RELU_POST) {
 #pragma unroll

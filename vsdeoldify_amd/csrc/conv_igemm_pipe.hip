@@ -537,6 +537,10 @@ int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
         case 70: return launch_pipe<2, 2, 4, 0>(a, s);        // 128 x 128, 4 waves
         case 71: return launch_pipe<1, 4, 8, 0>(a, s);        // 128 x 256, 4 waves
         case 72: return launch_pipe<1, 2, 4, 0>(a, s);        // 64 x 128, 2 waves
+        case 74: return launch_pipe<2, 2, 4, 0, 1>(a, s);     // ablations of cfg 70 (profiling only): no DMA in the loop
+        case 75: return launch_pipe<2, 2, 4, 0, 4>(a, s);     //   no MFMA
+        case 76: return launch_pipe<2, 2, 4, 0, 5>(a, s);     //   no epilogue
+        case 77: return launch_pipe<2, 2, 4, 0, 10>(a, s);    //   MFMA only (no fragment reads, no DMA, no barriers)
     }
     return (int)hipErrorInvalidValue;
 }

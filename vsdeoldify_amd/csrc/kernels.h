@@ -88,8 +88,11 @@ int launch_color_temporal_stabilizer(const uint8_t* const* frames, const double*
 // ddcolor.hip (+ the Lab wrapper kernels in zhang.hip)
 int launch_prep_ddcolor(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff, half_t* y2, int y2_cpitch, int y2_coff, int64_t npix,
                         hipStream_t s);
-int launch_ddcolor_post(const uint8_t* orig, const half_t* ab, int ab_cpitch, int ab_coff, int abH, int abW, uint8_t* out, int n_frames, int w,
-                        int h, hipStream_t s);
+int launch_ddcolor_post(const uint8_t* orig, const half_t* ab, int ab_cpitch, int ab_coff, int abH, int abW, uint8_t* out_u8, void* out_planes,
+                        int planes_half, int n_frames, int w, int h, hipStream_t s);
+int launch_planar_f_to_rgb8(const void* planes, int is_half, uint8_t* rgb, int64_t npix, hipStream_t s);
+int launch_planar_to_rgb8(const uint8_t* planes, uint8_t* rgb, int64_t npix, hipStream_t s);
+int launch_rgb8_to_planar(const uint8_t* rgb, uint8_t* planes, int64_t npix, hipStream_t s);
 int launch_dwconv7(const half_t* x, const half_t* w, const float* bias, half_t* y, int B, int H, int W, int C, int x_cpitch, int x_coff,
                    int y_cpitch, int y_coff, int w_pitch, hipStream_t s);
 int launch_layernorm_c(const half_t* x, half_t* y, const float* gamma, const float* beta, float eps, int64_t npix, int C, int x_cpitch,

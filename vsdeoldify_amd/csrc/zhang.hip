@@ -143,8 +143,11 @@ int launch_prep_ddcolor(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff,
 }
 // Lab(L of the original frame, ab from the network: fp16 NHWC channels 0, 1 at abH x abW, bilinear align_corners=False to the
 // frame size when that differs) -> RGB u8, truncating cast of clip(x, 0, 1) * 255
+// out_planes != NULL: the frame is written as three float (planes_half = 0) or half planes [3][h][w] in [0, 1] -- the RGBS / RGBH
+// shape vs-deoldify hands to / takes from vsddcolor.ddcolor (vsslib/vsmodels.py:353-363) -- instead of interleaved u8.
 __global__ void ddcolor_post_kernel(const uint8_t* __restrict__ orig, const half_t* __restrict__ ab, int ab_cpitch, int ab_coff, int abH,
-                                    int abW, uint8_t* __restrict__ out, int n_frames, int w, int h, float sh, float sw) {
+                                    int abW, uint8_t* __restrict__ out, void* __restrict__ out_planes, int planes_half, int n_frames, int w, int h,
+                                    float sh, float sw) {
     const int64_t total = (int64_t)n_frames * w * h;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % w), y = (int)((i / w) % h), f = (int)(i / ((int64_t)w * h));
@@ -167,13 +170,40 @@ __global__ void ddcolor_post_kernel(const uint8_t* __restrict__ orig, const half
         }
         double r, g, b;
         lab_to_rgb01(L, (double)a, (double)bb, r, g, b);
-        out[i * 3] = (uint8_t)(int)(r * 255.0); out[i * 3 + 1] = (uint8_t)(int)(g * 255.0); out[i * 3 + 2] = (uint8_t)(int)(b * 255.0);
+        if (out_planes) {
+            const int64_t plane = (int64_t)w * h, o = (int64_t)f * 3 * plane + (int64_t)y * w + x;
+            if (planes_half) {
+                half_t* q = reinterpret_cast<half_t*>(out_planes);
+                q[o] = (half_t)(float)r; q[o + plane] = (half_t)(float)g; q[o + 2 * plane] = (half_t)(float)b;
+            } else {
+                float* q = reinterpret_cast<float*>(out_planes);
+                q[o] = (float)r; q[o + plane] = (float)g; q[o + 2 * plane] = (float)b;
+            }
+        } else {
+            out[i * 3] = (uint8_t)(int)(r * 255.0); out[i * 3 + 1] = (uint8_t)(int)(g * 255.0); out[i * 3 + 2] = (uint8_t)(int)(b * 255.0);
+        }
     }
 }
-int launch_ddcolor_post(const uint8_t* orig, const half_t* ab, int ab_cpitch, int ab_coff, int abH, int abW, uint8_t* out, int n_frames, int w,
-                        int h, hipStream_t s) {
-    hipLaunchKernelGGL(ddcolor_post_kernel, dim3(grid_for((int64_t)n_frames * w * h)), dim3(256), 0, s, orig, ab, ab_cpitch, ab_coff, abH, abW, out,
-                       n_frames, w, h, (float)abH / (float)h, (float)abW / (float)w);
+int launch_ddcolor_post(const uint8_t* orig, const half_t* ab, int ab_cpitch, int ab_coff, int abH, int abW, uint8_t* out_u8, void* out_planes,
+                        int planes_half, int n_frames, int w, int h, hipStream_t s) {
+    hipLaunchKernelGGL(ddcolor_post_kernel, dim3(grid_for((int64_t)n_frames * w * h)), dim3(256), 0, s, orig, ab, ab_cpitch, ab_coff, abH, abW, out_u8,
+                       out_planes, planes_half, n_frames, w, h, (float)abH / (float)h, (float)abW / (float)w);
+    return (int)hipGetLastError();
+}
+
+// RGBS / RGBH planes in [0, 1] (full range, cast from RGB24 by zimg: exactly k / 255) -> interleaved u8: round to nearest, clamped
+__global__ void planar_f_to_rgb8_kernel(const void* __restrict__ planes, int is_half, uint8_t* __restrict__ rgb, int64_t npix) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const float v = is_half ? (float)reinterpret_cast<const half_t*>(planes)[p * npix + i] : reinterpret_cast<const float*>(planes)[p * npix + i];
+            const float q = floorf(fminf(fmaxf(v, 0.f), 1.f) * 255.f + 0.5f);
+            rgb[i * 3 + p] = (uint8_t)(int)q;
+        }
+    }
+}
+int launch_planar_f_to_rgb8(const void* planes, int is_half, uint8_t* rgb, int64_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(planar_f_to_rgb8_kernel, dim3(grid_for(npix)), dim3(256), 0, s, planes, is_half, rgb, npix);
     return (int)hipGetLastError();
 }
 

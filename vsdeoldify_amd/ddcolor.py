@@ -4,6 +4,8 @@ PARITY UNPINNED (external wheel, not in the reference tree; oracle/ddcolor.py). 
 u8 HWC frames; the network runs at input_size = trunc(render_factor / 2) * 32 (vsmodels.py:302) and frames of another size are
 squashed / the ab map stretched back inside the library.  The RGBH / RGBS <-> RGB24 casts around the call stay in VapourSynth.  No CPU fallback: everything runs through libhavc_mi355.
 """
+import os
+
 import numpy as np
 
 from . import _native as nat
@@ -30,20 +32,43 @@ class DDColorRuntime:
                 a = np.zeros((max_batch, rows_per_frame, pitch), np.float16)
                 a[:, :arr.shape[0], :arr.shape[1]] = arr.astype(np.float16)[None]
                 n.upload(buf, a)
+            if os.environ.get("HAVC_AUTOTUNE", "1") != "0":
+                n.autotune(max_batch)
             self.nets[key] = n
         return self.nets[key]
 
-    def colorize(self, frames, input_size=None):
+    def colorize(self, frames, input_size=None, max_batch=None):
         """frames: uint8 [N, H, W, 3] -> uint8 [N, H, W, 3]; the network runs at input_size (default: the frame size, which
         must then be square and a multiple of 32)."""
-        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        from .device import is_device, operand_ptr
+        dev = is_device(frames)
+        if not dev:
+            frames = np.ascontiguousarray(frames, dtype=np.uint8)
         assert frames.ndim == 4 and frames.shape[3] == 3
         S = frames.shape[1] if input_size is None else input_size
         assert S % 32 == 0 and (input_size is not None or frames.shape[1] == frames.shape[2])
-        net = self.net(S, min(len(frames), 8))
-        out = np.empty_like(frames)
-        nat.check(self.ctx.lib.havc_ddcolor_frames(self.ctx.h, net.h, nat.as_ptr(frames), nat.as_ptr(out), len(frames), frames.shape[2],
+        n = frames.shape[0]
+        net = self.net(S, max_batch or min(n, 8))
+        out = frames.empty_like() if dev else np.empty_like(frames)
+        nat.check(self.ctx.lib.havc_ddcolor_frames(self.ctx.h, net.h, operand_ptr(frames), operand_ptr(out), n, frames.shape[2],
                                                    frames.shape[1]), self.ctx.h)
+        return out
+
+    def colorize_planar_float(self, planes, input_size=None):
+        """The call shape of vsddcolor.ddcolor as vs-deoldify uses it (vsslib/vsmodels.py:353-363): ONE frame as float32 (RGBS)
+        or float16 (RGBH) planes [3, H, W] in [0, 1] -> planes of the same dtype, not quantised."""
+        import ctypes as C
+        planes = np.ascontiguousarray(planes)
+        if planes.ndim != 3 or planes.shape[0] != 3 or planes.dtype not in (np.float32, np.float16):
+            raise ValueError("ddcolor: RGBS / RGBH frame = float32 / float16 array [3, H, W]")
+        h, w = planes.shape[1:]
+        S = h if input_size is None else input_size
+        net = self.net(S, 1)
+        out = np.empty_like(planes)
+        esz = planes.dtype.itemsize
+        pin = (C.c_void_p * 3)(*[planes[p].ctypes.data for p in range(3)])
+        pout = (C.c_void_p * 3)(*[out[p].ctypes.data for p in range(3)])
+        nat.check(self.ctx.lib.havc_ddcolor_frame_planar_f(self.ctx.h, net.h, pin, w * esz, pout, w * esz, 1 if esz == 2 else 0, w, h), self.ctx.h)
         return out
 
     def close(self):
@@ -83,7 +108,19 @@ class DDColorRender:
 
     def colorize_frame(self, frame):
         """u8 HWC in -> u8 HWC out, any frame size (the network runs at input_size)."""
+        from .device import is_device
+        if is_device(frame):
+            if frame.ndim != 3:
+                raise ValueError("ddcolor: frame must be HWC RGB")
+            return self.rt.colorize(frame.reshaped((1,) + frame.shape), self.input_size).reshaped(frame.shape)
         f = np.asarray(frame)
         if f.ndim != 3 or f.shape[2] != 3:
             raise ValueError("ddcolor: frame must be HWC RGB")
         return self.rt.colorize(f[None], self.input_size)[0]
+
+    def colorize_frames(self, frames, max_batch=None):
+        """[N, H, W, 3] u8 (ndarray or DeviceImage) -> same kind"""
+        return self.rt.colorize(frames, self.input_size, max_batch)
+
+    def colorize_planar_float(self, planes):
+        return self.rt.colorize_planar_float(planes, self.input_size)

@@ -32,6 +32,39 @@ class DeoldifyGenerator:
         self.blob = self.pack.blob()
         self._frozen = True
 
+    # ---- offline conversion: packed blob + packing table on disk ---------------------------------
+    FORMAT = "havc-deoldify-blob/1"
+
+    def save(self, path):
+        """Write the packed model: everything havc_weights_load / plan() need, nothing of the fp32 state dict.  One
+        uncompressed .npz: `blob` (the device image, byte for byte), `meta` (JSON: arch, fusion flags, the offset table of
+        every packed conv / vector, and the state-dict SHAPES the plan emitter looks at plus the attention gammas)."""
+        import json
+        from dataclasses import asdict
+        meta = {"format": self.FORMAT, "arch": self.arch, "fuse_final": self.fuse_final, "fuse_blur": self.fuse_blur,
+                "convs": {k: asdict(v) for k, v in self._pc.items()}, "vecs": {k: list(v) for k, v in self._vec.items()},
+                "shapes": {k: list(v.shape) for k, v in self.sd.items()},
+                "scalars": {k: float(v.reshape(-1)[0]) for k, v in self.sd.items() if k.endswith(".gamma")}}
+        with open(path, "wb") as f:
+            np.savez(f, blob=np.frombuffer(self.blob, dtype=np.uint8), meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8))
+
+    @classmethod
+    def load(cls, path):
+        """Inverse of save(): no packing work, the plan emitter runs on a shape-only skeleton of the state dict."""
+        import json
+        from .plan import PackedConv
+        z = np.load(path)
+        meta = json.loads(bytes(z["meta"]).decode())
+        if meta.get("format") != cls.FORMAT:
+            raise ValueError(f"{path}: not a {cls.FORMAT} file")
+        g = cls.__new__(cls)
+        g.arch, g.fuse_final, g.fuse_blur = meta["arch"], meta["fuse_final"], meta["fuse_blur"]
+        g.sd = {k: np.broadcast_to(np.float32(meta["scalars"].get(k, 0.0)), tuple(shp)) for k, shp in meta["shapes"].items()}
+        g._pc = {k: PackedConv(**v) for k, v in meta["convs"].items()}
+        g._vec = {k: tuple(v) for k, v in meta["vecs"].items()}
+        g.pack, g.blob, g._frozen = None, z["blob"].tobytes(), True
+        return g
+
     # ---- cached packing helpers -------------------------------------------------------------
     def _conv(self, key, fn):
         if key not in self._pc:

@@ -1,0 +1,131 @@
+"""Images that stay in HBM between filters.
+
+Every frame / filter entry point of libhavc_mi355 takes host OR device pointers per operand (include/havc_mi355.h,
+"Pointers").  `DeviceImage` is the Python handle of a device operand: a uint8 [h, w, 3] frame or an [n, h, w, 3] stack in the
+memory of one ctx's GPU.  The numpy-facing wrappers of imfilters.py / mcomb.py / render.py / ddcolor.py accept a DeviceImage
+wherever they accept an ndarray and then return a DeviceImage: a whole HAVC merge graph (squash -> DeOldify -> DDColor ->
+merge method -> up-sample + luma) composes without a single PCIe hop, and nothing blocks until `.numpy()` is called.
+
+Allocation goes through a per-context free list (`hipMalloc` / `hipFree` synchronise the device): a buffer released by
+`__del__` is handed to the next request of the same size.  All work of a ctx is ordered on its one stream, so recycling a
+buffer behind work that is still queued is safe.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+
+_pools = {}          # id(ctx) -> {nbytes: [ptr, ...]}
+
+
+def _pool(ctx):
+    return _pools.setdefault(id(ctx), {})
+
+
+def pool_alloc(ctx, nbytes):
+    free = _pool(ctx).get(nbytes)
+    if free:
+        return free.pop()
+    return ctx.dev_alloc(nbytes)
+
+
+def pool_release(ctx, ptr, nbytes):
+    _pool(ctx).setdefault(nbytes, []).append(ptr)
+
+
+def pool_trim(ctx):
+    """give every cached buffer of this ctx back to the driver"""
+    for lst in _pool(ctx).values():
+        while lst:
+            ctx.dev_free(lst.pop())
+
+
+class DeviceImage:
+    """uint8 image(s) in HBM: shape (h, w, 3) or (n, h, w, 3), C-contiguous, interleaved RGB."""
+
+    def __init__(self, ctx, shape, ptr=None, owner=None):
+        shape = tuple(int(s) for s in shape)
+        if len(shape) not in (3, 4) or shape[-1] != 3:
+            raise ValueError("DeviceImage: shape must be (h, w, 3) or (n, h, w, 3)")
+        self.ctx, self.shape = ctx, shape
+        self.nbytes = int(np.prod(shape))
+        self._owner = owner                       # a view keeps its parent alive
+        self._own = ptr is None
+        self.ptr = pool_alloc(ctx, self.nbytes) if ptr is None else ptr
+
+    def __del__(self):
+        try:
+            if self._own and self.ptr is not None and self.ctx.h:
+                pool_release(self.ctx, self.ptr, self.nbytes)
+        except Exception:
+            pass
+        self.ptr = None
+
+    # ---- host <-> device ----
+    @classmethod
+    def from_numpy(cls, ctx, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint8)
+        d = cls(ctx, arr.shape)
+        ctx.dev_upload(d.ptr, arr)
+        return d
+
+    def numpy(self):
+        out = np.empty(self.shape, np.uint8)
+        self.ctx.dev_download(out, self.ptr)        # orders behind everything queued on the ctx stream
+        return out
+
+    # ---- geometry ----
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def n_frames(self):
+        return self.shape[0] if len(self.shape) == 4 else 1
+
+    @property
+    def frame_shape(self):
+        return self.shape[-3:]
+
+    def frame(self, i):
+        """view of frame i of a stack (no copy)"""
+        if len(self.shape) != 4 or not 0 <= i < self.shape[0]:
+            raise IndexError(i)
+        fb = int(np.prod(self.shape[1:]))
+        return DeviceImage(self.ctx, self.shape[1:], C.c_void_p(self.ptr.value + i * fb), owner=self)
+
+    def frames(self, lo, hi):
+        fb = int(np.prod(self.shape[1:]))
+        return DeviceImage(self.ctx, (hi - lo,) + self.shape[1:], C.c_void_p(self.ptr.value + lo * fb), owner=self)
+
+    def as_rows(self):
+        """(n, h, w, 3) seen as ONE (n*h, w, 3) image: valid operand of every purely per-pixel filter"""
+        if len(self.shape) == 3:
+            return self
+        n, h, w, _ = self.shape
+        return DeviceImage(self.ctx, (n * h, w, 3), self.ptr, owner=self)
+
+    def reshaped(self, shape):
+        if int(np.prod(shape)) != self.nbytes:
+            raise ValueError("reshape changes the size")
+        return DeviceImage(self.ctx, shape, self.ptr, owner=self)
+
+    def empty_like(self):
+        return DeviceImage(self.ctx, self.shape)
+
+    def copy_from(self, other):
+        """device -> device copy (enqueued on the ctx stream)"""
+        if other.nbytes != self.nbytes:
+            raise ValueError("size mismatch")
+        self.ctx.dev_copy(self.ptr, other.ptr, self.nbytes)
+        return self
+
+
+def is_device(x):
+    return isinstance(x, DeviceImage)
+
+
+def operand_ptr(x):
+    """ctypes pointer of an ndarray / DeviceImage operand"""
+    return x.ptr if isinstance(x, DeviceImage) else nat.as_ptr(x)

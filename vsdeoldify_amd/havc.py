@@ -1,12 +1,20 @@
-"""`HAVC_colorizer` without VapourSynth: the parameter normalisation, frame-size rule, model routing and
-combine-method dispatch of vsdeoldify/__init__.py:2290-2523 and vsslib/mcomb.py:125-192, applied to one uint8 HWC frame at a time
-and executed on the MI355X.  This is the harness counterpart of the VapourSynth graph the reference assembles; what only
-VapourSynth can do stays there and is refused here instead of being approximated: `vs_tweak` (deoldify / ddcolor sat / hue other than
-1 / 0, `luma_mask_sat` < 1), scene detection, the DDColor pre-tweaks.  zimg's Spline64 is replaced by the library's own Spline64
-(outside the parity contract).
+"""The public HAVC entry points without VapourSynth, executed on the MI355X:
 
-    col = HAVCFrameColorizer(method=2, mweight=0.4, package_dir=..., ddcolor_model_dir=...)
-    out = col.colorize(frame)            # frame: uint8 [H, W, 3], any size; out has the same size
+    HAVC_colorizer   vsdeoldify/__init__.py:2290-2523     HAVC_merge       vsdeoldify/__init__.py:2536-2675
+    HAVC_ddeoldify   vsdeoldify/__init__.py:3612-3628     ddeoldify        vsdeoldify/__init__.py:3642-3653
+
+Same names, argument lists, defaults, parameter normalisation, frame-size rule, model routing, combine dispatch
+(vsslib/mcomb.py:125-192) and error texts; a "clip" is a uint8 array [n, h, w, 3] (or one frame [h, w, 3], or a
+`device.DeviceImage` of either shape: then the whole graph runs without leaving HBM).  `HAVCFrameColorizer` is the object
+behind `HAVC_colorizer` (models and nets are built once and reused between calls).
+
+What only VapourSynth can do stays there and is REFUSED here instead of being approximated: `vs_tweak` (deoldify / ddcolor
+sat / hue other than 1 / 0, `luma_mask_sat` < 1), scene detection (`sc_threshold` > 0, `sc_min_freq` > 0), the DDColor
+pre-tweaks (`ddtweak`), non-RGB24 formats.  zimg's Spline64 is replaced by the library's own Spline64 (outside the parity
+contract).
+
+    out = HAVC_colorizer(clip, method=2, mweight=0.4, torch_dir=..., ...)          # clip: uint8 [n, 1080, 1920, 3]
+    col = HAVCFrameColorizer(method=2, mweight=0.4, package_dir=...); out = col.colorize(frame)
 """
 import math
 
@@ -15,23 +23,41 @@ import numpy as np
 from . import _native as nat
 from . import imfilters as F
 from . import mcomb
+from .device import DeviceImage, is_device
 from .render import get_context
 
 DEF_CMC_p = [0.15, True, 20, 24]            # vsslib/constants.py:19-22
 DEF_LMM_p = [0.15, 0.65, 1.0]
 DEF_ALM_p = [0.8, 1.0, 0.15]
 DEF_CRT_p = [0.8, 30, 2, False, 0, 0]
-DEF_STABLE_WEIGHT = DEF_ARTISTIC_WEIGHT = 0.5  # deoldify/constants? vsslib/constants.py:56-57
+DEF_TWEAK_p = [0.0, 0.9, 0.7, False, 0.3, 0.6, 1.5, 0.5]
+DEF_THT_WHITE, DEF_THT_BLACK = 0.88, 0.12
+DEF_STABLE_WEIGHT = DEF_ARTISTIC_WEIGHT = 0.5  # vsslib/constants.py:56-57
 
 
 class HAVCError(ValueError):
     """what the reference raises as vs.Error / HAVC_LogMessage(EXCEPTION)"""
 
 
+def _as_clip(x):
+    """-> (4-D operand, was_single_frame)"""
+    if is_device(x):
+        return (x, False) if x.ndim == 4 else (x.reshaped((1,) + x.shape), True)
+    a = np.ascontiguousarray(x, dtype=np.uint8)
+    if a.ndim == 3:
+        a, single = a[None], True
+    else:
+        single = False
+    if a.ndim != 4 or a.shape[3] != 3:
+        raise HAVCError("HAVC: only RGB24 clips (uint8 [n, h, w, 3]) are supported")
+    return a, single
+
+
 class HAVCFrameColorizer:
     def __init__(self, method=2, mweight=0.4, deoldify_p=(0, 24, 1.0, 0.0), ddcolor_p=(1, 24, 1.0, 0.0, True), cmc_p=DEF_CMC_p,
                  lmm_p=DEF_LMM_p, alm_p=DEF_ALM_p, crt_p=DEF_CRT_p, cmb_sw=False, device_index=0, package_dir=None,
-                 ddcolor_model_dir=None, state_dicts=None, ddcolor_state_dict=None, zhang_state_dict=None):
+                 ddcolor_model_dir=None, state_dicts=None, ddcolor_state_dict=None, zhang_state_dict=None, max_batch=1,
+                 ddcolor_kwargs=None):
         # ---- __init__.py:2452-2462: method <-> merge weight normalisation ----
         merge_weight = 0.0 if method == 0 else (1.0 if method == 1 else mweight)
         if merge_weight == 0.0:
@@ -53,9 +79,11 @@ class HAVCFrameColorizer:
         if method == 4 and self.lmm_p[2] < 1:
             raise NotImplementedError("luma_mask_sat < 1 uses vs_tweak (VapourSynth): not in this harness")
         self.device_index, self.ctx = device_index, get_context(device_index)
+        self.max_batch = max_batch
         self._package_dir, self._dd_dir = package_dir, ddcolor_model_dir
         self._sds, self._dd_sd, self._zh_sd = state_dicts, ddcolor_state_dict, zhang_state_dict
-        self._deoldify = self._ddcolor = None
+        self._dd_kwargs = dict(ddcolor_kwargs or {})
+        self._deoldify = self._ddcolor = self._zhang = None
         self._dd_size = None
 
     # ---- model routing: vsslib/vsmodels.py:196-213 (deoldify), :290-350 (ddcolor / zhang) ----
@@ -64,19 +92,24 @@ class HAVCFrameColorizer:
             from .render import ModelImageRender
             name, w = {0: ("video", 0), 1: ("stable", DEF_STABLE_WEIGHT), 2: ("artistic", DEF_ARTISTIC_WEIGHT)}.get(self.deoldify_model, ("video", 0))
             self._deoldify = ModelImageRender(self._package_dir, name, self.deoldify_rf, video_weight=w, device_index=self.device_index,
-                                              state_dicts=self._sds)
+                                              state_dicts=self._sds, max_batch=self.max_batch)
         return self._deoldify
 
-    def _ddcolor_frame(self, sq, input_size):
+    def _ddcolor_clip(self, sq, input_size):
+        """sq: [n, fs, fs, 3] ndarray or DeviceImage -> same kind"""
         if self.ddcolor_model in (0, 1):
             if self._ddcolor is None or self._dd_size != input_size:
                 from .ddcolor import DDColorRender
-                self._ddcolor = DDColorRender(self.ddcolor_model, input_size, self.device_index, state_dict=self._dd_sd, model_dir=self._dd_dir)
+                self._ddcolor = DDColorRender(self.ddcolor_model, input_size, self.device_index, state_dict=self._dd_sd, model_dir=self._dd_dir,
+                                              **self._dd_kwargs)
                 self._dd_size = input_size
-            return self._ddcolor.colorize_frame(sq)
+            return self._ddcolor.colorize_frames(sq, max_batch=self.max_batch)
         from .colorization import ModelColorization                                               # vsmodels.py:346-350
-        mc = ModelColorization("siggraph17" if self.ddcolor_model == 2 else "eccv16", True, self.device_index, state_dict=self._zh_sd)
-        return mc.colorize_frame(sq)
+        if self._zhang is None:
+            self._zhang = ModelColorization("siggraph17" if self.ddcolor_model == 2 else "eccv16", True, self.device_index, state_dict=self._zh_sd)
+        host = sq.numpy() if is_device(sq) else sq
+        out = np.stack([self._zhang.colorize_frame(f) for f in host])
+        return DeviceImage.from_numpy(self.ctx, out) if is_device(sq) else out
 
     def frame_size(self, width):
         """__init__.py:2490-2502."""
@@ -84,52 +117,205 @@ class HAVCFrameColorizer:
         return dd_rf, min(max(dd_rf, self.deoldify_rf) * 16, width)
 
     def _spline64(self, img, w, h, luma_from=None):
-        img = np.ascontiguousarray(img, dtype=np.uint8)
-        out = np.empty((h, w, 3), np.uint8)
-        lf = None if luma_from is None else np.ascontiguousarray(luma_from, dtype=np.uint8)
-        nat.check(self.ctx.lib.havc_spline64_resize(self.ctx.h, nat.as_ptr(img), img.shape[1], img.shape[0], nat.as_ptr(out), w, h,
-                                                    nat.as_ptr(lf) if lf is not None else None), self.ctx.h)
-        return out
+        return spline64(self.ctx, img, w, h, luma_from)
 
     # ---- vsslib/mcomb.py:125-192 ----
     def _combine(self, a, b):
-        if self.cmb_sw:
-            a, b = b, a
-        if a is None or b is None:
-            return a if b is None else b
-        m, w = self.method, self.merge_weight
-        di = self.device_index
-        if m == 2:
-            return mcomb.simple_merge(a, b, w, di)
-        if m == 3:
-            ccm = mcomb.constrained_chroma_merge(a, b, w, self.cmc_p[0], self.cmc_p[1] if len(self.cmc_p) > 1 else True, di)
-            mm = mcomb.simple_merge(a, b, min(w, 0.6), di)
-            return mcomb.simple_merge(ccm, mm, 0.3, di)
-        if m == 4:
-            return mcomb.luma_masked_merge(a, b, None, self.lmm_p[0], self.lmm_p[1], w, di)
-        if m == 5:
-            return mcomb.adaptive_luma_merge(a, b, self.alm_p[0], self.alm_p[1], w, self.alm_p[2], di)
-        if m == 6:
-            if self.crt_p[3]:
-                raise NotImplementedError("ChromaRetentionMerge(chroma_resize=True) is a VapourSynth-level resize round trip")
-            restored = mcomb.chroma_retention_frame(a, b, self.crt_p[0], self.crt_p[1], self.crt_p[4], self.crt_p[2], False, self.crt_p[5], di)
-            return mcomb.simple_merge(a, restored, w, di)             # vs_simple_merge = std.Merge in the reference (VapourSynth core)
-        big = len(self.cmc_p) > 1
-        return mcomb.chroma_bound_adaptive_merge(a, b, self.cmc_p[1] if big else True, self.cmc_p[2] if big else 20, self.cmc_p[3] if big else 24, w, di)
+        return combine_models(a, b, self.method, self.merge_weight, self.cmc_p, self.lmm_p, self.alm_p, self.crt_p, self.cmb_sw, self.device_index)
 
-    def colorize(self, frame):
-        """one frame through HAVC_colorizer's graph: squash -> deoldify / ddcolor -> combine -> Spline64 back + luma of the source"""
-        from PIL import Image
-        frame = np.ascontiguousarray(frame, dtype=np.uint8)
-        if frame.ndim != 3 or frame.shape[2] != 3:
-            raise HAVCError("HAVC_colorizer: only RGB24 frames")
-        h, w = frame.shape[:2]
+    def colorize_clip(self, clip):
+        """HAVC_colorizer's graph on a clip: Spline64 squash -> deoldify / ddcolor -> combine -> Spline64 back + luma of the source
+        (_clip_chroma_resize, __init__.py:3545-3554).  ndarray in -> ndarray out; DeviceImage in -> DeviceImage out (nothing leaves
+        HBM; frames go through the models in batches of max_batch)."""
+        clip, single = _as_clip(clip)
+        n, h, w, _ = clip.shape
         dd_rf, fs = self.frame_size(w)
-        sq = frame if (w, h) == (fs, fs) else self._spline64(frame, fs, fs)
+        host_in = not is_device(clip)
+        dclip = DeviceImage.from_numpy(self.ctx, clip) if host_in else clip
+        sq = dclip if (w, h) == (fs, fs) else self._spline64(dclip, fs, fs)
         a = b = None
         if self.method != 1:
-            a = np.asarray(self._deoldify_render().get_transformed_image(Image.fromarray(sq)))
+            a = self._deoldify_render().render_square_batch(sq)
         if self.method != 0:
-            b = self._ddcolor_frame(sq, math.trunc(dd_rf / 2) * 32)                               # vsmodels.py:302
+            b = self._ddcolor_clip(sq, math.trunc(dd_rf / 2) * 32)                               # vsmodels.py:302
         col = self._combine(a, b)
-        return self._spline64(col, w, h, luma_from=frame)                                         # _clip_chroma_resize, __init__.py:3545-3554
+        out = self._spline64(col, w, h, luma_from=dclip)
+        if host_in:
+            out = out.numpy()
+        return (out[0] if host_in else out.reshaped(out.shape[1:])) if single else out
+
+    def colorize(self, frame):
+        """one uint8 [h, w, 3] frame (or a clip) through the graph"""
+        return self.colorize_clip(frame)
+
+    __call__ = colorize_clip
+
+
+def spline64(ctx, img, w, h, luma_from=None):
+    """the harness stand-in of `resize.Spline64` (+ vs_recover_clip_luma when luma_from is given) on frames or clips,
+    host or device operands"""
+    import ctypes as C
+    dev = is_device(img) or is_device(luma_from)
+    if dev:
+        img = img if is_device(img) else DeviceImage.from_numpy(ctx, img)
+        if luma_from is not None and not is_device(luma_from):
+            luma_from = DeviceImage.from_numpy(ctx, luma_from)
+    else:
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        luma_from = None if luma_from is None else np.ascontiguousarray(luma_from, dtype=np.uint8)
+    n = img.shape[0] if img.ndim == 4 else 1
+    sh, sw = img.shape[-3], img.shape[-2]
+    shape = ((n, h, w, 3) if img.ndim == 4 else (h, w, 3))
+    if luma_from is not None and tuple(luma_from.shape) != shape:
+        raise ValueError("luma_from must have the output shape")
+    out = DeviceImage(ctx, shape) if dev else np.empty(shape, np.uint8)
+    from .device import operand_ptr
+    nat.check(ctx.lib.havc_spline64_resize_n(ctx.h, operand_ptr(img), sw, sh, operand_ptr(out), w, h,
+                                             operand_ptr(luma_from) if luma_from is not None else None, n), ctx.h)
+    return out
+
+
+def _per_frame(fn, *clips):
+    """apply a frame-level function (frame statistics / neighbourhoods inside) to every frame of 4-D operands"""
+    first = clips[0]
+    n = first.shape[0]
+    if is_device(first):
+        out = first.empty_like()
+        for i in range(n):
+            out.frame(i).copy_from(fn(*[c.frame(i) for c in clips]))
+        return out
+    return np.stack([np.asarray(fn(*[c[i] for c in clips])) for i in range(n)])
+
+
+def combine_models(a, b, method, w, cmc_p=DEF_CMC_p, lmm_p=DEF_LMM_p, alm_p=DEF_ALM_p, crt_p=DEF_CRT_p, invert_clips=False, device_index=0):
+    """vs_sc_combine_models (vsslib/mcomb.py:125-192) on clips [n, h, w, 3] (ndarray or DeviceImage); sat / hue tweaks refused
+    by the callers.  Purely per-pixel methods run on the whole stack in one launch, methods with frame-level decisions (mean
+    luma, Laplacian) frame by frame."""
+    if invert_clips:
+        a, b = b, a
+    if a is None or b is None:
+        return a if b is None else b
+    di = device_index
+    big = len(cmc_p) > 1
+    red_fix = cmc_p[1] if big else True
+    rows = (lambda x: x.as_rows()) if is_device(a) else (lambda x: x.reshape((-1,) + x.shape[2:]))
+    unrows = (lambda x: x.reshaped(a.shape)) if is_device(a) else (lambda x: x.reshape(a.shape))
+    if method == 2:
+        return unrows(mcomb.simple_merge(rows(a), rows(b), w, di))
+    if method == 3:
+        ccm = _per_frame(lambda x, y: mcomb.constrained_chroma_merge(x, y, w, cmc_p[0], red_fix, di), a, b)
+        mm = mcomb.simple_merge(rows(a), rows(b), min(w, 0.6), di)
+        return unrows(mcomb.simple_merge(rows(ccm), mm, 0.3, di))
+    if method == 4:
+        return unrows(mcomb.luma_masked_merge(rows(a), rows(b), None, lmm_p[0], lmm_p[1], w, di))
+    if method == 5:
+        return _per_frame(lambda x, y: mcomb.adaptive_luma_merge(x, y, alm_p[0], alm_p[1], w, alm_p[2], di), a, b)
+    if method == 6:
+        if crt_p[3]:
+            raise NotImplementedError("ChromaRetentionMerge(chroma_resize=True) is a VapourSynth-level resize round trip")
+        restored = _per_frame(lambda x, y: mcomb.chroma_retention_frame(x, y, crt_p[0], crt_p[1], crt_p[4], crt_p[2], False, crt_p[5], di), a, b)
+        return unrows(mcomb.simple_merge(rows(a), rows(restored), w, di))   # vs_simple_merge = std.Merge in the reference (VapourSynth core)
+    if method == 7:
+        return _per_frame(lambda x, y: mcomb.chroma_bound_adaptive_merge(x, y, red_fix, cmc_p[2] if big else 20, cmc_p[3] if big else 24, w, di), a, b)
+    raise HAVCError("HAVC: only dd_method in (0,6) is supported")
+
+
+# ======================================================================================================================
+# function-shaped API (argument lists of the reference)
+# ======================================================================================================================
+_colorizers = {}
+
+
+def _refuse_vs_only(ddtweak, sc_threshold, sc_min_freq):
+    flags = list(ddtweak) if isinstance(ddtweak, (list, tuple)) else [ddtweak]
+    if any(bool(f) for f in flags):
+        raise NotImplementedError("ddtweak (vs_sc_tweak / vs_auto_levels pre-tweaks, denoise) is VapourSynth glue: not in this harness")
+    if sc_threshold and sc_threshold > 0 or sc_min_freq and sc_min_freq > 0:
+        raise NotImplementedError("scene detection (sc_threshold / sc_min_freq) is VapourSynth glue (SCDetect): not in this harness")
+
+
+def HAVC_colorizer(clip, method=2, mweight=0.4, deoldify_p=(0, 24, 1.0, 0.0), ddcolor_p=(1, 24, 1.0, 0.0, True), ddtweak=(False, False, False),
+                   ddtweak_p=(DEF_TWEAK_p, "300:360|0.8,0.1"), cmc_p=DEF_CMC_p, lmm_p=DEF_LMM_p, alm_p=DEF_ALM_p, crt_p=DEF_CRT_p, cmb_sw=False,
+                   sc_threshold=0.0, sc_tht_offset=1, sc_min_freq=0, sc_tht_ssim=0.0, sc_normalize=False, sc_min_int=1, sc_tht_white=DEF_THT_WHITE,
+                   sc_tht_black=DEF_THT_BLACK, device_index=0, torch_dir=None, debug_level=0, **harness):
+    """vsdeoldify/__init__.py:2290-2298.  `harness` = keyword-only extras of this library: state_dicts / ddcolor_state_dict /
+    zhang_state_dict (seeded weights instead of files under torch_dir), ddcolor_model_dir, max_batch, ddcolor_kwargs."""
+    if clip is None or not (is_device(clip) or isinstance(clip, np.ndarray)):
+        raise HAVCError("HAVC_colorizer: this is not a clip")                                     # __init__.py:2437-2438
+    _refuse_vs_only(ddtweak, sc_threshold, sc_min_freq)
+    cmc = list(cmc_p) if isinstance(cmc_p, (list, tuple)) else [cmc_p]
+    key = (method, mweight, tuple(deoldify_p), tuple(ddcolor_p), tuple(cmc), tuple(lmm_p), tuple(alm_p), tuple(crt_p), cmb_sw, device_index,
+           torch_dir, id(harness.get("state_dicts")), id(harness.get("ddcolor_state_dict")), harness.get("max_batch", 1))
+    col = _colorizers.get(key)
+    if col is None:
+        col = HAVCFrameColorizer(method, mweight, deoldify_p, ddcolor_p, cmc, lmm_p, alm_p, crt_p, cmb_sw, device_index, package_dir=torch_dir,
+                                 **harness)
+        _colorizers.clear()                     # one live graph at a time: the nets hold GBs of activations
+        _colorizers[key] = col
+    return col.colorize_clip(clip)
+
+
+def HAVC_ddeoldify(clip, method=2, mweight=0.4, deoldify_p=(0, 24, 1.0, 0.0), ddcolor_p=(1, 24, 1.0, 0.0, True), ddtweak=False,
+                   ddtweak_p=(DEF_TWEAK_p, "300:360|0.8,0.1"), cmc_tresh=0.2, lmm_p=(0.2, 0.8, 1.0), alm_p=(0.8, 1.0, 0.15), cmb_sw=False,
+                   sc_threshold=0.0, sc_tht_offset=1, sc_min_freq=0, sc_tht_ssim=0.0, sc_normalize=False, sc_min_int=1, sc_tht_white=DEF_THT_WHITE,
+                   sc_tht_black=DEF_THT_BLACK, device_index=0, torch_dir=None, sc_debug=False, **harness):
+    """deprecated wrapper, vsdeoldify/__init__.py:3612-3628: the same call with cmc_p = [cmc_tresh] and DEF_CRT_p"""
+    import warnings
+    warnings.warn("Warning: HAVC_ddeoldify is deprecated and may be removed in the future, please use 'HAVC_colorizer' instead.", DeprecationWarning)
+    return HAVC_colorizer(clip, method, mweight, deoldify_p, ddcolor_p, [ddtweak, False, False], ddtweak_p, [cmc_tresh], lmm_p, alm_p, DEF_CRT_p, cmb_sw,
+                          sc_threshold, sc_tht_offset, sc_min_freq, sc_tht_ssim, sc_normalize, sc_min_int, sc_tht_white, sc_tht_black, device_index,
+                          torch_dir, 1 if sc_debug else 0, **harness)
+
+
+def ddeoldify(clip, method=2, mweight=0.4, deoldify_p=(0, 24, 1.0, 0.0), ddcolor_p=(1, 24, 1.0, 0.0, True), dotweak=False,
+              dotweak_p=(0.0, 1.0, 1.0, False, 0.2, 0.5, 1.5, 0.5), ddtweak=False, ddtweak_p=(DEF_TWEAK_p, "300:360|0.8,0.1"), degrain_strength=0,
+              cmc_tresh=0.2, lmm_p=(0.2, 0.8, 1.0), alm_p=(0.8, 1.0, 0.15), cmb_sw=False, device_index=0, torch_dir=None, **harness):
+    """deprecated wrapper, vsdeoldify/__init__.py:3642-3653 (dotweak / degrain_strength are accepted and ignored, as there)"""
+    import warnings
+    warnings.warn("Warning: ddeoldify is deprecated and may be removed in the future, please use 'HAVC_colorizer' instead.", DeprecationWarning)
+    return HAVC_colorizer(clip, method, mweight, deoldify_p, ddcolor_p, [ddtweak, False, False], ddtweak_p, [cmc_tresh], lmm_p, alm_p, DEF_CRT_p, cmb_sw,
+                          sc_threshold=0, sc_min_freq=0, device_index=device_index, torch_dir=torch_dir, **harness)
+
+
+def _clip_chroma_resize(clip_hires, clip_lowres, device_index=0):
+    """__init__.py:3545-3554: Spline64 to the hi-res size, then vs_recover_clip_luma (luma of clip_hires, chroma of the resized)"""
+    hi, _ = _as_clip(clip_hires)
+    lo, _ = _as_clip(clip_lowres)
+    return spline64(get_context(device_index), lo, hi.shape[2], hi.shape[1], luma_from=hi)
+
+
+def HAVC_merge(clipa=None, clipb=None, clip_luma=None, weight=0.5, method=2, cmc_p=DEF_CMC_p, lmm_p=DEF_LMM_p, alm_p=DEF_ALM_p, crt_p=DEF_CRT_p,
+               device_index=0):
+    """vsdeoldify/__init__.py:2536-2675: the HAVC merge methods on two already coloured clips (+ optional luma source)."""
+    for name, c in (("clipa", clipa), ("clipb", clipb), ("clip_luma", clip_luma)):
+        if c is not None and not (is_device(c) or isinstance(c, np.ndarray)):
+            raise HAVCError(f"HAVC_merge: this is not a clip: {name}")                           # __init__.py:2631-2638
+    single = (clipa if clipa is not None else clipb).ndim == 3
+
+    def done(x):
+        if single and x.ndim == 4:
+            return x.reshaped(x.shape[1:]) if is_device(x) else x[0]
+        return x
+    if method == 0 or weight == 0:                                                                # __init__.py:2640-2645
+        return done(_clip_chroma_resize(clip_luma, clipa, device_index)) if clip_luma is not None else clipa
+    if method == 1 or weight == 1:                                                                # __init__.py:2647-2652
+        return done(_clip_chroma_resize(clip_luma, clipb, device_index)) if clip_luma is not None else clipb
+    a, _ = _as_clip(clipa)
+    b, _ = _as_clip(clipb)
+    if is_device(a) != is_device(b):
+        ctx = get_context(device_index)
+        a = a if is_device(a) else DeviceImage.from_numpy(ctx, a)
+        b = b if is_device(b) else DeviceImage.from_numpy(ctx, b)
+    if method == 2:                                                                               # __init__.py:2659-2661
+        return done(combine_models(a, b, 2, weight, device_index=device_index))
+    if clip_luma is not None:                                                                     # __init__.py:2663-2667
+        luma, _ = _as_clip(clip_luma)
+        rf = min(max(math.trunc(0.4 * luma.shape[2] / 16), 16), 32)
+        fs = min(rf * 16, luma.shape[2])
+        ctx = get_context(device_index)
+        a, b = spline64(ctx, a, fs, fs), spline64(ctx, b, fs, fs)
+    cmc = list(cmc_p) if isinstance(cmc_p, (list, tuple)) else [cmc_p]
+    merged = combine_models(a, b, method, weight, cmc, lmm_p, alm_p, crt_p, False, device_index)  # vs_combine_models(sat=[1,1], hue=[0,0])
+    if clip_luma is not None:                                                                     # __init__.py:2673-2676
+        merged = _clip_chroma_resize(clip_luma, merged, device_index)
+    return done(merged)

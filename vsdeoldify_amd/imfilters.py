@@ -1,14 +1,33 @@
 """Host-side mirror of the per-frame pixel filters the merge path uses (vsdeoldify/vsslib/imfilters.py),
 backed by the HIP kernels in csrc/colorfilters.hip.  PIL.Image in / PIL.Image out like the reference;
-the *_np variants take/return uint8 HWC arrays.
+the *_np variants take/return uint8 HWC arrays -- or `device.DeviceImage`s: when any operand lives in HBM the others are
+uploaded once, the result stays in HBM and the call does not block (include/havc_mi355.h, "Pointers").
 """
 import numpy as np
 
 from . import _native as nat
+from .device import DeviceImage, is_device, operand_ptr as _p
 from .render import get_context
 
 
-def _prep(a, b):
+def _one(ctx, a):
+    """operand + matching output buffer: ndarray -> ndarray, DeviceImage -> DeviceImage"""
+    if is_device(a):
+        return a, a.empty_like()
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("not an RGB image")
+    return a, np.empty_like(a)
+
+
+def _prep(a, b, ctx=None):
+    if is_device(a) or is_device(b):
+        ctx = ctx or (a.ctx if is_device(a) else b.ctx)
+        a = a if is_device(a) else DeviceImage.from_numpy(ctx, a)
+        b = b if is_device(b) else DeviceImage.from_numpy(ctx, b)
+        if a.shape != b.shape:
+            raise ValueError("images do not match")
+        return a, b, a.empty_like()
     a = np.ascontiguousarray(a, dtype=np.uint8)
     b = np.ascontiguousarray(b, dtype=np.uint8)
     if a.shape != b.shape or a.ndim != 3 or a.shape[2] != 3:
@@ -16,22 +35,31 @@ def _prep(a, b):
     return a, b, np.empty_like(a)
 
 
+def _wh(a, per_frame=False):
+    """(width, height) handed to the C entry point; a DeviceImage stack is ONE tall image for purely per-pixel filters"""
+    if a.ndim == 4:
+        if per_frame:
+            raise ValueError("this filter works on one frame at a time (frame-level statistics / neighbourhoods)")
+        return a.shape[2], a.shape[0] * a.shape[1]
+    return a.shape[1], a.shape[0]
+
+
 def blend_np(ctx, a, b, w):
     a, b, out = _prep(a, b)
-    nat.check(ctx.lib.havc_blend(ctx.h, nat.as_ptr(a), nat.as_ptr(b), float(w), nat.as_ptr(out), a.shape[1], a.shape[0]), ctx.h)
+    nat.check(ctx.lib.havc_blend(ctx.h, _p(a), _p(b), float(w), _p(out), *_wh(a)), ctx.h)
     return out
 
 
 def chroma_post_process_np(ctx, color, orig):
     a, b, out = _prep(color, orig)
-    nat.check(ctx.lib.havc_chroma_post_process(ctx.h, nat.as_ptr(a), nat.as_ptr(b), nat.as_ptr(out), a.shape[1], a.shape[0]), ctx.h)
+    nat.check(ctx.lib.havc_chroma_post_process(ctx.h, _p(a), _p(b), _p(out), *_wh(a)), ctx.h)
     return out
 
 
 def chroma_stabilizer_np(ctx, img_stable, img_new, alpha=0.15, weight=1.0):
     a, b, out = _prep(img_stable, img_new)
-    nat.check(ctx.lib.havc_chroma_stabilizer(ctx.h, nat.as_ptr(a), nat.as_ptr(b), float(alpha), float(weight), nat.as_ptr(out),
-                                             a.shape[1], a.shape[0]), ctx.h)
+    nat.check(ctx.lib.havc_chroma_stabilizer(ctx.h, _p(a), _p(b), float(alpha), float(weight), _p(out),
+                                             *_wh(a)), ctx.h)
     return out
 
 
@@ -62,42 +90,43 @@ def chroma_stabilizer(img_stable, img_new, alpha=0.15, weight=1.0, device_index=
 # ---- merge-method filters of HAVC_merge methods 4, 5, 7 and the temporal limiters --------------------------------
 def chroma_stabilizer_adaptive_np(ctx, img_stable, img_new, base_tol=18, max_extra=22, weight=1.0):
     a, b, out = _prep(img_stable, img_new)
-    nat.check(ctx.lib.havc_chroma_stabilizer_adaptive(ctx.h, nat.as_ptr(a), nat.as_ptr(b), float(base_tol), float(max_extra),
-                                                      float(weight), nat.as_ptr(out), a.shape[1], a.shape[0]), ctx.h)
+    nat.check(ctx.lib.havc_chroma_stabilizer_adaptive(ctx.h, _p(a), _p(b), float(base_tol), float(max_extra),
+                                                      float(weight), _p(out), *_wh(a, per_frame=True)), ctx.h)
     return out
 
 
 def chroma_temporal_limiter_np(ctx, cur, prv, alpha=0.05):
     a, b, out = _prep(cur, prv)
-    nat.check(ctx.lib.havc_chroma_temporal_limiter(ctx.h, nat.as_ptr(a), nat.as_ptr(b), float(alpha), nat.as_ptr(out), a.shape[1], a.shape[0]), ctx.h)
+    nat.check(ctx.lib.havc_chroma_temporal_limiter(ctx.h, _p(a), _p(b), float(alpha), _p(out), *_wh(a)), ctx.h)
     return out
 
 
 def color_temporal_stabilizer_np(ctx, frames, weight_list):
     import ctypes as C
-    frames = [np.ascontiguousarray(f, dtype=np.uint8) for f in frames]
+    dev = any(is_device(f) for f in frames)
+    frames = [f if is_device(f) else (DeviceImage.from_numpy(ctx, f) if dev else np.ascontiguousarray(f, dtype=np.uint8)) for f in frames]
     if len(frames) != len(weight_list) or not 1 <= len(frames) <= 9 or any(f.shape != frames[0].shape for f in frames):
         raise ValueError("frames / weight_list mismatch (1..9 frames of one size)")
-    ptrs = (C.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+    ptrs = (C.c_void_p * len(frames))(*[(f.ptr.value if is_device(f) else f.ctypes.data) for f in frames])
     w = np.array([float(x) / 100.0 for x in weight_list], np.float64)         # weight_list is in percent (imfilters.py:690)
-    out = np.empty_like(frames[0])
-    nat.check(ctx.lib.havc_color_temporal_stabilizer(ctx.h, C.cast(ptrs, C.c_void_p), nat.as_ptr(w), len(frames), nat.as_ptr(out),
-                                                     out.shape[1], out.shape[0]), ctx.h)
+    out = frames[0].empty_like() if dev else np.empty_like(frames[0])
+    nat.check(ctx.lib.havc_color_temporal_stabilizer(ctx.h, C.cast(ptrs, C.c_void_p), nat.as_ptr(w), len(frames), _p(out),
+                                                     *_wh(out)), ctx.h)
     return out
 
 
 def image_luma_np(ctx, img):
     import ctypes as C
-    a = np.ascontiguousarray(img, dtype=np.uint8)
+    a = img if is_device(img) else np.ascontiguousarray(img, dtype=np.uint8)
     m = C.c_double()
-    nat.check(ctx.lib.havc_image_luma(ctx.h, nat.as_ptr(a), a.shape[1], a.shape[0], C.byref(m)), ctx.h)
+    nat.check(ctx.lib.havc_image_luma(ctx.h, _p(a), *_wh(a, per_frame=True), C.byref(m)), ctx.h)
     return m.value
 
 
 def luma_merge_np(ctx, img_dark, img_white, mode, tresh=0.0, grad=0.0):
     a, b, out = _prep(img_dark, img_white)
-    nat.check(ctx.lib.havc_image_luma_merge(ctx.h, nat.as_ptr(a), nat.as_ptr(b), int(mode), float(tresh), float(grad), nat.as_ptr(out),
-                                            a.shape[1], a.shape[0]), ctx.h)
+    nat.check(ctx.lib.havc_image_luma_merge(ctx.h, _p(a), _p(b), int(mode), float(tresh), float(grad), _p(out),
+                                            *_wh(a)), ctx.h)
     return out
 
 
@@ -125,34 +154,41 @@ def get_image_luma(img, maxrange=255, device_index=0):
     return round(image_luma_np(get_context(device_index), np.asarray(img)) / maxrange, 6)
 
 
+def image_luma_merge_np(ctx, img_dark, img_white, luma=0):
+    """imfilters.py:66-77 on arrays / DeviceImages"""
+    if luma > 0:
+        return luma_merge_np(ctx, img_dark, img_white, 0, round(luma * 255))
+    return luma_merge_np(ctx, img_dark, img_white, 3)        # np_rgb_to_gray without threshold: mask = luma itself, merged with /255
+
+
+def w_image_luma_merge_np(ctx, img_dark, img_white, dark_luma=0.3, white_luma=0.9):
+    """imfilters.py:80-100 with w_np_rgb_to_gray's threshold / gradient arithmetic (nputils.py:141-183) on the host"""
+    if dark_luma >= white_luma:
+        return img_dark
+    if dark_luma > 0:
+        max_white = round(white_luma * 255)
+        tresh = min(round(dark_luma * 255), max_white - 10)
+        grad = round(1 / (max_white - tresh), 3)
+        return luma_merge_np(ctx, img_dark, img_white, 1, tresh, grad)
+    return luma_merge_np(ctx, img_dark, img_white, 2)
+
+
 def image_luma_merge(img_dark, img_white, luma=0, return_mask=False, device_index=0):
     """imfilters.py:66-77 (hard luma mask built from img_white)."""
     from PIL import Image
     if return_mask:
         raise NotImplementedError("return_mask is a debugging aid of the reference; not on the hot path")
-    if luma > 0:
-        out = luma_merge_np(get_context(device_index), np.asarray(img_dark), np.asarray(img_white), 0, round(luma * 255))
-    else:                                     # np_rgb_to_gray without threshold: mask = luma itself, merged with /255
-        out = luma_merge_np(get_context(device_index), np.asarray(img_dark), np.asarray(img_white), 3)
-    return Image.fromarray(out)
+    return Image.fromarray(image_luma_merge_np(get_context(device_index), np.asarray(img_dark), np.asarray(img_white), luma))
 
 
 def w_image_luma_merge(img_dark, img_white, dark_luma=0.3, white_luma=0.9, return_mask=False, device_index=0):
-    """imfilters.py:80-100 with w_np_rgb_to_gray's threshold / gradient arithmetic (nputils.py:141-183) on the host."""
+    """imfilters.py:80-100."""
     from PIL import Image
     if dark_luma >= white_luma:
         return img_dark
     if return_mask:
         raise NotImplementedError("return_mask is a debugging aid of the reference; not on the hot path")
-    ctx = get_context(device_index)
-    if dark_luma > 0:
-        max_white = round(white_luma * 255)
-        tresh = min(round(dark_luma * 255), max_white - 10)
-        grad = round(1 / (max_white - tresh), 3)
-        out = luma_merge_np(ctx, np.asarray(img_dark), np.asarray(img_white), 1, tresh, grad)
-    else:
-        out = luma_merge_np(ctx, np.asarray(img_dark), np.asarray(img_white), 2)
-    return Image.fromarray(out)
+    return Image.fromarray(w_image_luma_merge_np(get_context(device_index), np.asarray(img_dark), np.asarray(img_white), dark_luma, white_luma))
 
 
 # ---- tweaks and gray-pixel restoration (SURVEY.md §8 a17 / a19) ----------------------------------------------------
@@ -179,12 +215,11 @@ def image_tweak_np(ctx, img, sat=1.0, cont=1.0, bright=0.0, hue=0.0, gamma=1.0, 
         # imfilters.py:507-517: the reference passes `uint8_array * 3` (256 entries) to Image.point of an RGB image and
         # Pillow raises; the gamma branch of image_tweak has never produced a frame.  Same error, same text.
         raise ValueError("wrong number of lut entries")
-    a = np.ascontiguousarray(img, dtype=np.uint8)
-    out = np.empty_like(a)
+    a, out = _one(ctx, img)
     rng = [] if hue_range in ("none", "") else parse_hue_ranges(hue_range)
     arr = (C.c_double * max(len(rng), 1))(*rng)
     hue_off = int((hue / 360.0) * 255) if hue != 0.0 else 0                  # imfilters.py:530
-    nat.check(ctx.lib.havc_image_tweak(ctx.h, nat.as_ptr(a), nat.as_ptr(out), a.shape[1], a.shape[0], hue_off,
+    nat.check(ctx.lib.havc_image_tweak(ctx.h, _p(a), _p(out), *_wh(a, per_frame=(cont != 1.0)), hue_off,
                                        float(1 + bright / 255) if bright != 0.0 else 1.0, float(cont), float(sat), arr,
                                        len(rng) // 2), ctx.h)
     return out
@@ -211,11 +246,10 @@ def luma_levels_lut(luma, luma_min=0.0, gamma=1.0, gamma_luma_min=0.0, gamma_alp
 
 
 def luma_adjusted_levels_np(ctx, img, luma_min=0.0, gamma=1.0, gamma_luma_min=0.0, gamma_alpha=0.0, gamma_min=0.2, i_min=0, i_max=255):
-    a = np.ascontiguousarray(img, dtype=np.uint8)
+    a, out = _one(ctx, img)
     luma = image_luma_np(ctx, a) / 255
     lut = luma_levels_lut(luma, luma_min, gamma, gamma_luma_min, gamma_alpha, gamma_min, i_min, i_max)
-    out = np.empty_like(a)
-    nat.check(ctx.lib.havc_luma_lut(ctx.h, nat.as_ptr(a), nat.as_ptr(lut), nat.as_ptr(out), a.shape[1], a.shape[0]), ctx.h)
+    nat.check(ctx.lib.havc_luma_lut(ctx.h, _p(a), nat.as_ptr(lut), _p(out), *_wh(a)), ctx.h)
     return out
 
 
@@ -229,7 +263,7 @@ def luma_adjusted_levels(img, luma_min=0, gamma=1.0, gamma_luma_min=0, gamma_alp
 
 def restore_color_gradient_np(ctx, img_color, img_gray, sat=1.0, tht=50, weight=0.0, alpha=2.0, return_mask=False, algo=0):
     a, b, out = _prep(img_color, img_gray)
-    nat.check(ctx.lib.havc_restore_color_gradient(ctx.h, nat.as_ptr(a), nat.as_ptr(b), nat.as_ptr(out), a.shape[1], a.shape[0],
+    nat.check(ctx.lib.havc_restore_color_gradient(ctx.h, _p(a), _p(b), _p(out), *_wh(a),
                                                   float(sat), int(tht), float(weight), float(alpha), int(algo), int(bool(return_mask))), ctx.h)
     return out
 
@@ -270,14 +304,13 @@ def parse_hue_adjust(hue_adjust):
 
 def image_chroma_tweak_np(ctx, img, sat=1, bright=0, hue=0, hue_adjust="none"):
     import ctypes as C
-    a = np.ascontiguousarray(img, dtype=np.uint8)
     if sat == 1 and bright == 0 and hue == 0 and hue_adjust == "none":
-        return a                                                          # restcolor.py:290-291
+        return img if is_device(img) else np.ascontiguousarray(img, dtype=np.uint8)            # restcolor.py:290-291
+    a, out = _one(ctx, img)
     param = None if hue_adjust in ("none", "") else parse_hue_adjust(hue_adjust)
     rng = parse_hue_ranges(param[0]) if param else []
     arr = (C.c_double * max(len(rng), 1))(*rng)
-    out = np.empty_like(a)
-    nat.check(ctx.lib.havc_image_chroma_tweak(ctx.h, nat.as_ptr(a), nat.as_ptr(out), a.shape[1], a.shape[0], float(sat), float(bright), int(hue),
+    nat.check(ctx.lib.havc_image_chroma_tweak(ctx.h, _p(a), _p(out), *_wh(a), float(sat), float(bright), int(hue),
                                               1 if param else 0, arr, len(rng) // 2, float(param[1]) if param else 1.0,
                                               int(param[2]) if param else 0, float(param[3]) if param else 0.0), ctx.h)
     return out

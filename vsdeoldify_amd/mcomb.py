@@ -15,16 +15,21 @@ back through w_image_luma_merge.
 import numpy as np
 
 from . import imfilters as F
+from .device import is_device
 from .render import get_context
+
+
+def _img(x):
+    return x if is_device(x) else np.asarray(x)
 
 DEF_STANDARD_DARK, DEF_STANDARD_BRIGHT = 0.22, 0.78        # vsslib/constants.py:28-29
 
 
 def simple_merge(a, b, weight=0.5, device_index=0):
     if weight == 0.0:
-        return np.asarray(a)
+        return _img(a)
     if weight == 1.0:
-        return np.asarray(b)
+        return _img(b)
     return F.blend_np(get_context(device_index), a, b, weight)
 
 
@@ -56,13 +61,12 @@ def chroma_bound_adaptive_merge(a, b, red_fix=True, base_tol=14, max_extra=18, c
 
 def luma_masked_merge(a, b, c=None, luma_mask_limit=0.4, luma_white_limit=0.7, clipm_weight=0.5, device_index=0):
     """a = clipa frame, b = clipb frame, c = de-saturated clipa frame (== a when luma_mask_sat >= 1)."""
-    from PIL import Image
+    ctx = get_context(device_index)
     c = a if c is None else c
-    pc, pb = Image.fromarray(np.asarray(c)), Image.fromarray(np.asarray(b))
     if luma_mask_limit == luma_white_limit:
-        masked = np.asarray(F.image_luma_merge(pc, pb, luma_mask_limit, device_index=device_index))
+        masked = F.image_luma_merge_np(ctx, _img(c), _img(b), luma_mask_limit)
     else:
-        masked = np.asarray(F.w_image_luma_merge(pc, pb, luma_mask_limit, luma_white_limit, device_index=device_index))
+        masked = F.w_image_luma_merge_np(ctx, _img(c), _img(b), luma_mask_limit, luma_white_limit)
     return simple_merge(a, masked, clipm_weight, device_index) if clipm_weight < 1.0 else masked
 
 

@@ -41,9 +41,9 @@ def _load_pth(path):
 class GeneratorRuntime:
     """Packed weights on one GPU + a cache of nets keyed by (render size, max_batch)."""
 
-    def __init__(self, ctx, state_dict, arch, fuse_final=True, fuse_blur=True):
+    def __init__(self, ctx, state_dict, arch, fuse_final=True, fuse_blur=True, generator=None):
         self.ctx, self.arch = ctx, arch
-        self.gen = DeoldifyGenerator(state_dict, arch, fuse_final=fuse_final, fuse_blur=fuse_blur)
+        self.gen = generator or DeoldifyGenerator(state_dict, arch, fuse_final=fuse_final, fuse_blur=fuse_blur)
         self.weights = nat.Weights(ctx, self.gen.blob)
         self.nets = {}
 
@@ -53,6 +53,8 @@ class GeneratorRuntime:
             ops, bufs, i, o, names = self.gen.plan(S)
             n = nat.Net(self.ctx, self.weights, ops, bufs, i, o, S, max_batch)
             n.names = names
+            if os.environ.get("HAVC_AUTOTUNE", "1") != "0":
+                n.autotune(max_batch)          # per-op conv tile configuration by measurement: same bytes, ~1 s once per net
             self.nets[key] = n
         return self.nets[key]
 
@@ -84,6 +86,9 @@ class ModelImageRender:
             sd = state_dicts[which]
         else:
             path = os.path.join(str(self.package_dir), "models", name + ".pth")      # Learner.load path
+            packed = os.path.splitext(path)[0] + ".havc"                             # tools/convert_weights.py output, if newer
+            if os.path.isfile(packed) and (not os.path.isfile(path) or os.path.getmtime(packed) >= os.path.getmtime(path)):
+                return GeneratorRuntime(self.ctx, None, arch, generator=DeoldifyGenerator.load(packed))
             if not os.path.isfile(path) or os.path.getsize(path) == 0:
                 raise FileNotFoundError(f"DeOldify weights not found: {path}")
             sd = _load_pth(path)
@@ -91,16 +96,42 @@ class ModelImageRender:
 
     # -- raw batched entry (frames already S x S, uint8 [n,S,S,3]) ------------------------------
     def render_square_batch(self, frames, post_process=True):
-        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        """uint8 [n, S, S, 3] (ndarray, or a device.DeviceImage: then nothing leaves HBM and the call does not block)"""
+        from .device import is_device, operand_ptr
+        dev = is_device(frames)
+        if not dev:
+            frames = np.ascontiguousarray(frames, dtype=np.uint8)
         n, S = frames.shape[0], frames.shape[1]
-        assert frames.shape[1:] == (S, S, 3) and S == self._render_factor * RENDER_BASE
+        assert tuple(frames.shape[1:]) == (S, S, 3) and S == self._render_factor * RENDER_BASE
         v = self._video.net(S, self._max_batch)
         s = self._second.net(S, self._max_batch) if self._second else None
-        out = np.empty_like(frames)
+        out = frames.empty_like() if dev else np.empty_like(frames)
         nat.check(self.ctx.lib.havc_deoldify_frames(self.ctx.h, v.h, s.h if s else None, float(self._video_weight),
-                                                    1 if post_process else 0, nat.as_ptr(frames), nat.as_ptr(out), n),
+                                                    1 if post_process else 0, operand_ptr(frames), operand_ptr(out), n),
                   self.ctx.h)
         return out
+
+    def get_transformed_planes(self, planes_in, planes_out=None, post_process=True):
+        """One VapourSynth RGB24 frame given as its three planes (2-D uint8 arrays with any row stride, S x S) -> three planes:
+        frame_to_image + get_transformed_image + image_to_frame (vsslib/vsmodels.py:214-230, vsslib/vsutils.py:60-110) in one
+        call, the plane <-> interleaved shuffles on the GPU."""
+        import ctypes as C
+        S = self._render_factor * RENDER_BASE
+        pl = [np.asarray(p) for p in planes_in]
+        if len(pl) != 3 or any(p.shape != (S, S) or p.dtype != np.uint8 or p.strides[1] != 1 for p in pl) or len({p.strides[0] for p in pl}) != 1:
+            raise ValueError("planes must be three uint8 [S, S] arrays with unit pixel stride and one common row stride")
+        if planes_out is None:
+            planes_out = [np.empty((S, S), np.uint8) for _ in range(3)]
+        po = [np.asarray(p) for p in planes_out]
+        if any(p.shape != (S, S) or p.dtype != np.uint8 or p.strides[1] != 1 or not p.flags.writeable for p in po) or len({p.strides[0] for p in po}) != 1:
+            raise ValueError("output planes must be three writable uint8 [S, S] arrays with one common row stride")
+        v = self._video.net(S, self._max_batch)
+        s = self._second.net(S, self._max_batch) if self._second else None
+        pin = (C.c_void_p * 3)(*[p.ctypes.data for p in pl])
+        pout = (C.c_void_p * 3)(*[p.ctypes.data for p in po])
+        nat.check(self.ctx.lib.havc_deoldify_frame_planar(self.ctx.h, v.h, s.h if s else None, float(self._video_weight), 1 if post_process else 0,
+                                                          pin, pl[0].strides[0], pout, po[0].strides[0]), self.ctx.h)
+        return planes_out
 
     def get_transformed_image(self, img_orig, post_process=True):
         """PIL RGB in -> PIL RGB out, same size (visualize.py:118-137).  Frames already at the render size
@@ -109,30 +140,27 @@ class ModelImageRender:
         from PIL import Image
         S = self._render_factor * RENDER_BASE
         img_orig = img_orig.convert("RGB") if img_orig.mode != "RGB" else img_orig
-        try:
-            if img_orig.size == (S, S):
+        if img_orig.size == (S, S):
+            try:
                 out = self.render_square_batch(np.asarray(img_orig)[None], post_process)[0]
                 return Image.fromarray(out)
-            sq = np.asarray(img_orig.resize((S, S), resample=Image.BILINEAR))
-            raw_v, raw_s = self._raw_colors(sq)
-            outs = []
-            for raw in (raw_v, raw_s):
-                if raw is None:
-                    continue
-                col = np.asarray(Image.fromarray(raw).resize(img_orig.size, resample=Image.BILINEAR))
-                if post_process:
-                    from .imfilters import chroma_post_process_np
-                    col = chroma_post_process_np(self.ctx, col, np.asarray(img_orig))
-                outs.append(col)
-            if len(outs) == 1:
-                return Image.fromarray(outs[0])
-            from .imfilters import blend_np
-            return Image.fromarray(blend_np(self.ctx, outs[1], outs[0], self._video_weight))
-        except nat.HavcOutOfMemory:
-            # deoldify/filters.py:55-63: OOM -> warn and return the (squared, gray) model image
-            logging.warning("Warning: render_factor was set too high, and out of memory error resulted. "
-                            "Returning original image.")
-            return img_orig.resize((S, S), resample=Image.BILINEAR).convert("LA").convert("RGB")
+            except nat.HavcOutOfMemory:
+                pass                                 # fall through to the per-model path below, which reproduces the reference's OOM flow
+        sq = np.asarray(img_orig.resize((S, S), resample=Image.BILINEAR))
+        raw_v, raw_s = self._raw_colors(sq)
+        outs = []
+        for raw in (raw_v, raw_s):
+            if raw is None:
+                continue
+            col = np.asarray(Image.fromarray(raw).resize(img_orig.size, resample=Image.BILINEAR))
+            if post_process:
+                from .imfilters import chroma_post_process_np
+                col = chroma_post_process_np(self.ctx, col, np.asarray(img_orig))
+            outs.append(col)
+        if len(outs) == 1:
+            return Image.fromarray(outs[0])
+        from .imfilters import blend_np
+        return Image.fromarray(blend_np(self.ctx, outs[1], outs[0], self._video_weight))
 
     def _raw_colors(self, sq):
         S = sq.shape[0]
@@ -141,9 +169,18 @@ class ModelImageRender:
             if rt is None:
                 outs.append(None)
                 continue
-            n = rt.net(S, self._max_batch)
-            o = np.empty_like(sq[None])
-            nat.check(self.ctx.lib.havc_deoldify_frames(self.ctx.h, n.h, None, 0.0, 0, nat.as_ptr(np.ascontiguousarray(sq[None])),
-                                                        nat.as_ptr(o), 1), self.ctx.h)
-            outs.append(o[0])
+            try:
+                n = rt.net(S, self._max_batch)
+                o = np.empty_like(sq[None])
+                nat.check(self.ctx.lib.havc_deoldify_frames(self.ctx.h, n.h, None, 0.0, 0, nat.as_ptr(np.ascontiguousarray(sq[None])),
+                                                            nat.as_ptr(o), 1), self.ctx.h)
+                outs.append(o[0])
+            except nat.HavcOutOfMemory:
+                # deoldify/filters.py:55-63: on OOM _model_process warns and returns the (squared, gray) model image, and
+                # filter() CONTINUES with it: un-square to the source size, post-process, blend -- the caller still gets an
+                # image of img_orig.size
+                from PIL import Image
+                logging.warning("Warning: render_factor was set too high, and out of memory error resulted. "
+                                "Returning original image.")
+                outs.append(np.asarray(Image.fromarray(sq).convert("LA").convert("RGB")))
         return outs

@@ -58,3 +58,83 @@ def timed_steps(step_fn, steps, warmup, sync_fn, dist=None, device=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed
+
+
+# ---- a clip through N GPUs: scatter -> colour -> gather, frame order preserved -----------------------------------------------
+def colorize_clip_sharded(frames, colorize_fn, dist=None, rank=0, world_size=1, device="cpu", n_frames=None, frame_shape=None):
+    """Colour a clip on `world_size` ranks and return it, in frame order, on rank 0 (None on the other ranks).
+
+    frames      rank 0: uint8 tensor / array [n, h, w, 3] (host or device); other ranks: None (pass n_frames / frame_shape, or
+                let rank 0 broadcast them)
+    colorize_fn maps a uint8 torch tensor [m, h, w, 3] ON `device` to a tensor of the same shape on the same device -- on the
+                MI355X this is `DeviceClipFn(colorizer)` below, which hands the tensor's device pointer to libhavc_mi355
+                (every entry point takes device pointers): the shard never leaves HBM between the collectives
+    Frames are independent: frame i goes to rank i mod G (shard_frames); the only exchange is ONE scatter of
+    the gray frames and ONE gather of the coloured frames (RCCL over xGMI with backend "nccl"; "gloo" in the CPU tests).
+    Shards are padded to ceil(n / G) frames so that the collectives see equal sizes; padding frames are not coloured."""
+    import torch
+    if dist is None or world_size == 1:
+        t = torch.as_tensor(frames).to(device)
+        return colorize_fn(t)
+    meta = torch.zeros(4, dtype=torch.int64, device=device)
+    if rank == 0:
+        t = torch.as_tensor(frames)
+        meta = torch.tensor(list(t.shape), dtype=torch.int64, device=device)
+    if n_frames is None or frame_shape is None:
+        dist.broadcast(meta, src=0)
+        n, h, w, c = (int(v) for v in meta.tolist())
+    else:
+        n, (h, w, c) = n_frames, frame_shape
+    m = (n + world_size - 1) // world_size                      # frames per padded shard
+    mine = shard_frames(n, rank, world_size)
+    shard = torch.empty((m, h, w, c), dtype=torch.uint8, device=device)
+    scatter_list = None
+    if rank == 0:
+        t = t.to(device)
+        scatter_list = []
+        for r in range(world_size):
+            s = torch.zeros((m, h, w, c), dtype=torch.uint8, device=device)
+            idx = shard_frames(n, r, world_size)
+            if idx:
+                s[:len(idx)] = t[idx]
+            scatter_list.append(s)
+    dist.scatter(shard, scatter_list, src=0)
+    out = torch.zeros_like(shard)
+    if mine:
+        out[:len(mine)] = colorize_fn(shard[:len(mine)].contiguous())
+    gather_list = [torch.empty_like(out) for _ in range(world_size)] if rank == 0 else None
+    dist.gather(out, gather_list, dst=0)
+    if rank != 0:
+        return None
+    result = torch.empty((n, h, w, c), dtype=torch.uint8, device=device)
+    for r in range(world_size):
+        idx = shard_frames(n, r, world_size)
+        if idx:
+            result[idx] = gather_list[r][:len(idx)]
+    return result
+
+
+class DeviceClipFn:
+    """colorize_fn for colorize_clip_sharded on a GPU rank: wraps anything with `colorize_clip(DeviceImage) -> DeviceImage`
+    (HAVCFrameColorizer) or a ClipColorizer.  The torch tensor's storage is used in place through its device pointer."""
+
+    def __init__(self, colorizer):
+        self.colorizer = colorizer
+
+    def __call__(self, t):
+        import ctypes
+        import torch
+        from .device import DeviceImage
+        assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
+        ctx = self.colorizer.ctx
+        torch.cuda.current_stream(t.device).synchronize()            # the scatter wrote `t` on torch's stream
+        out = torch.empty_like(t)
+        src = DeviceImage(ctx, tuple(t.shape), ctypes.c_void_p(t.data_ptr()))
+        if hasattr(self.colorizer, "colorize_device"):               # ClipColorizer: havc_colorize_clip
+            n, h, w, _ = t.shape
+            self.colorizer.colorize_device(src.ptr, ctypes.c_void_p(out.data_ptr()), n, w, h)
+        else:
+            res = self.colorizer.colorize_clip(src)
+            DeviceImage(ctx, tuple(out.shape), ctypes.c_void_p(out.data_ptr())).copy_from(res)
+        ctx.synchronize()                                            # the gather reads `out` on torch's stream
+        return out
