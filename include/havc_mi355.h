@@ -94,6 +94,8 @@ enum havc_op_type {
 #define HAVC_F_GELU 0x400         /* exact (erf) GELU at the RELU_PRE position (ConvNeXt pwconv1)                            */
 #define HAVC_F_W_FROM_BUF 0x800   /* conv weights are ACTIVATIONS: buffer src2 holds, per frame, fp16 [Npad][Kc * 8] rows (the colour
                                      embeddings of DDColor's einsum(bqc,bchw->bqhw)); launched once per frame; no residual  */
+#define HAVC_F_NT_STORE 0x1000    /* the LDS-transposed epilogue stores its rows with non-temporal (streaming) stores: for outputs far
+                                     larger than the 256 MiB Infinity Cache that are not re-read soon (set by the runtime, HAVC_NT_STORE_MB) */
 #define HAVC_F_FUSE_RGB8 0x100    /* the conv output is NOT stored: a following 1x1 conv to 3 channels (fp32 weights at
                                      scale_off [3][Npad], bias at shift_off [3]) + OUT_RGB8 maths run in the epilogue and
                                      write u8 RGB to buffer aux0 (layers.10.1 + layers.11 + layers.12 of the generator);

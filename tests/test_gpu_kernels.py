@@ -99,7 +99,7 @@ def test_conv_tile_configurations_are_bit_identical(ctx, flags, with_res):
     kw = dict(bias=bias, pad=1, flags=flags, res=res)
     if flags & nat.F_AFFINE:
         kw.update(scale=sc, shift=sh)
-    outs = {cfg: gu.conv_op(ctx, x, Wt, cfg=cfg, **kw)[1] for cfg in (0, 1, 2, 3, 7, 60, 70, 71, 72)}
+    outs = {cfg: gu.conv_op(ctx, x, Wt, cfg=cfg, **kw)[1] for cfg in (0, 1, 2, 3, 7, 60, 70, 71, 72, 90, 91, 93, 95, 96, 97, 98)}
     base = outs[0]
     for cfg, o in outs.items():
         assert np.array_equal(o.view(np.uint16), base.view(np.uint16)), f"cfg {cfg} differs from the heuristic's choice"

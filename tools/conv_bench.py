@@ -19,6 +19,8 @@ SHAPES = {  # name: (Cin, Cout, k, stride, pad, H, W, flags)
     "mid1": (4096, 2048, 3, 1, 1, 18, 18, nat.F_RELU_PRE | nat.F_AFFINE),
     "l8ps": (256, 1024, 1, 1, 0, 280, 280, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),
     "l7ps": (512, 1024, 1, 1, 0, 140, 140, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),
+    "l8blur": (256, 1024, 1, 1, 0, 280, 280, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF | nat.F_PS_BLUR),
+    "l7blur": (512, 1024, 1, 1, 0, 140, 140, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF | nat.F_PS_BLUR),
     "l8nops": (256, 1024, 1, 1, 0, 280, 280, nat.F_RELU_PRE),
     "l7nops": (512, 1024, 1, 1, 0, 140, 140, nat.F_RELU_PRE),
     "enc3x3_35": (256, 256, 3, 1, 1, 35, 35, nat.F_RELU_PRE),
@@ -51,7 +53,7 @@ def bench(ctx, name, batch, reps, cfg=0):
     kw = dict(bias=r.standard_normal(Cout).astype(np.float32))
     if flags & nat.F_AFFINE:
         kw.update(scale=np.ones(Cout, np.float32), shift=np.zeros(Cout, np.float32))
-    pc = pack_conv(pack, Wt, x.cmap, x.span, pixshuf=bool(flags & nat.F_OUT_PIXSHUF), **kw)
+    pc = pack_conv(pack, Wt, x.cmap, x.span, pixshuf=("blur" if flags & nat.F_PS_BLUR else bool(flags & nat.F_OUT_PIXSHUF)), **kw)
     Ho = (H + 2 * p - k) // s + 1
     y = b.tensor(2 * Ho, 2 * Ho, Cout // 4) if flags & nat.F_OUT_PIXSHUF else b.tensor(Ho, Ho, Cout)
     res = b.tensor(Ho, Ho, Cout) if with_res else None

@@ -44,6 +44,7 @@ struct Geo {
     static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
     static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0, "pieces must divide over an even number of waves");
     static_assert(FM >= FN, "second-half weight fragments are prefetched during the first FM steps");
+    static_assert(FM % 2 == 0, "the 4-slot pixel-fragment ring wraps cleanly only when a stage has a multiple of 4 steps");
     static_assert(!EXTRA || (WM == 2 && WN == 4 && FM == 8), "extra columns: 256x256 tile only");
     static_assert(NW * FM * 2048 <= LDS_BYTES, "LDS epilogue image");
 };
@@ -528,6 +529,8 @@ int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
         case 69: return launch_pipe<2, 4, 8, 0, 9>(a, s);
         case 73: return launch_pipe<2, 4, 8, 0, 10>(a, s);
         case 65: return launch_pipe<2, 4, 8, 0, 5>(a, s);
+        case 66: return launch_pipe<2, 4, 8, 0, 11>(a, s);    // PS_BLUR epilogue without its global stores
+        case 67: return launch_pipe<2, 4, 8, 0, 13>(a, s);    // PS_BLUR epilogue with plain instead of non-temporal stores
         case 80: return launch_halo<0>(a, s);                 // 3x3 s1 p1, 16x16-pixel tiles with halo reuse
         case 81: return launch_halo<1>(a, s);
         case 82: return launch_halo<0, 1>(a, s);              // ablations (profiling only)
@@ -537,6 +540,15 @@ int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
         case 70: return launch_pipe<2, 2, 4, 0>(a, s);        // 128 x 128, 4 waves
         case 71: return launch_pipe<1, 4, 8, 0>(a, s);        // 128 x 256, 4 waves
         case 72: return launch_pipe<1, 2, 4, 0>(a, s);        // 64 x 128, 2 waves
+        // more tile geometries for the autotuner (round 2): layers whose pixel count leaves the standard tiles with a ragged last
+        // wave of blocks (16 x 35^2 = 19 600 pixels: 154 tiles of 128 -> 308 blocks on 256 CUs) get a tile height that divides better
+        case 90: return launch_pipe<1, 4, 6, 0>(a, s);        //  96 x 256, 4 waves
+        case 91: return launch_pipe<1, 4, 4, 0>(a, s);        //  64 x 256, 4 waves
+        case 93: return launch_pipe<2, 2, 6, 0>(a, s);        // 192 x 128, 4 waves
+        case 95: return launch_pipe<1, 2, 6, 0>(a, s);        //  96 x 128, 2 waves
+        case 96: return launch_pipe<2, 4, 4, 0>(a, s);        // 128 x 256, 8 waves
+        case 97: return launch_pipe<2, 4, 6, 0>(a, s);        // 192 x 256, 8 waves
+        case 98: return launch_pipe<4, 2, 4, 0>(a, s);        // 256 x 128, 8 waves
         case 74: return launch_pipe<2, 2, 4, 0, 1>(a, s);     // ablations of cfg 70 (profiling only): no DMA in the loop
         case 75: return launch_pipe<2, 2, 4, 0, 4>(a, s);     //   no MFMA
         case 76: return launch_pipe<2, 2, 4, 0, 5>(a, s);     //   no epilogue

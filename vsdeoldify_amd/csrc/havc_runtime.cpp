@@ -32,6 +32,7 @@ struct havc_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_main_done = nullptr;
     hipStream_t cur = nullptr;            // stream the plan executor launches on (stream or stream2)
     bool two_streams = true;              // HAVC_TWO_STREAMS=0 serialises the two generators (A/B measurements)
+    uint64_t nt_store_bytes = 0;          // conv outputs at least this large are written with non-temporal stores (0 = never); HAVC_NT_STORE_MB
     uint64_t desc_limit = 0xE0000000ull;  // bytes one conv launch may address per operand (32-bit buffer descriptors);
                                           // HAVC_DESC_LIMIT_BYTES lowers it so tests reach the frame-chunking path at small sizes
     std::mutex mu;
@@ -302,6 +303,8 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             a.Kc = op.Kc; a.Npad = op.Npad;
             a.M = batch * op.Ho * op.Wo;   // (PS_BLUR: set below)
             a.flags = op.flags;
+            if (c->nt_store_bytes && (uint64_t)batch * n->bufdesc[op.dst].elems_per_frame * n->bufdesc[op.dst].elem_bytes >= c->nt_store_bytes)
+                a.flags |= HAVC_F_NT_STORE;
             a.pix_pitch = op.aux0;
             a.C8a = (op.aux1 > 0 && op.aux1 < op.Ci / 8) ? op.aux1 : op.Ci / 8;
             a.f0 = op.f0; a.f1 = op.f1; a.f2 = op.f2;
@@ -575,6 +578,7 @@ int havc_create(havc_ctx** out, int device_id) {
     havc_ctx* c = new havc_ctx();
     c->dev = device_id;
     if (const char* e = getenv("HAVC_TWO_STREAMS")) c->two_streams = atoi(e) != 0;
+    if (const char* e = getenv("HAVC_NT_STORE_MB")) c->nt_store_bytes = strtoull(e, nullptr, 0) << 20;
     if (const char* e = getenv("HAVC_DESC_LIMIT_BYTES")) {
         const unsigned long long v = strtoull(e, nullptr, 0);
         if (v >= 4096 && v <= 0xE0000000ull) c->desc_limit = v;
@@ -856,9 +860,9 @@ int havc_net_autotune(havc_net* n, int batch, int* n_changed) {
         auto it = seen.find(sig);
         if (it != seen.end()) { if (op.reserved != it->second) { op.reserved = it->second; ++changed; } continue; }
         std::vector<int> cand = {0};
-        if (op.Npad % 256 == 0) { cand.push_back(60); cand.push_back(71); }
+        if (op.Npad % 256 == 0) { for (int k : {60, 71, 90, 91, 96, 97}) cand.push_back(k); }
         if (op.Npad % 256 == 16) cand.push_back(61);
-        if (op.Npad % 128 == 0) { cand.push_back(70); cand.push_back(72); }
+        if (op.Npad % 128 == 0) { for (int k : {70, 72, 93, 95, 98}) cand.push_back(k); }
         if (op.Npad <= 16) cand = {0};                                     // thin N: the 128x16 kernel only
         else { cand.push_back(1); cand.push_back(2); cand.push_back(3); cand.push_back(7); }   // register-staged 128x128 / 128x64 / 64x64 / 64x128
         const int before = op.reserved;

@@ -111,6 +111,19 @@ class HAVCFrameColorizer:
         out = np.stack([self._zhang.colorize_frame(f) for f in host])
         return DeviceImage.from_numpy(self.ctx, out) if is_device(sq) else out
 
+    def _deoldify_clip(self, sq):
+        """ModelImageRender over a clip.  Frames at the model's render size (the usual case: frame_size is derived from the larger
+        render factor) run as device batches; any other size goes frame by frame through get_transformed_image, which squashes /
+        un-squashes with Pillow BILINEAR on the host exactly where the reference does (deoldify/filters.py:37-41,70-73)."""
+        from PIL import Image
+        r = self._deoldify_render()
+        S = self.deoldify_rf * 16
+        if tuple(sq.shape[1:3]) == (S, S):
+            return r.render_square_batch(sq)
+        host = sq.numpy() if is_device(sq) else sq
+        out = np.stack([np.asarray(r.get_transformed_image(Image.fromarray(f))) for f in host])
+        return DeviceImage.from_numpy(self.ctx, out) if is_device(sq) else out
+
     def frame_size(self, width):
         """__init__.py:2490-2502."""
         dd_rf = self.ddcolor_rf or min(max(math.trunc(0.4 * width / 16), 16), 32)
@@ -135,7 +148,7 @@ class HAVCFrameColorizer:
         sq = dclip if (w, h) == (fs, fs) else self._spline64(dclip, fs, fs)
         a = b = None
         if self.method != 1:
-            a = self._deoldify_render().render_square_batch(sq)
+            a = self._deoldify_clip(sq)
         if self.method != 0:
             b = self._ddcolor_clip(sq, math.trunc(dd_rf / 2) * 32)                               # vsmodels.py:302
         col = self._combine(a, b)
