@@ -304,6 +304,28 @@ int havc_dev_upload(havc_ctx* ctx, void* d_dst, const void* h_src, size_t nbytes
 int havc_dev_download(havc_ctx* ctx, void* h_dst, const void* d_src, size_t nbytes);
 int havc_dev_copy(havc_ctx* ctx, void* d_dst, const void* d_src, size_t nbytes);      /* device -> device, enqueued on the ctx stream */
 
+/* ---- ColorMNet exemplar path, first kernels (fp32, the reference's tensor layouts, host or device pointers) ----
+ * havc_memory_read_topk replaces get_similarity + do_softmax(top_k) + readout (colormnet/model/memory_util.py:7-80) as
+ * MemoryManager.match_memory calls them once per frame (colormnet/inference/memory_manager.py:58-150, top_k = 30):
+ *   mk [B][CK][N] memory keys, ms [B][N] shrinkage or NULL, qk [B][CK][HW] query keys, qe [B][CK][HW] selection or NULL,
+ *   mv [B][CV][N] memory values -> out [B][CV][HW].  The N x HW similarity lives only in the ctx workspace; the top-k softmax
+ *   uses exp(v) / sum exp(v) without max subtraction, as the reference's top-k branch does.  top_k <= 64.
+ * havc_memory_similarity returns the dense similarity [B][N][HW] (get_similarity alone; memory consolidation uses it). */
+int havc_memory_read_topk(havc_ctx* ctx, const float* mk, const float* ms, const float* qk, const float* qe, const float* mv, float* out, int B,
+                          int CK, int CV, int N, int HW, int top_k);
+int havc_memory_similarity(havc_ctx* ctx, const float* mk, const float* ms, const float* qk, const float* qe, float* sim, int B, int CK, int N, int HW);
+/* havc_local_correlation replaces the SpatialCorrelationSampler call of LocalGatedPropagation (colormnet/model/attention.py:827-835;
+ * kernel_size 1, patch_size 2 max_dis + 1, dilation_patch = dilation): q, k [n][C][H][W] ->
+ * out [n][(2 max_dis + 1)^2][H * W], out[n][(dy+R) ws + (dx+R)][y W + x] = q_scale * sum_c q[n][c][y][x] k[n][c][y + dy dil][x + dx dil], zero outside.
+ * havc_local_attention is LocalGatedPropagation.forward with use_linear=False, one head, up to agg_value (attention.py:783-856):
+ * relative_emb = conv1x1(q; rel_w [ws*ws][C], rel_b), correlation of q / sqrt(C) with k, -1e8 on window positions outside the image,
+ * softmax over the window, agg[p][n][cv] = sum_d attn[n][d][p] v[n][cv][p + d].  agg: [H*W][n][CV]; attn (may be NULL): [n][ws*ws][H*W].
+ * max_dis <= 7.  (The depthwise 5x5 conv and the projection that follow are ordinary conv ops of the plan executor.) */
+int havc_local_correlation(havc_ctx* ctx, const float* q, const float* k, float* out, int n, int C, int H, int W, int max_dis, int dilation,
+                           float q_scale);
+int havc_local_attention(havc_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_w, const float* rel_b, float* agg,
+                         float* attn, int n, int C, int CV, int H, int W, int max_dis, int dilation);
+
 /* timing of the dominant kernel for bench.py's roofline object: average duration (ms) and launch count
  * of HAVC_OP_CONV ops with the given tag over the launches since havc_reset_stats (HIP events on the
  * ctx stream are recorded around those launches only while enabled). */

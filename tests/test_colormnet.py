@@ -1,0 +1,101 @@
+"""ColorMNet memory kernels.  CPU: the oracle against vectors produced by EXECUTING the reference
+(tools/gen_golden_colormnet.py).  GPU: the HIP kernels against those vectors and against the oracle on other shapes."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import colormnet as O
+from tests.conftest import GOLDEN
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+@pytest.fixture(scope="module")
+def gm():
+    return np.load(os.path.join(GOLDEN, "colormnet_memory.npz"))
+
+
+@pytest.fixture(scope="module")
+def gl():
+    return np.load(os.path.join(GOLDEN, "colormnet_local.npz"))
+
+
+CASES = [("full", True, True), ("nosel", True, False), ("plain", False, False)]
+
+
+@pytest.mark.parametrize("tag,has_ms,has_qe", CASES)
+def test_oracle_memory_read_matches_reference(gm, tag, has_ms, has_qe):
+    ms, qe = (T(gm["ms"]) if has_ms else None), (T(gm["qe"]) if has_qe else None)
+    sim = O.get_similarity(T(gm["mk"]), ms, T(gm["qk"]), qe)
+    assert torch.equal(sim, T(gm[f"sim_{tag}"]))
+    aff = O.do_softmax(sim, int(gm["top_k"]))
+    assert torch.equal(aff, T(gm[f"aff_{tag}"])) and int((aff > 0).sum(1).max()) == 30
+    assert torch.allclose(O.readout(aff, T(gm["mv"])), T(gm[f"read_{tag}"]), atol=1e-6)
+    assert torch.allclose(O.do_softmax(O.get_similarity(T(gm["mk"]), T(gm["ms"]), T(gm["qk"]), T(gm["qe"]))), T(gm["aff_full_notopk"]), atol=1e-7)
+
+
+def test_oracle_local_attention_matches_reference(gl):
+    assert torch.equal(O.local_correlation(T(gl["q"]) / 8.0, T(gl["k"])), T(gl["corr_scaled"]))
+    agg, attn = O.local_attention(T(gl["q"]), T(gl["k"]), T(gl["v"]), T(gl["rel_w"]), T(gl["rel_b"]))
+    assert torch.allclose(attn, T(gl["attn"]), atol=1e-7) and torch.allclose(agg, T(gl["agg"]), atol=2e-6)
+    # every window position outside the image carries no weight; rows sum to one
+    assert torch.allclose(attn.sum(2), torch.ones_like(attn.sum(2)), atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,has_ms,has_qe", CASES)
+def test_gpu_memory_read_matches_reference_vectors(ctx, gm, tag, has_ms, has_qe):
+    from vsdeoldify_amd import colormnet as M
+    ms, qe = (gm["ms"] if has_ms else None), (gm["qe"] if has_qe else None)
+    sim = M.get_similarity(gm["mk"], ms, gm["qk"], qe)
+    assert np.allclose(sim, gm[f"sim_{tag}"], rtol=2e-5, atol=2e-5), float(np.abs(sim - gm[f"sim_{tag}"]).max())
+    got = M.match_memory_readout(gm["mk"], ms, gm["qk"], qe, gm["mv"], int(gm["top_k"]))
+    ref = gm[f"read_{tag}"]
+    assert got.shape == ref.shape and np.allclose(got, ref, rtol=1e-4, atol=1e-4), float(np.abs(got - ref).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,CK,CV,N,HW,k", [(1, 64, 512, 2000, 600, 30), (2, 32, 40, 77, 130, 30), (1, 64, 8, 20, 50, 30), (1, 16, 16, 300, 64, 5)])
+def test_gpu_memory_read_matches_oracle(ctx, B, CK, CV, N, HW, k):
+    """bigger / ragged shapes, k > N, several batches; near-ties in the top-k may pick another element of (almost) equal weight:
+    the readout is compared, not the index set"""
+    from vsdeoldify_amd import colormnet as M
+    g = torch.Generator().manual_seed(N + HW)
+    mk, qk = torch.randn(B, CK, N, generator=g) * 0.4, torch.randn(B, CK, HW, generator=g) * 0.4
+    ms, qe, mv = torch.rand(B, N, generator=g) + 1, torch.rand(B, CK, HW, generator=g), torch.randn(B, CV, N, generator=g)
+    ref = O.memory_read(mk, ms, qk, qe, mv, min(k, N))
+    got = M.match_memory_readout(mk, ms, qk, qe, mv, k)
+    assert isinstance(got, torch.Tensor) and got.shape == ref.shape
+    assert torch.allclose(got, ref, rtol=2e-4, atol=2e-4), float((got - ref).abs().max())
+
+
+@pytest.mark.gpu
+def test_gpu_local_attention_matches_reference_vectors(ctx, gl):
+    from vsdeoldify_amd import colormnet as M
+    corr = M.local_correlation(gl["q"], gl["k"], 7, 1, 1.0 / 8.0)
+    assert np.allclose(corr, gl["corr_scaled"], rtol=1e-5, atol=1e-5), float(np.abs(corr - gl["corr_scaled"]).max())
+    agg, attn = M.local_attention(gl["q"], gl["k"], gl["v"], gl["rel_w"], gl["rel_b"])
+    assert np.allclose(attn, gl["attn"], rtol=1e-4, atol=1e-6), float(np.abs(attn - gl["attn"]).max())
+    assert np.allclose(agg, gl["agg"], rtol=1e-4, atol=1e-5), float(np.abs(agg - gl["agg"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,C,Cv,h,w,R,dil", [(1, 64, 96, 23, 37, 7, 1), (2, 64, 32, 9, 8, 7, 1), (1, 32, 40, 17, 5, 3, 2), (1, 64, 33, 30, 30, 7, 1)])
+def test_gpu_local_attention_matches_oracle(ctx, n, C, Cv, h, w, R, dil):
+    """sizes that are not multiples of the 8 x 8 tile, a smaller window, dilation 2, value widths off the 32-channel chunk"""
+    from vsdeoldify_amd import colormnet as M
+    g = torch.Generator().manual_seed(h * w + Cv)
+    q, k, v = torch.randn(n, C, h, w, generator=g), torch.randn(n, C, h, w, generator=g), torch.randn(n, Cv, h, w, generator=g)
+    ws = 2 * R + 1
+    rel_w, rel_b = torch.randn(ws * ws, C, generator=g) * 0.1, torch.randn(ws * ws, generator=g) * 0.1
+    ref_agg, ref_attn = O.local_attention(q, k, v, rel_w, rel_b, R, dil)
+    agg, attn = M.local_attention(q, k, v, rel_w, rel_b, R, dil)
+    assert torch.allclose(attn, ref_attn, rtol=1e-4, atol=1e-6), float((attn - ref_attn).abs().max())
+    assert torch.allclose(agg, ref_agg, rtol=1e-4, atol=1e-5), float((agg - ref_agg).abs().max())
+    ref_c = O.local_correlation(q, k, R, dil)
+    assert torch.allclose(M.local_correlation(q, k, R, dil), ref_c, rtol=1e-5, atol=1e-5)

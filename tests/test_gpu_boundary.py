@@ -136,3 +136,39 @@ def test_pipelined_host_clip_equals_resident_clip(ctx, pinned):
         got = cc.colorize_host(frames)
     assert np.array_equal(got, want)
     assert np.array_equal(cc.colorize_host(frames[:1]), want[:1])
+
+
+def test_worker_contexts_run_concurrently_and_share_weights(ctx):
+    """VERDICT r1 #10 / SURVEY §5: VapourSynth calls the selector from several worker threads.  One context per worker (own mutex,
+    streams, workspace, activation arena), ONE packed weight blob per device: two threads colour different frames at the same
+    time and get exactly what a single thread gets; the second worker adds activations but no second copy of the weights."""
+    import threading
+    from PIL import Image
+    from tests.test_gpu_deoldify import make_frame
+    from vsdeoldify_amd import render
+    from vsdeoldify_amd.render import ModelImageRender
+    sds = {"video": synth_state_dict("wide", 1), "stable": synth_state_dict("wide", 2)}
+    frames = [make_frame(64, 200 + i) for i in range(6)]
+    ref = ModelImageRender(None, "stable", 4, 0.5, state_dicts=sds)
+    want = [np.asarray(ref.get_transformed_image(Image.fromarray(f))) for f in frames]
+    workers = [ModelImageRender(None, "stable", 4, 0.5, state_dicts=sds, worker=w) for w in (1, 2)]
+    assert workers[0].ctx is not workers[1].ctx and workers[0].ctx is not ctx
+    assert workers[0]._video.weights is workers[1]._video.weights                   # shared blob
+    w_bytes = len(workers[0]._video.gen.blob) + len(workers[0]._second.gen.blob)
+    assert workers[1].ctx.stats().bytes_resident < w_bytes                          # worker 2 holds no weights of its own
+    got, errs = {}, []
+
+    def run(w, idxs):
+        try:
+            for _ in range(3):                                                     # several rounds: overlap is certain
+                for i in idxs:
+                    got[i] = np.asarray(workers[w].get_transformed_image(Image.fromarray(frames[i])))
+        except Exception as e:                                                     # pragma: no cover
+            errs.append(e)
+    ts = [threading.Thread(target=run, args=(0, [0, 2, 4])), threading.Thread(target=run, args=(1, [1, 3, 5]))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert all(np.array_equal(got[i], want[i]) for i in range(6))

@@ -20,13 +20,14 @@ for _ in range(2):
 ms = np.mean([net.profile(batch) for _ in range(3)], axis=0)
 ops = net.ops
 fl = ops["flops"].astype(np.float64) * batch
+cfgs = net.cfgs()
 order = np.argsort(-ms)
 print(f"{arch} S={S} batch={batch}: total {ms.sum():.3f} ms for {fl.sum()/1e9:.1f} GFLOP -> {fl.sum()/ms.sum()/1e9:.1f} TFLOP/s, {batch/ms.sum()*1e3:.1f} passes/s")
 print(f"{'op':40s} {'ms':>8s} {'%':>6s} {'GFLOP':>9s} {'TF/s':>8s}  shape")
-for i in order[:40]:
+for i in order[:int(os.environ.get("TOP", "40"))]:
     o = ops[i]
     print(f"{net.names[i]:40s} {ms[i]:8.3f} {100*ms[i]/ms.sum():6.1f} {fl[i]/1e9:9.2f} {fl[i]/ms[i]/1e9 if ms[i]>0 else 0:8.1f}  "
-          f"t{o['type']} {o['Ci']}->{o['Npad']} k{o['kh']} s{o['stride']} {o['Hi']}x{o['Wi']}->{o['Ho']}x{o['Wo']}")
+          f"t{o['type']} {o['Ci']}->{o['Npad']} k{o['kh']} s{o['stride']} {o['Hi']}x{o['Wi']}->{o['Ho']}x{o['Wo']} cfg{cfgs[i]}")
 # group totals
 import collections
 grp = collections.OrderedDict()

@@ -105,6 +105,10 @@ SYMBOLS = [
     ("havc_deoldify_frame_planar", _I, [_P, _P, _P, _F, _I, C.POINTER(_P), _I, C.POINTER(_P), _I]),
     ("havc_planar_to_rgb8", _I, [_P, C.POINTER(_P), _I, _P, _I, _I]),
     ("havc_rgb8_to_planar", _I, [_P, _P, C.POINTER(_P), _I, _I, _I]),
+    ("havc_memory_read_topk", _I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
+    ("havc_memory_similarity", _I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
+    ("havc_local_correlation", _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F]),
+    ("havc_local_attention", _I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),
     ("havc_dev_alloc", _I, [_P, _SZ, C.POINTER(_P)]),
     ("havc_dev_free", _I, [_P, _P]),
     ("havc_dev_upload", _I, [_P, _P, _P, _SZ]),

@@ -1,0 +1,324 @@
+// ColorMNet memory kernels: the two per-frame reads of the exemplar path, fp32 like the reference tensors.
+//   memory read      colormnet/model/memory_util.py:7-80 (get_similarity + do_softmax(top_k) + readout; inference/memory_manager.py:58-150)
+//   local attention  colormnet/model/attention.py:783-856 (LocalGatedPropagation.forward; :827-835 is the local correlation the
+//                    reference takes from the CUDA-only spatial_correlation_sampler wheel)
+// Layouts are the reference's: NCHW / [B][C][N] fp32, contiguous.  None of this is GEMM-shaped enough to pay for MFMA at fp32
+// (157 TF/s = the vector rate): the similarity is a 64-deep contraction, everything else is selection / gather / window sums --
+// LDS-tiled fp32 FMA, coalesced along the query / pixel axis.
+#include "kernels.h"
+
+#include <cmath>
+
+namespace {
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- similarity[n][q] = (-sum_c mk^2 qe + 2 sum_c mk (qk qe) - sum_c qe qk^2) * ms[n] / sqrt(CK)   (memory_util.py:19-37) ----
+// Block = 64 memory entries x 64 queries, 256 threads, thread = 4 x 4 outputs; the three sums are kept apart and combined as the
+// reference combines them (-a_sq + two_ab - b_sq).
+template <bool HAS_QE>
+__global__ void __launch_bounds__(256) mem_similarity_kernel(const float* __restrict__ mk, const float* __restrict__ ms, const float* __restrict__ qk,
+                                                             const float* __restrict__ qe, float* __restrict__ sim, int CK, int N, int HW, float sqrt_ck) {
+    __shared__ float Ms[16][64 + 1], Qs[16][64 + 1], Es[16][64 + 1];
+    const int b = blockIdx.z, n0 = blockIdx.y * 64, q0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, tq = tid & 15, tn = tid >> 4;
+    const float* mkb = mk + (int64_t)b * CK * N;
+    const float* qkb = qk + (int64_t)b * CK * HW;
+    const float* qeb = HAS_QE ? qe + (int64_t)b * CK * HW : nullptr;
+    float a_sq[4][4], two_ab[4][4], b_sq[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        b_sq[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a_sq[i][j] = two_ab[i][j] = 0.f;
+    }
+    for (int c0 = 0; c0 < CK; c0 += 16) {
+        __syncthreads();
+        for (int i = tid; i < 16 * 64; i += 256) {
+            const int c = i >> 6, x = i & 63;
+            const bool cok = c0 + c < CK;
+            Ms[c][x] = (cok && n0 + x < N) ? mkb[(int64_t)(c0 + c) * N + n0 + x] : 0.f;
+            Qs[c][x] = (cok && q0 + x < HW) ? qkb[(int64_t)(c0 + c) * HW + q0 + x] : 0.f;
+            if (HAS_QE) Es[c][x] = (cok && q0 + x < HW) ? qeb[(int64_t)(c0 + c) * HW + q0 + x] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float m[4], qv[4], ev[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { m[i] = Ms[c][tn * 4 + i]; qv[i] = Qs[c][tq * 4 + i]; ev[i] = HAS_QE ? Es[c][tq * 4 + i] : 1.f; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float qe_qk = HAS_QE ? qv[j] * ev[j] : qv[j];
+                if (HAS_QE) b_sq[j] += ev[j] * (qv[j] * qv[j]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (HAS_QE) a_sq[i][j] += (m[i] * m[i]) * ev[j];
+                    else if (j == 0) a_sq[i][0] += m[i] * m[i];
+                    two_ab[i][j] += m[i] * qe_qk;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int n = n0 + tn * 4 + i;
+        if (n >= N) continue;
+        const float sc = (ms ? ms[(int64_t)b * N + n] : 1.f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + tq * 4 + j;
+            if (q >= HW) continue;
+            float s = HAS_QE ? (-a_sq[i][j] + 2.f * two_ab[i][j] - b_sq[j]) : (-a_sq[i][0] + 2.f * two_ab[i][j]);
+            s = ms ? s * sc / sqrt_ck : s / sqrt_ck;                  // `similarity * ms / math.sqrt(CK)`
+            sim[((int64_t)b * N + n) * HW + q] = s;
+        }
+    }
+}
+
+// ---- top-k over the memory axis + softmax of the kept values (memory_util.py:41-52): one thread per query, the similarity is
+// read with consecutive threads on consecutive queries (coalesced rows); the running top-k set lives in LDS ([k][thread]) with
+// its minimum cached in registers.  Output: idx [B][k][HW], w [B][k][HW] (w = exp(v) / sum exp(v), no max subtraction: the
+// reference's top-k branch has none). ----
+constexpr int TOPK_MAX = 64, TOPK_THREADS = 128;
+__global__ void __launch_bounds__(TOPK_THREADS) mem_topk_kernel(const float* __restrict__ sim, int* __restrict__ idx, float* __restrict__ wgt, int N,
+                                                                int HW, int K) {
+    extern __shared__ float sh[];                                   // val [K][T], then idx [K][T]
+    float* val = sh;
+    int* ind = reinterpret_cast<int*>(sh + K * TOPK_THREADS);
+    const int b = blockIdx.y, t = threadIdx.x, q = blockIdx.x * TOPK_THREADS + t;
+    if (q >= HW) return;
+    const float* s = sim + (int64_t)b * N * HW + q;
+    const int first = N < K ? N : K;
+    float vmin = INFINITY;
+    int pmin = 0;
+    for (int j = 0; j < first; ++j) {
+        const float v = s[(int64_t)j * HW];
+        val[j * TOPK_THREADS + t] = v;
+        ind[j * TOPK_THREADS + t] = j;
+        if (v < vmin) { vmin = v; pmin = j; }
+    }
+    for (int j = first; j < K; ++j) { val[j * TOPK_THREADS + t] = -INFINITY; ind[j * TOPK_THREADS + t] = 0; }
+    for (int n = first; n < N; ++n) {
+        const float v = s[(int64_t)n * HW];
+        if (v > vmin) {                                             // replace the current minimum, then find the new one
+            val[pmin * TOPK_THREADS + t] = v;
+            ind[pmin * TOPK_THREADS + t] = n;
+            vmin = INFINITY;
+            for (int j = 0; j < K; ++j) {
+                const float u = val[j * TOPK_THREADS + t];
+                if (u < vmin) { vmin = u; pmin = j; }
+            }
+        }
+    }
+    float sum = 0.f;
+    for (int j = 0; j < first; ++j) {
+        const float e = expf(val[j * TOPK_THREADS + t]);
+        val[j * TOPK_THREADS + t] = e;
+        sum += e;
+    }
+    for (int j = 0; j < K; ++j) {
+        const int64_t o = ((int64_t)b * K + j) * HW + q;
+        idx[o] = ind[j * TOPK_THREADS + t];
+        wgt[o] = j < first ? val[j * TOPK_THREADS + t] / sum : 0.f;
+    }
+}
+
+// ---- readout: out[cv][q] = sum_j w[j][q] mv[cv][idx[j][q]]   (memory_manager._readout on the sparse affinity) ----
+__global__ void __launch_bounds__(256) mem_readout_kernel(const float* __restrict__ mv, const int* __restrict__ idx, const float* __restrict__ wgt,
+                                                          float* __restrict__ out, int CV, int N, int HW, int K) {
+    __shared__ int si[TOPK_MAX][64];
+    __shared__ float sw[TOPK_MAX][64];
+    const int b = blockIdx.z, q0 = blockIdx.x * 64, cv0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, tq = tid & 63, tc = tid >> 6;
+    for (int i = tid; i < K * 64; i += 256) {
+        const int j = i >> 6, x = i & 63;
+        const bool ok = q0 + x < HW;
+        si[j][x] = ok ? idx[((int64_t)b * K + j) * HW + q0 + x] : 0;
+        sw[j][x] = ok ? wgt[((int64_t)b * K + j) * HW + q0 + x] : 0.f;
+    }
+    __syncthreads();
+    if (q0 + tq >= HW) return;
+    for (int c = tc; c < 64 && cv0 + c < CV; c += 4) {
+        const float* row = mv + ((int64_t)b * CV + cv0 + c) * N;
+        float acc = 0.f;
+        for (int j = 0; j < K; ++j) acc += sw[j][tq] * row[si[j][tq]];
+        out[((int64_t)b * CV + cv0 + c) * HW + q0 + tq] = acc;
+    }
+}
+
+// ---- local correlation (attention.py:827-835): out[n][(dy+R)*ws+(dx+R)][y*w+x] = sum_c q[n][c][y][x] k[n][c][y+dy*dil][x+dx*dil] ----
+// Block = 8 x 8 query pixels; K halo tile ((8 + 2 R dil)^2 pixels) staged in LDS 16 channels at a time; thread = pixel p (tid & 63)
+// and a quarter of the window rows (tid >> 6): for its rows dy it keeps the ws accumulators of one row at a time.
+constexpr int LC_T = 8, LC_CC = 16, LC_MAXWS = 15;     // window up to 15 x 15 (max_dis 7): 4 row-quarters x 15 accumulators per thread
+__global__ void __launch_bounds__(256) local_corr_kernel(const float* __restrict__ q, const float* __restrict__ k, float* __restrict__ out, int C, int H,
+                                                         int W, int R, int dil, float qscale) {
+    extern __shared__ float lds[];                                  // k tile [LC_CC][HT][HT + 1], q tile [LC_CC][64]
+    const int ws = 2 * R + 1, HT = LC_T + 2 * R * dil, HP = HT + 1;
+    float* kt = lds;
+    float* qt = lds + LC_CC * HT * HP;
+    const int n = blockIdx.z, ty0 = blockIdx.y * LC_T, tx0 = blockIdx.x * LC_T;
+    const int tid = threadIdx.x, p = tid & 63, py = p >> 3, px = p & 7, part = tid >> 6;
+    const int y = ty0 + py, x = tx0 + px;
+    const float* qb = q + (int64_t)n * C * H * W;
+    const float* kb = k + (int64_t)n * C * H * W;
+    float* ob = out + (int64_t)n * ws * ws * H * W;
+    // thread `part` owns window rows dy = part, part + 4, ... (at most 4 of the 15): all of their accumulators stay in registers
+    // while the K halo is staged ONCE per 16-channel chunk (uniform trip counts: every thread reaches every barrier)
+    float acc[4][LC_MAXWS];
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int j = 0; j < LC_MAXWS; ++j) acc[it][j] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += LC_CC) {
+        __syncthreads();
+        for (int i = tid; i < LC_CC * HT * HT; i += 256) {
+            const int c = i / (HT * HT), r = i - c * HT * HT, hy = r / HT, hx = r - hy * HT;
+            const int iy = ty0 - R * dil + hy, ix = tx0 - R * dil + hx;
+            kt[(c * HT + hy) * HP + hx] = (c0 + c < C && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? kb[((int64_t)(c0 + c) * H + iy) * W + ix] : 0.f;
+        }
+        for (int i = tid; i < LC_CC * 64; i += 256) {
+            const int c = i >> 6, pp = i & 63, yy = ty0 + (pp >> 3), xx = tx0 + (pp & 7);
+            qt[i] = (c0 + c < C && yy < H && xx < W) ? qb[((int64_t)(c0 + c) * H + yy) * W + xx] * qscale : 0.f;
+        }
+        __syncthreads();
+        for (int c = 0; c < LC_CC; ++c) {
+            const float qv = qt[c * 64 + p];
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int dyi = it * 4 + part;
+                if (dyi < ws) {
+                    const float* krow = kt + (c * HT + py + dyi * dil) * HP + px;
+#pragma unroll
+                    for (int j = 0; j < LC_MAXWS; ++j)
+                        if (j < ws) acc[it][j] += qv * krow[j * dil];
+                }
+            }
+        }
+    }
+    if (y < H && x < W) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int dyi = it * 4 + part;
+            if (dyi >= ws) continue;
+#pragma unroll
+            for (int j = 0; j < LC_MAXWS; ++j)
+                if (j < ws) ob[((int64_t)(dyi * ws + j) * H + y) * W + x] = acc[it][j];
+        }
+    }
+}
+
+// ---- logits = corr + relative_emb(q) - 1e8 [window position outside the image]; softmax over the window (attention.py:806-846) ----
+// in place on the correlation buffer [n][ws*ws][h*w]; one thread per pixel (coalesced across pixels for every window position).
+__global__ void local_softmax_kernel(float* __restrict__ qk, const float* __restrict__ q, const float* __restrict__ rel_w, const float* __restrict__ rel_b,
+                                     int C, int H, int W, int R, int dil, int n_total) {
+    const int ws = 2 * R + 1, WW = ws * ws, HWp = H * W;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n_total * HWp) return;
+    const int n = (int)(i / HWp), p = (int)(i - (int64_t)n * HWp), y = p / W, x = p - y * W;
+    float* col = qk + (int64_t)n * WW * HWp + p;
+    const float* qp = q + (int64_t)n * C * HWp + p;
+    float mx = -INFINITY;
+    for (int d = 0; d < WW; ++d) {
+        float r = rel_b[d];
+        for (int c = 0; c < C; ++c) r += rel_w[d * C + c] * qp[(int64_t)c * HWp];
+        const int yy = y + (d / ws - R) * dil, xx = x + (d % ws - R) * dil;
+        const bool inside = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        float v = col[(int64_t)d * HWp] + r;
+        if (!inside) v -= 1e8f;
+        col[(int64_t)d * HWp] = v;
+        mx = fmaxf(mx, v);
+    }
+    float sum = 0.f;
+    for (int d = 0; d < WW; ++d) {
+        const float e = expf(col[(int64_t)d * HWp] - mx);
+        col[(int64_t)d * HWp] = e;
+        sum += e;
+    }
+    const float inv = 1.f / sum;
+    for (int d = 0; d < WW; ++d) col[(int64_t)d * HWp] *= inv;
+}
+
+// ---- agg[p][n][cv] = sum_d attn[n][d][p] v[n][cv][p + d]  (local2global + matmul of attention.py:850-853, without the dense map) ----
+// Block = 8 x 8 pixels x 32 value channels; the V halo tile and the tile's attention weights are staged in LDS.
+constexpr int LA_CC = 32;
+__global__ void __launch_bounds__(256) local_agg_kernel(const float* __restrict__ attn, const float* __restrict__ v, float* __restrict__ agg, int CV, int H,
+                                                        int W, int R, int dil, int n_total) {
+    extern __shared__ float lds[];                                  // v tile [LA_CC][HT][HT + 1], attention [ws*ws][64]
+    const int ws = 2 * R + 1, WW = ws * ws, HT = LC_T + 2 * R * dil, HP = HT + 1, HWp = H * W;
+    float* vt = lds;
+    float* at = lds + LA_CC * HT * HP;
+    const int tiles_x = (W + LC_T - 1) / LC_T;
+    const int n = blockIdx.z, ty0 = (blockIdx.x / tiles_x) * LC_T, tx0 = (blockIdx.x % tiles_x) * LC_T, c0 = blockIdx.y * LA_CC;
+    const int tid = threadIdx.x, p = tid & 63, py = p >> 3, px = p & 7, cg = tid >> 6;
+    const float* vb = v + (int64_t)n * CV * HWp;
+    for (int i = tid; i < LA_CC * HT * HT; i += 256) {
+        const int c = i / (HT * HT), r = i - c * HT * HT, hy = r / HT, hx = r - hy * HT;
+        const int iy = ty0 - R * dil + hy, ix = tx0 - R * dil + hx;
+        vt[(c * HT + hy) * HP + hx] = (c0 + c < CV && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? vb[((int64_t)(c0 + c) * H + iy) * W + ix] : 0.f;
+    }
+    for (int i = tid; i < WW * 64; i += 256) {
+        const int d = i >> 6, pp = i & 63, yy = ty0 + (pp >> 3), xx = tx0 + (pp & 7);
+        at[i] = (yy < H && xx < W) ? attn[((int64_t)n * WW + d) * HWp + yy * W + xx] : 0.f;
+    }
+    __syncthreads();
+    const int y = ty0 + py, x = tx0 + px;
+    float acc[LA_CC / 4];
+#pragma unroll
+    for (int e = 0; e < LA_CC / 4; ++e) acc[e] = 0.f;
+    for (int d = 0; d < WW; ++d) {
+        const float a = at[d * 64 + p];
+        const int off = (py + (d / ws) * dil) * HP + px + (d % ws) * dil;
+#pragma unroll
+        for (int e = 0; e < LA_CC / 4; ++e) acc[e] += a * vt[(cg * (LA_CC / 4) + e) * HT * HP + off];
+    }
+    if (y < H && x < W) {
+#pragma unroll
+        for (int e = 0; e < LA_CC / 4; ++e) {
+            const int c = c0 + cg * (LA_CC / 4) + e;
+            if (c < CV) agg[((int64_t)(y * W + x) * n_total + n) * CV + c] = acc[e];
+        }
+    }
+}
+
+}  // namespace
+
+int launch_mem_similarity(const float* mk, const float* ms, const float* qk, const float* qe, float* sim, int B, int CK, int N, int HW, hipStream_t s) {
+    dim3 grid(cdiv(HW, 64), cdiv(N, 64), B);
+    const float sq = sqrtf((float)CK);
+    if (qe) hipLaunchKernelGGL(mem_similarity_kernel<true>, grid, dim3(256), 0, s, mk, ms, qk, qe, sim, CK, N, HW, sq);
+    else hipLaunchKernelGGL(mem_similarity_kernel<false>, grid, dim3(256), 0, s, mk, ms, qk, qe, sim, CK, N, HW, sq);
+    return (int)hipGetLastError();
+}
+
+int launch_mem_topk_readout(const float* sim, const float* mv, int* idx, float* wgt, float* out, int B, int CV, int N, int HW, int K, hipStream_t s) {
+    if (K < 1 || K > TOPK_MAX) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(mem_topk_kernel, dim3(cdiv(HW, TOPK_THREADS), B), dim3(TOPK_THREADS), (size_t)K * TOPK_THREADS * 8, s, sim, idx, wgt, N, HW, K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(mem_readout_kernel, dim3(cdiv(HW, 64), cdiv(CV, 64), B), dim3(256), 0, s, mv, idx, wgt, out, CV, N, HW, K);
+    return (int)hipGetLastError();
+}
+
+int launch_local_correlation(const float* q, const float* k, float* out, int n, int C, int H, int W, int R, int dil, float qscale, hipStream_t s) {
+    const int ws = 2 * R + 1, HT = LC_T + 2 * R * dil;
+    if (ws > LC_MAXWS || R < 0 || dil < 1) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)(LC_CC * HT * (HT + 1) + LC_CC * 64) * sizeof(float);
+    if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(local_corr_kernel, dim3(cdiv(W, LC_T), cdiv(H, LC_T), n), dim3(256), lds, s, q, k, out, C, H, W, R, dil, qscale);
+    return (int)hipGetLastError();
+}
+
+int launch_local_softmax(float* qk, const float* q, const float* rel_w, const float* rel_b, int n, int C, int H, int W, int R, int dil, hipStream_t s) {
+    hipLaunchKernelGGL(local_softmax_kernel, dim3(cdiv((int64_t)n * H * W, 128)), dim3(128), 0, s, qk, q, rel_w, rel_b, C, H, W, R, dil, n);
+    return (int)hipGetLastError();
+}
+
+int launch_local_agg(const float* attn, const float* v, float* agg, int n, int CV, int H, int W, int R, int dil, hipStream_t s) {
+    const int ws = 2 * R + 1, HT = LC_T + 2 * R * dil;
+    const size_t lds = (size_t)(LA_CC * HT * (HT + 1) + ws * ws * 64) * sizeof(float);
+    if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(local_agg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(local_agg_kernel, dim3(cdiv(W, LC_T) * cdiv(H, LC_T), cdiv(CV, LA_CC), n), dim3(256), lds, s, attn, v, agg, CV, H, W, R, dil, n);
+    return (int)hipGetLastError();
+}

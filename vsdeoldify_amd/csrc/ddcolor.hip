@@ -1,6 +1,7 @@
 // HBM-bound / small kernels of the DDColor path (architecture: oracle/ddcolor.py).  NHWC fp16 activations,
 // fp32 arithmetic.  Token tensors (the 100 colour queries) use the same layout with H = 1, W = tokens.
 #include "kernels.h"
+#include <cstdlib>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
@@ -256,6 +257,86 @@ __global__ void __launch_bounds__(128) mha32_split_kernel(const half_t* __restri
         for (int e = 0; e < 32; ++e) o[2 + e] = acc[e];
     }
 }
+// ---- the key-split attention on MFMA (round 2).  Same splitting and the same {m, l, acc[32]} partial states as mha32_split_kernel
+// (mha32_merge_kernel folds them); what changes is who does the arithmetic: a block (split of 256 keys, head, frame) = 4 waves, a
+// wave owns up to two 16-query fragments.  Head dim 32 is exactly the K of v_mfma_f32_16x16x32_f16:
+//   S^T[key][query] = K[key][:] . Q[query][:]      A = K rows straight from global (16 B per lane: row = key, chunk = lane >> 4)
+//   O^T[dv][query]  = V^T[dv][key] . P^T[key][query] A = V^T from an LDS image transposed while staging, B = P from registers
+// S fragment f covers keys 32 (f >> 1) + (i >> 2) 8 + (f & 1) 4 + (i & 3) (i = MFMA row), so that a lane's eight P values of two
+// neighbouring fragments are keys lg * 8 .. + 7 of a 32-key step in natural order: the second MFMA's B operand needs no shuffle.
+typedef float float4v_dd __attribute__((ext_vector_type(4)));
+constexpr int MHA_VP = MHA_KC + 8;                 // V^T row pitch (halfs): 528 B rows spread the 16 rows of a fragment read over the banks
+__global__ void __launch_bounds__(256) mha32_split_mfma_kernel(const half_t* __restrict__ q, int q_cpitch, int q_coff, int q_tok,
+                                                               const half_t* __restrict__ kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,
+                                                               float* __restrict__ part, int heads, int Lq, int Lk, float scale) {
+    __shared__ __attribute__((aligned(16))) half_t VsT[32 * MHA_VP];
+    const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z, nsplit = gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    const int k0 = c * MHA_KC, nk = min(MHA_KC, Lk - k0);
+    const half_t* kb = kv + ((int64_t)b * kv_tok + k0) * kv_cpitch + h * 32;
+    // V tile -> LDS, transposed: thread (key, chunk) scatters its 8 channels into 8 rows
+    for (int i = tid; i < MHA_KC * 4; i += 256) {
+        const int key = i >> 2, ch = i & 3;
+        half8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (half_t)0.f;
+        if (key < nk) t = *reinterpret_cast<const half8*>(kb + (int64_t)key * kv_cpitch + v_coff + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) VsT[(ch * 8 + e) * MHA_VP + key] = t[e];
+    }
+    // K fragments of the whole split in registers: 16 fragments x 16 B per lane
+    half8 kf[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+        const int key = 32 * (f >> 1) + (lr >> 2) * 8 + (f & 1) * 4 + (lr & 3);
+        kf[f] = *reinterpret_cast<const half8*>(kb + (int64_t)min(key, nk - 1) * kv_cpitch + k_coff + lg * 8);     // masked below when key >= nk
+    }
+    __syncthreads();
+    const int nqf = (Lq + 15) / 16;
+    for (int qfi = wave; qfi < nqf; qfi += 4) {
+        const int iq = qfi * 16 + lr;
+        const half8 qv = *reinterpret_cast<const half8*>(q + ((int64_t)b * q_tok + min(iq, Lq - 1)) * q_cpitch + q_coff + h * 32 + lg * 8);
+        float4v_dd sacc[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int f = 0; f < 16; ++f) {
+            sacc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[f], qv, float4v_dd{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 32 * (f >> 1) + lg * 8 + (f & 1) * 4 + r;
+                sacc[f][r] = key < nk ? sacc[f][r] * scale : -INFINITY;
+                mx = fmaxf(mx, sacc[f][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float l = 0.f;
+        float4v_dd o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+            half8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pv = __expf(sacc[2 * s2 + (j >> 2)][j & 3] - mx);
+                l += pv;
+                pf[j] = (half_t)pv;
+            }
+            const half8 v0 = *reinterpret_cast<const half8*>(&VsT[lr * MHA_VP + s2 * 32 + lg * 8]);
+            const half8 v1 = *reinterpret_cast<const half8*>(&VsT[(16 + lr) * MHA_VP + s2 * 32 + lg * 8]);
+            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0, pf, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, pf, o1, 0, 0, 0);
+        }
+        l += __shfl_xor(l, 16);
+        l += __shfl_xor(l, 32);
+        if (iq < Lq) {
+            float* op = part + ((((int64_t)b * heads + h) * nsplit + c) * Lq + iq) * 34;
+            if (lg == 0) { op[0] = mx; op[1] = l; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { op[2 + lg * 4 + r] = o0[r]; op[2 + 16 + lg * 4 + r] = o1[r]; }
+        }
+    }
+}
+
 __global__ void mha32_merge_kernel(const float* __restrict__ part, half_t* __restrict__ o, int o_cpitch, int o_coff, int o_tok, int B, int heads,
                                    int Lq, int nsplit) {
     const int64_t total = (int64_t)B * heads * Lq * 4;                       // 4 threads per (frame, head, query): 8 channels each
@@ -287,8 +368,13 @@ int mha32_nsplit(int Lk) { return (Lk + MHA_KC - 1) / MHA_KC; }
 int launch_mha32_split(const half_t* q, int q_cpitch, int q_coff, int q_tok, const half_t* kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,
                        half_t* o, int o_cpitch, int o_coff, int o_tok, float* part, int B, int heads, int Lq, int Lk, float scale, hipStream_t s) {
     const int nsplit = mha32_nsplit(Lk);
-    hipLaunchKernelGGL(mha32_split_kernel, dim3(nsplit, heads, B), dim3(128), 0, s, q, q_cpitch, q_coff, q_tok, kv, kv_cpitch, k_coff, v_coff, kv_tok,
-                       part, heads, Lq, Lk, scale);
+    static const bool v1 = getenv("HAVC_MHA_V1") != nullptr;                  // A/B switch (profiling): the one-thread-per-query kernel
+    if (v1)
+        hipLaunchKernelGGL(mha32_split_kernel, dim3(nsplit, heads, B), dim3(128), 0, s, q, q_cpitch, q_coff, q_tok, kv, kv_cpitch, k_coff, v_coff, kv_tok,
+                           part, heads, Lq, Lk, scale);
+    else
+        hipLaunchKernelGGL(mha32_split_mfma_kernel, dim3(nsplit, heads, B), dim3(256), 0, s, q, q_cpitch, q_coff, q_tok, kv, kv_cpitch, k_coff, v_coff,
+                           kv_tok, part, heads, Lq, Lk, scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(mha32_merge_kernel, dim3(grid_for_dd((int64_t)B * heads * Lq * 4)), dim3(256), 0, s, part, o, o_cpitch, o_coff, o_tok, B, heads,

@@ -1540,6 +1540,103 @@ int havc_dev_download(havc_ctx* c, void* h_dst, const void* d_src, size_t nbytes
     return HAVC_OK;
 }
 
+// ---- ColorMNet memory kernels.  fp32 operands in the reference's layouts, host or device pointers. ----
+static int stage_in_f(havc_ctx* c, int slot, const void* p, size_t nbytes, const float** d) {
+    const uint8_t* q = nullptr;
+    int rc = stage_in(c, slot, p, nbytes, &q);
+    *d = reinterpret_cast<const float*>(q);
+    return rc;
+}
+
+int havc_memory_read_topk(havc_ctx* c, const float* mk, const float* ms, const float* qk, const float* qe, const float* mv, float* out, int B, int CK,
+                          int CV, int N, int HW, int top_k) {
+    if (!c || !mk || !qk || !mv || !out || B < 1 || CK < 1 || CV < 1 || N < 1 || HW < 1 || top_k < 1 || top_k > 64)
+        return fail(c, HAVC_E_INVALID, "memory_read_topk: bad args (top_k 1..64)");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t fmk = (size_t)B * CK * N * 4, fq = (size_t)B * CK * HW * 4, fms = (size_t)B * N * 4, fmv = (size_t)B * CV * N * 4, fo = (size_t)B * CV * HW * 4;
+    const float *d_mk, *d_ms = nullptr, *d_qk, *d_qe = nullptr, *d_mv;
+    uint8_t* d_out;
+    bool host;
+    int rc;
+    if ((rc = stage_in_f(c, 0, mk, fmk, &d_mk)) || (rc = stage_in_f(c, 1, qk, fq, &d_qk)) || (rc = stage_in_f(c, 3, mv, fmv, &d_mv)) ||
+        (ms && (rc = stage_in_f(c, 4, ms, fms, &d_ms))) || (qe && (rc = stage_in_f(c, 5, qe, fq, &d_qe))) || (rc = stage_out_ptr(c, 2, out, fo, &d_out, &host)))
+        return rc;
+    // scratch 8: similarity [B][N][HW]; 9: top-k indices; 10: top-k weights
+    if ((rc = ensure_scratch(c, 8, (size_t)B * N * HW * 4)) || (rc = ensure_scratch(c, 9, (size_t)B * top_k * HW * 4)) ||
+        (rc = ensure_scratch(c, 10, (size_t)B * top_k * HW * 4))) return rc;
+    int e = launch_mem_similarity(d_mk, d_ms, d_qk, d_qe, (float*)c->scratch[8], B, CK, N, HW, c->stream);
+    if (!e) e = launch_mem_topk_readout((const float*)c->scratch[8], d_mv, (int*)c->scratch[9], (float*)c->scratch[10], (float*)d_out, B, CV, N, HW, top_k, c->stream);
+    c->stats.launches += 3;
+    if (e) return hip_fail(c, (hipError_t)e, "memory_read_topk");
+    return stage_out(c, out, d_out, fo, host);
+}
+
+int havc_memory_similarity(havc_ctx* c, const float* mk, const float* ms, const float* qk, const float* qe, float* sim, int B, int CK, int N, int HW) {
+    if (!c || !mk || !qk || !sim || B < 1 || CK < 1 || N < 1 || HW < 1) return fail(c, HAVC_E_INVALID, "memory_similarity: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t fmk = (size_t)B * CK * N * 4, fq = (size_t)B * CK * HW * 4, fms = (size_t)B * N * 4, fo = (size_t)B * N * HW * 4;
+    const float *d_mk, *d_ms = nullptr, *d_qk, *d_qe = nullptr;
+    uint8_t* d_out;
+    bool host;
+    int rc;
+    if ((rc = stage_in_f(c, 0, mk, fmk, &d_mk)) || (rc = stage_in_f(c, 1, qk, fq, &d_qk)) || (ms && (rc = stage_in_f(c, 4, ms, fms, &d_ms))) ||
+        (qe && (rc = stage_in_f(c, 5, qe, fq, &d_qe))) || (rc = stage_out_ptr(c, 2, sim, fo, &d_out, &host))) return rc;
+    int e = launch_mem_similarity(d_mk, d_ms, d_qk, d_qe, (float*)d_out, B, CK, N, HW, c->stream);
+    c->stats.launches++;
+    if (e) return hip_fail(c, (hipError_t)e, "memory_similarity");
+    return stage_out(c, sim, d_out, fo, host);
+}
+
+int havc_local_correlation(havc_ctx* c, const float* q, const float* k, float* out, int n, int C, int H, int W, int max_dis, int dilation, float q_scale) {
+    if (!c || !q || !k || !out || n < 1 || C < 1 || H < 1 || W < 1 || max_dis < 0 || max_dis > 7 || dilation < 1)
+        return fail(c, HAVC_E_INVALID, "local_correlation: bad args (max_dis 0..7, dilation >= 1)");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const int ws = 2 * max_dis + 1;
+    const size_t fi = (size_t)n * C * H * W * 4, fo = (size_t)n * ws * ws * H * W * 4;
+    const float *d_q, *d_k;
+    uint8_t* d_out;
+    bool host;
+    int rc;
+    if ((rc = stage_in_f(c, 0, q, fi, &d_q)) || (rc = stage_in_f(c, 1, k, fi, &d_k)) || (rc = stage_out_ptr(c, 2, out, fo, &d_out, &host))) return rc;
+    int e = launch_local_correlation(d_q, d_k, (float*)d_out, n, C, H, W, max_dis, dilation, q_scale, c->stream);
+    c->stats.launches++;
+    if (e) return hip_fail(c, (hipError_t)e, "local_correlation");
+    return stage_out(c, out, d_out, fo, host);
+}
+
+int havc_local_attention(havc_ctx* c, const float* q, const float* k, const float* v, const float* rel_w, const float* rel_b, float* agg, float* attn,
+                         int n, int C, int CV, int H, int W, int max_dis, int dilation) {
+    if (!c || !q || !k || !v || !rel_w || !rel_b || !agg || n < 1 || C < 1 || CV < 1 || H < 1 || W < 1 || max_dis < 0 || max_dis > 7 || dilation < 1)
+        return fail(c, HAVC_E_INVALID, "local_attention: bad args (max_dis 0..7, dilation >= 1)");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const int ws = 2 * max_dis + 1, WW = ws * ws;
+    const size_t fi = (size_t)n * C * H * W * 4, fv = (size_t)n * CV * H * W * 4, fa = (size_t)n * WW * H * W * 4, fo = (size_t)H * W * n * CV * 4;
+    const float *d_q, *d_k, *d_v, *d_rw, *d_rb;
+    uint8_t *d_agg, *d_attn;
+    bool host_agg, host_attn = false;
+    int rc;
+    if ((rc = stage_in_f(c, 0, q, fi, &d_q)) || (rc = stage_in_f(c, 1, k, fi, &d_k)) || (rc = stage_in_f(c, 3, v, fv, &d_v)) ||
+        (rc = stage_in_f(c, 4, rel_w, (size_t)WW * C * 4, &d_rw)) || (rc = stage_in_f(c, 5, rel_b, (size_t)WW * 4, &d_rb)) ||
+        (rc = stage_out_ptr(c, 2, agg, fo, &d_agg, &host_agg))) return rc;
+    if (attn) { if ((rc = stage_out_ptr(c, 8, attn, fa, &d_attn, &host_attn))) return rc; }
+    else { if ((rc = ensure_scratch(c, 8, fa))) return rc; d_attn = (uint8_t*)c->scratch[8]; }
+    // q / T with T = sqrt(d_att) = sqrt(C) (attention.py:742, 809); the relative embedding is taken from the UNSCALED q (:806)
+    int e = launch_local_correlation(d_q, d_k, (float*)d_attn, n, C, H, W, max_dis, dilation, 1.0f / sqrtf((float)C), c->stream);
+    if (!e) e = launch_local_softmax((float*)d_attn, d_q, d_rw, d_rb, n, C, H, W, max_dis, dilation, c->stream);
+    if (!e) e = launch_local_agg((const float*)d_attn, d_v, (float*)d_agg, n, CV, H, W, max_dis, dilation, c->stream);
+    c->stats.launches += 3;
+    if (e) return hip_fail(c, (hipError_t)e, "local_attention");
+    if (attn && host_attn) {
+        HIP_TRY(c, hipMemcpyAsync(attn, d_attn, fa, hipMemcpyDeviceToHost, c->stream));
+        if (!host_agg) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return stage_out(c, agg, d_agg, fo, host_agg);
+}
+
 int havc_dev_copy(havc_ctx* c, void* d_dst, const void* d_src, size_t nbytes) {
     if (!c || !d_dst || !d_src) return HAVC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);

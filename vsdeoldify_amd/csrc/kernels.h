@@ -130,3 +130,10 @@ int launch_restore_color_gradient(const uint8_t* color, const uint8_t* gray, uin
 int launch_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int n_frames, float* tmp,
                          const int* h_start, const float* h_w, int h_taps, const int* v_start, const float* v_w,
                          int v_taps, const uint8_t* orig, hipStream_t s);
+
+// ---- ColorMNet memory kernels (colormnet.hip) ----
+int launch_mem_similarity(const float* mk, const float* ms, const float* qk, const float* qe, float* sim, int B, int CK, int N, int HW, hipStream_t s);
+int launch_mem_topk_readout(const float* sim, const float* mv, int* idx, float* wgt, float* out, int B, int CV, int N, int HW, int K, hipStream_t s);
+int launch_local_correlation(const float* q, const float* k, float* out, int n, int C, int H, int W, int R, int dil, float qscale, hipStream_t s);
+int launch_local_softmax(float* qk, const float* q, const float* rel_w, const float* rel_b, int n, int C, int H, int W, int R, int dil, hipStream_t s);
+int launch_local_agg(const float* attn, const float* v, float* agg, int n, int CV, int H, int W, int R, int dil, hipStream_t s);

@@ -23,13 +23,29 @@ RENDER_BASE = 16                      # ColorizerFilter.render_base, deoldify/fi
 _contexts = {}
 
 
-def get_context(device_index=0):
-    """One havc context per GPU (process-wide), like device.set(DeviceId(n)) (deoldify/_device.py:21-30)."""
+def get_context(device_index=0, worker=0):
+    """One havc context per (GPU, worker), process-wide, like device.set(DeviceId(n)) (deoldify/_device.py:21-30).
+    A context serialises its calls behind one mutex and owns its streams, workspace and activation arenas, so VapourSynth worker
+    threads that should colour frames CONCURRENTLY on one GPU take one context each (`worker` = 0, 1, ...).  Packed weights are
+    shared between the workers of a device (`_shared_weights`): only the activations (~1.1 GB per frame at 560x560) are per worker."""
     if device_index == 99:
         raise nat.NativeLibraryError("device_index=99 (CPU) is not supported by vsdeoldify_amd: MI355X only")
-    if device_index not in _contexts:
-        _contexts[device_index] = nat.Context(device_index)
-    return _contexts[device_index]
+    key = (device_index, worker)
+    if key not in _contexts:
+        _contexts[key] = nat.Context(device_index)
+    return _contexts[key]
+
+
+_weights_cache = {}          # (device, arch, fusion flags, id of the state dict / path) -> (generator, device weights)
+
+
+def _shared_weights(ctx, key, make_generator):
+    """pack + upload a model once per device; every worker context of that device builds its nets on the same blob (read-only)"""
+    full = (ctx.device_id,) + key
+    if full not in _weights_cache:
+        gen = make_generator()
+        _weights_cache[full] = (gen, nat.Weights(ctx, gen.blob))
+    return _weights_cache[full]
 
 
 def _load_pth(path):
@@ -41,10 +57,16 @@ def _load_pth(path):
 class GeneratorRuntime:
     """Packed weights on one GPU + a cache of nets keyed by (render size, max_batch)."""
 
-    def __init__(self, ctx, state_dict, arch, fuse_final=True, fuse_blur=True, generator=None):
+    def __init__(self, ctx, state_dict, arch, fuse_final=True, fuse_blur=True, generator=None, share_key=None):
         self.ctx, self.arch = ctx, arch
-        self.gen = generator or DeoldifyGenerator(state_dict, arch, fuse_final=fuse_final, fuse_blur=fuse_blur)
-        self.weights = nat.Weights(ctx, self.gen.blob)
+        if share_key is not None:              # worker contexts of one device: one packed blob for all of them
+            self.gen, self.weights = _shared_weights(ctx, (arch, fuse_final, fuse_blur) + tuple(share_key), lambda: generator or DeoldifyGenerator(
+                state_dict, arch, fuse_final=fuse_final, fuse_blur=fuse_blur))
+            self._owns_weights = False
+        else:
+            self.gen = generator or DeoldifyGenerator(state_dict, arch, fuse_final=fuse_final, fuse_blur=fuse_blur)
+            self.weights = nat.Weights(ctx, self.gen.blob)
+            self._owns_weights = True
         self.nets = {}
 
     def net(self, S, max_batch=1):
@@ -62,20 +84,24 @@ class GeneratorRuntime:
         for n in self.nets.values():
             n.close()
         self.nets.clear()
-        self.weights.close()
+        if self._owns_weights:
+            self.weights.close()
 
 
 class ModelImageRender:
     """Drop-in for vsdeoldify.deoldify.visualize.ModelImageRender."""
 
     def __init__(self, package_dir=None, modelname="video", render_factor=24, video_weight=0, device_index=0,
-                 state_dicts=None, max_batch=1):
+                 state_dicts=None, max_batch=1, worker=0):
+        """`worker`: index of the per-thread context on this GPU (get_context): renders built with different worker indices run
+        concurrently from different threads and share the packed weights."""
         self.package_dir = package_dir
         self._modelname = modelname
         self._video_weight = video_weight
         self._render_factor = render_factor
         self._max_batch = max_batch
-        self.ctx = get_context(device_index)
+        self._worker = worker
+        self.ctx = get_context(device_index, worker)
         second = None if modelname == "video" else ("stable" if modelname == "stable" else "artistic")
         self._video = self._runtime("video", state_dicts)
         self._second = self._runtime(second, state_dicts) if second else None
@@ -84,14 +110,22 @@ class ModelImageRender:
         name, arch = WEIGHTS[which]
         if state_dicts is not None and which in state_dicts:
             sd = state_dicts[which]
+            if self._worker or os.environ.get("HAVC_SHARE_WEIGHTS", "0") != "0":
+                return GeneratorRuntime(self.ctx, sd, arch, share_key=("sd", id(sd)))
         else:
             path = os.path.join(str(self.package_dir), "models", name + ".pth")      # Learner.load path
             packed = os.path.splitext(path)[0] + ".havc"                             # tools/convert_weights.py output, if newer
             if os.path.isfile(packed) and (not os.path.isfile(path) or os.path.getmtime(packed) >= os.path.getmtime(path)):
-                return GeneratorRuntime(self.ctx, None, arch, generator=DeoldifyGenerator.load(packed))
+                key = ("file", packed, os.path.getmtime(packed))
+                if (self.ctx.device_id, arch, True, True) + key in _weights_cache:
+                    return GeneratorRuntime(self.ctx, None, arch, share_key=key)
+                return GeneratorRuntime(self.ctx, None, arch, generator=DeoldifyGenerator.load(packed), share_key=key)
             if not os.path.isfile(path) or os.path.getsize(path) == 0:
                 raise FileNotFoundError(f"DeOldify weights not found: {path}")
-            sd = _load_pth(path)
+            key = ("file", path, os.path.getmtime(path))
+            if (self.ctx.device_id, arch, True, True) + key in _weights_cache:
+                return GeneratorRuntime(self.ctx, None, arch, share_key=key)
+            return GeneratorRuntime(self.ctx, _load_pth(path), arch, share_key=key)
         return GeneratorRuntime(self.ctx, sd, arch)
 
     # -- raw batched entry (frames already S x S, uint8 [n,S,S,3]) ------------------------------
