@@ -37,6 +37,12 @@ for i, n in enumerate(net.names):
     a = grp.setdefault(g, [0.0, 0.0, 0]); a[0] += ms[i]; a[1] += fl[i]; a[2] += 1
 for g, (tt, f, k) in grp.items():
     print(f"{g:34s} {k:4d} ops {tt:8.3f} ms {100*tt/ms.sum():5.1f}%  {f/1e9:9.1f} GF {f/tt/1e9 if tt else 0:7.1f} TF/s")
+kinds = collections.OrderedDict()
+for i, n in enumerate(net.names):
+    if n.startswith("encoder.arch.stages.2."):
+        a = kinds.setdefault("stage2 " + n.split(".")[-1], [0.0, 0.0, 0]); a[0] += ms[i]; a[1] += fl[i]; a[2] += 1
+for g, (tt, f, k) in kinds.items():
+    print(f"{g:34s} {k:4d} ops {tt:8.3f} ms avg {1e3*tt/k:7.1f} us  {f/tt/1e9 if tt else 0:7.1f} TF/s  cfgs {sorted(set(c for c, n in zip(net.cfgs(), net.names) if n.startswith('encoder.arch.stages.2.') and n.endswith(g.split()[-1])))}")
 order = np.argsort(-ms)
 for i in order[:14]:
     o = net.plan_ops[i]
