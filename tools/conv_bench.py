@@ -11,6 +11,9 @@ from vsdeoldify_amd.render import get_context
 SHAPES = {  # name: (Cin, Cout, k, stride, pad, H, W, flags)
     "tail259": (259, 259, 3, 1, 1, 560, 560, nat.F_RELU_PRE),
     "tail256": (256, 256, 3, 1, 1, 560, 560, nat.F_RELU_PRE),
+    "tailA320": (320, 256, 3, 1, 1, 560, 560, nat.F_RELU_PRE),      # stagger experiment: no extra column fragment, 640-byte pitch
+    "tailB272": (256, 259, 3, 1, 1, 560, 560, nat.F_RELU_PRE),      #   extra column fragment, 512-byte input pitch
+    "tailC264": (259, 256, 3, 1, 1, 560, 560, nat.F_RELU_PRE),      #   no extra fragment, K = 38 stages, 640-byte pitch
     "l7conv": (320, 256, 3, 1, 1, 280, 280, nat.F_RELU_PRE | nat.F_AFFINE),
     "l6conv": (768, 512, 3, 1, 1, 140, 140, nat.F_RELU_PRE | nat.F_AFFINE),
     "l5conv": (1024, 512, 3, 1, 1, 70, 70, nat.F_RELU_PRE | nat.F_AFFINE),
