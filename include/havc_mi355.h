@@ -74,6 +74,9 @@ enum havc_op_type {
                                 then the ICNR blur -> dst [4Hi][4Wi][Co]                                              */
     HAVC_OP_PREP_DDCOLOR = 16,  /* u8 RGB -> Lab L -> RGB of Lab(L,0,0) -> imagenet normalise -> fp16 C8 (dst) and a 3-channel
                                 slice of src2 @ res_coff (the refine conv's image input)                             */
+    HAVC_OP_DWCONV7_LN = 17,    /* DWCONV7 followed by LAYERNORM of its result, one kernel (ConvNeXt block head): fields of both
+                                ops (w_off / bias_off / Kc; scale_off gamma, shift_off beta, f0 eps); Ci = 64, 192, 384, 768 or 1536.
+                                The norm reads the fp32 conv result (the two-op form rounds it to fp16 in between)      */
 };
 
 /* conv epilogue flags: v = acc + bias; RELU_PRE; v = v*scale+shift; v += residual; RELU_POST */

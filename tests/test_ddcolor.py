@@ -147,3 +147,47 @@ def test_gpu_ddcolor_full_depth_end_to_end(ctx):
         dd.rt.close()
     with pytest.raises(ValueError):
         DDColorRender(model=2, input_size=S, state_dict=sd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("C,H,W", [(192, 13, 10), (384, 8, 8), (768, 7, 9), (1536, 5, 6), (64, 3, 2)])
+def test_gpu_dwconv7_layernorm_fused_kernel(ctx, C, H, W):
+    """ConvNeXt block head (depthwise 7x7 + bias, LayerNorm over channels) as ONE kernel against torch fp32 and against the two-kernel
+    form; sizes that are not multiples of the 2 x 4 patch, every LDS weight format (fp32 up to 768 channels, fp16 above)."""
+    from vsdeoldify_amd import _native as nat
+    from vsdeoldify_amd.ddcolor_net import DDColorGenerator
+    from vsdeoldify_amd.plan import PlanBuilder, WeightPack
+    B = 3
+    r = np.random.default_rng(C + H)
+    Wt = (r.standard_normal((C, 1, 7, 7)) / 7).astype(np.float32)
+    bias, gamma, beta = (r.standard_normal(C).astype(np.float32) * s + o for s, o in ((0.1, 0), (0.2, 1), (0.1, 0)))
+    x = r.standard_normal((B, H, W, C)).astype(np.float16)
+    outs = {}
+    for fused in (True, False):
+        pack, b = WeightPack(), PlanBuilder()
+        xin, mid, y = b.tensor(H, W, C), b.tensor(H, W, C), b.tensor(H, W, C)
+        w_off, b_off, g_off, be_off = (pack.add(a) for a in (DDColorGenerator._dw_pack(Wt, xin.span), bias, gamma, beta))
+        if fused:
+            b.dwconv7_ln("dwln", xin, y, w_off, b_off, xin.span, g_off, be_off, 1e-6)
+        else:
+            b.dwconv7("dw", xin, mid, w_off, b_off, xin.span)
+            b.layernorm("ln", mid, y, g_off, be_off, 1e-6)
+        ops, bufs = b.finish()
+        wts = nat.Weights(ctx, pack.blob())
+        net = nat.Net(ctx, wts, ops, bufs, 0, 0, 0, B)
+        try:
+            full = np.zeros((B, H, W, xin.cpitch), np.float16)
+            full[..., :C] = x
+            net.upload(xin.buf, full)
+            net.run_ops(0, len(ops), B)
+            outs[fused] = net.download(y.buf, (B, H, W, y.cpitch), np.float16)[..., :C].astype(np.float32)
+        finally:
+            net.close(); wts.close()
+    xt = torch.from_numpy(x.astype(np.float32)).permute(0, 3, 1, 2)
+    wq = torch.from_numpy(Wt.astype(np.float16).astype(np.float32))
+    conv = torch.nn.functional.conv2d(xt, wq, torch.from_numpy(bias), padding=3, groups=C)
+    ref = torch.nn.functional.layer_norm(conv.permute(0, 2, 3, 1), (C,), torch.from_numpy(gamma), torch.from_numpy(beta), 1e-6).numpy()
+    err = np.abs(outs[True] - ref)
+    assert err.max() < 6e-3 and err.mean() < 6e-4, (float(err.max()), float(err.mean()))           # fp16 output rounding: |y| < 8
+    err2 = np.abs(outs[False] - ref)
+    assert err.mean() <= err2.mean() * 1.05                       # the fused form norms the fp32 conv result: never less accurate

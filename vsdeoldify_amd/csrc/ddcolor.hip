@@ -1,6 +1,7 @@
 // HBM-bound / small kernels of the DDColor path (architecture: oracle/ddcolor.py).  NHWC fp16 activations,
 // fp32 arithmetic.  Token tensors (the 100 colour queries) use the same layout with H = 1, W = tokens.
 #include "kernels.h"
+#include <atomic>
 #include <cstdlib>
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -105,6 +106,305 @@ int launch_layernorm_c(const half_t* x, half_t* y, const float* gamma, const flo
     hipLaunchKernelGGL(layernorm_c_kernel, dim3(grid_for_dd(npix, 4)), dim3(256), 0, s, x, y, gamma, beta, eps, npix, C, x_cpitch, x_coff,
                        y_cpitch, y_coff);
     return (int)hipGetLastError();
+}
+
+// ---- ConvNeXt block head in ONE kernel: depthwise 7x7 (+ bias) followed by the channel LayerNorm (convnext.py Block: dwconv, norm) ----
+// The two-kernel form above is load bound (98 16-byte loads per 392 MACs, every tap fetched again for every output) and writes /
+// re-reads the conv result.  Here a thread owns 4 channels of a 4 x 4 pixel patch: an input row segment (10 pixels) is loaded ONCE,
+// converted to fp32 once and feeds up to 4 x 7 x 4 MACs per element; the 49 x C weights sit in LDS (fp32 up to 768 channels, fp16
+// above), the MACs are v_pk_fma_f32 on channel pairs, and the next row segment is in flight while the current one is multiplied.
+// A block = all C/4 channel groups of S = 768 / (C/4) patches, so LayerNorm's per-pixel sums stay inside the block: 8-lane DPP
+// adds, then C/32 partials per pixel through LDS, summed by every thread in the same order (deterministic).  The norm works on the
+// fp32 accumulators (the unfused pair rounds the conv result to fp16 first).
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef float float4e __attribute__((ext_vector_type(4)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float dpp_sum8(float v) {          // sum over the 8-lane group of the lane, result in every lane
+    int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, t);
+    t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false);          // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, t);
+    t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false);         // row_half_mirror
+    return v + __builtin_bit_cast(float, t);
+}
+
+constexpr int DWLN_T = 4, DWLN_R = 4;
+constexpr unsigned DWLN_OOB = 0xF0000000u;        // voffset beyond every descriptor range: the buffer load returns zeros
+static inline size_t dwln_lds_bytes(int C, bool wf32, int threads) {
+    const int C4 = C / 4, S = threads / C4;
+    return (size_t)49 * C * (wf32 ? 4 : 2) + (size_t)S * (C4 / 8) * (DWLN_T * DWLN_R) * 4;
+}
+typedef unsigned int uint2e __attribute__((ext_vector_type(2)));
+
+// C4 (channel groups of 4) is a template parameter so that the 49 LDS weight offsets are immediates, not 49 live registers.
+// THREADS / PAIR: 768 threads (3 waves per SIMD, <= 168 VGPRs) with one output row per step, or 512 threads (2 per SIMD, 256 VGPRs)
+// with two output rows per step (a step then covers the LDS latency by itself) -- picked per channel count by measurement.
+template <int C4, bool WF32, int THREADS, bool PAIR>
+__global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
+                                                                   const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, float eps, half_t* __restrict__ y, int B,
+                                                                   int H, int W, unsigned x_bytes, int x_cpitch, int x_coff, int y_cpitch,
+                                                                   int y_coff, int w_pitch) {
+    constexpr int T = DWLN_T, R = DWLN_R, NP = T * R, XR = R + 6;
+    constexpr int C = C4 * 4, S = THREADS / C4, G = C4 / 8;
+    constexpr int WB = WF32 ? 16 : 8;                         // bytes of one thread's weights per tap
+    extern __shared__ __attribute__((aligned(16))) char dw_smem[];
+    const int tid = threadIdx.x;
+    const int c4 = tid % C4, strip = tid / C4;
+    const bool active = strip < S;
+    char* wbase = dw_smem + c4 * WB;                          // tap t at wbase + t * C4 * WB
+    float* red = reinterpret_cast<float*>(dw_smem + (size_t)49 * C4 * WB);
+    {   // all of a thread's weight loads in flight at once (the block has a single pass over them: a serial loop costs ~1 us per trip)
+        constexpr int NW_IT = (49 * C4 + THREADS - 1) / THREADS;
+        half4 hv[NW_IT];
+#pragma unroll
+        for (int k = 0; k < NW_IT; ++k) {
+            const int i = tid + k * THREADS, tap = i / C4, cc = i - tap * C4;
+            hv[k] = half4{0, 0, 0, 0};
+            if (i < 49 * C4) hv[k] = *reinterpret_cast<const half4*>(w + (size_t)tap * w_pitch + cc * 4);
+        }
+#pragma unroll
+        for (int k = 0; k < NW_IT; ++k) {
+            const int i = tid + k * THREADS;
+            if (i < 49 * C4) {
+                if (WF32) *reinterpret_cast<float4e*>(dw_smem + (size_t)i * 16) = __builtin_convertvector(hv[k], float4e);
+                else *reinterpret_cast<half4*>(dw_smem + (size_t)i * 8) = hv[k];
+            }
+        }
+    }
+    __syncthreads();
+    float2v bias2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (bias && active) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + c4 * 4);
+        bias2[0][0] = bv.x; bias2[0][1] = bv.y; bias2[1][0] = bv.z; bias2[1][1] = bv.w;
+    }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(x), 0, x_bytes, 0x00020000);
+    const int n_px = (W + R - 1) / R, n_py = (H + T - 1) / T;
+    const int64_t total = (int64_t)B * n_py * n_px;
+    const float inv_c = 1.0f / (float)C;
+    float* my_red = red + (size_t)(active ? strip : 0) * G * NP;
+    const unsigned pix_bytes = (unsigned)x_cpitch * 2u;
+
+    // Block -> patches: vertically adjacent patches share 6 of their 10 input rows, so every XCD (blockIdx & 7, own L2) gets ONE
+    // contiguous range of patches (whole frames at the DDColor sizes) and each of its blocks a contiguous sub-range: the 6.25x
+    // re-read of the input is then served by that XCD's L2 instead of HBM.
+    int64_t it_begin, it_end;
+    {
+        const int nb = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q = nb >> 3, rem = nb & 7;
+        const int pid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (orig >> 3);
+        const int64_t iters = (total + S - 1) / S, per = (iters + nb - 1) / nb;
+        it_begin = (int64_t)pid * per;
+        it_end = it_begin + per < iters ? it_begin + per : iters;
+    }
+    for (int64_t it = it_begin; it < it_end; ++it) {
+        const int64_t patch = it * S + strip;
+        const bool valid = active && patch < total;
+        int b = 0, ho0 = 0, wo0 = 0;
+        if (valid) {
+            const int px = (int)(patch % n_px);
+            const int64_t q = patch / n_px;
+            const int py = (int)(q % n_py);
+            b = (int)(q / n_py);
+            ho0 = py * T;
+            wo0 = px * R;
+        }
+        // byte offset of (frame b, row 0, pixel wo0 - 3, this thread's channels), modulo 2^32: lanes whose column is outside the image
+        // are masked, for the others adding the column offset brings it back in range (the range check is on the final voffset)
+        const unsigned col0 = (unsigned)(((int64_t)b * H * W + (wo0 - 3)) * x_cpitch + x_coff + c4 * 4) * 2u;
+        unsigned colmask = 0;                                  // bit j: input column wo0 - 3 + j is inside the image
+#pragma unroll
+        for (int j = 0; j < XR; ++j) colmask |= ((unsigned)(wo0 + j - 3) < (unsigned)W ? 1u : 0u) << j;
+        if (!valid) colmask = 0;
+        auto load_row = [&](int r, uint2e (&dst)[XR]) {
+            const int hi = ho0 + r - 3;
+            const bool rok = (unsigned)hi < (unsigned)H;
+            const unsigned rowoff = col0 + (unsigned)hi * (unsigned)W * pix_bytes;
+#pragma unroll
+            for (int j = 0; j < XR; ++j)
+                dst[j] = __builtin_amdgcn_raw_buffer_load_b64(rx, (rok && ((colmask >> j) & 1)) ? rowoff + (unsigned)j * pix_bytes : DWLN_OOB, 0, 0);
+        };
+        float2v acc[T][R][2];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < R; ++j) { acc[t][j][0] = bias2[0]; acc[t][j][1] = bias2[1]; }
+        auto wread = [&](const char* p) -> float4e {
+            if (WF32) return *reinterpret_cast<const float4e*>(p);
+            return __builtin_convertvector(*reinterpret_cast<const half4*>(p), float4e);
+        };
+        uint2e nxt[XR];
+        load_row(0, nxt);
+        // Per input row: convert it, start the loads of the next one, then for every output row t it feeds (tap row dy = r - t) seven
+        // steps of one LDS weight read (issued one step ahead) + 2R packed FMAs.  The sched_barriers pin that order: left alone,
+        // the scheduler hoists every weight read of the row and spills.
+#pragma unroll 1
+        for (int r = 0; r < T + 6; ++r) {
+            float2v xr[XR][2];
+#pragma unroll
+            for (int j = 0; j < XR; ++j) {
+                const float4e f = __builtin_convertvector(__builtin_bit_cast(half4, nxt[j]), float4e);
+                xr[j][0][0] = f[0]; xr[j][0][1] = f[1]; xr[j][1][0] = f[2]; xr[j][1][1] = f[3];
+            }
+            if (r + 1 < T + 6) load_row(r + 1, nxt);
+            __builtin_amdgcn_sched_barrier(0);
+            // output rows in pairs: a step = two weight reads (tap rows dy and dy - 1) + 4R packed FMAs on the same pixel operands, long
+            // enough to cover the LDS latency of the reads issued one step ahead; single rows at the top / bottom of the window
+            auto one_row = [&](int t, int dy) {
+                const char* wrow = wbase + dy * (7 * C4 * WB);
+                float4e wq[2];
+                wq[0] = wread(wrow);
+#pragma unroll
+                for (int dx = 0; dx < 7; ++dx) {
+                    if (dx < 6) wq[(dx + 1) & 1] = wread(wrow + (dx + 1) * C4 * WB);
+                    const float4e f = wq[dx & 1];
+                    const float2v w0 = {f[0], f[1]}, w1 = {f[2], f[3]};
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        acc[t][j][0] = __builtin_elementwise_fma(xr[j + dx][0], w0, acc[t][j][0]);
+                        acc[t][j][1] = __builtin_elementwise_fma(xr[j + dx][1], w1, acc[t][j][1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            auto two_rows = [&](int t, int dy) {               // rows t (tap row dy) and t + 1 (tap row dy - 1)
+                const char* wrow = wbase + dy * (7 * C4 * WB);
+                float4e wa[2], wb[2];
+                wa[0] = wread(wrow);
+                wb[0] = wread(wrow - 7 * C4 * WB);
+#pragma unroll
+                for (int dx = 0; dx < 7; ++dx) {
+                    if (dx < 6) {
+                        wa[(dx + 1) & 1] = wread(wrow + (dx + 1) * C4 * WB);
+                        wb[(dx + 1) & 1] = wread(wrow + (dx + 1 - 7) * C4 * WB);
+                    }
+                    const float4e fa = wa[dx & 1], fb = wb[dx & 1];
+                    const float2v a0 = {fa[0], fa[1]}, a1 = {fa[2], fa[3]}, b0 = {fb[0], fb[1]}, b1 = {fb[2], fb[3]};
+#pragma unroll
+                    for (int j = 0; j < R; ++j) {
+                        acc[t][j][0] = __builtin_elementwise_fma(xr[j + dx][0], a0, acc[t][j][0]);
+                        acc[t][j][1] = __builtin_elementwise_fma(xr[j + dx][1], a1, acc[t][j][1]);
+                        acc[t + 1][j][0] = __builtin_elementwise_fma(xr[j + dx][0], b0, acc[t + 1][j][0]);
+                        acc[t + 1][j][1] = __builtin_elementwise_fma(xr[j + dx][1], b1, acc[t + 1][j][1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if constexpr (PAIR) {
+#pragma unroll
+                for (int t = 0; t < T; t += 2) {
+                    const int dy = r - t;                      // tap row for output row t; t + 1 uses dy - 1
+                    const bool va = dy >= 0 && dy <= 6, vb = dy - 1 >= 0 && dy - 1 <= 6;
+                    if (va && vb) two_rows(t, dy);
+                    else if (va) one_row(t, dy);
+                    else if (vb) one_row(t + 1, dy - 1);
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int dy = r - t;
+                    if (dy >= 0 && dy <= 6) one_row(t, dy);
+                }
+            }
+        }
+        // ---- LayerNorm over the C channels of each of the NP pixels (biased variance of the centred values, as F.layer_norm) ----
+        float part[NP];
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+                part[t * R + j] = dpp_sum8((acc[t][j][0][0] + acc[t][j][0][1]) + (acc[t][j][1][0] + acc[t][j][1][1]));
+        auto block_sum = [&](float (&v)[NP]) {                  // v: 8-lane sums in, per-pixel sums over all C4 groups out
+            if (active && (c4 & 7) == 0) {
+#pragma unroll
+                for (int p = 0; p < NP; p += 4) *reinterpret_cast<float4*>(my_red + (c4 >> 3) * NP + p) = float4{v[p], v[p + 1], v[p + 2], v[p + 3]};
+            }
+            __syncthreads();
+#pragma unroll
+            for (int p = 0; p < NP; ++p) v[p] = 0.f;
+#pragma unroll 4
+            for (int g = 0; g < G; ++g) {
+#pragma unroll
+                for (int p = 0; p < NP; p += 4) {
+                    const float4 q = *reinterpret_cast<const float4*>(my_red + g * NP + p);
+                    v[p] += q.x; v[p + 1] += q.y; v[p + 2] += q.z; v[p + 3] += q.w;
+                }
+            }
+            __syncthreads();
+        };
+        block_sum(part);
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                const float mean = part[t * R + j] * inv_c;
+                float sq = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    acc[t][j][k][0] -= mean;
+                    acc[t][j][k][1] -= mean;
+                    sq += acc[t][j][k][0] * acc[t][j][k][0] + acc[t][j][k][1] * acc[t][j][k][1];
+                }
+                part[t * R + j] = dpp_sum8(sq);
+            }
+        block_sum(part);
+        if (valid) {
+            const float4 g4 = *reinterpret_cast<const float4*>(gamma + c4 * 4), b4 = *reinterpret_cast<const float4*>(beta + c4 * 4);
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const int ho = ho0 + t, wo = wo0 + j;
+                    if (ho >= H || wo >= W) continue;
+                    const float rstd = 1.0f / sqrtf(part[t * R + j] * inv_c + eps);
+                    half4 o;
+                    o[0] = (half_t)(acc[t][j][0][0] * rstd * g4.x + b4.x);
+                    o[1] = (half_t)(acc[t][j][0][1] * rstd * g4.y + b4.y);
+                    o[2] = (half_t)(acc[t][j][1][0] * rstd * g4.z + b4.z);
+                    o[3] = (half_t)(acc[t][j][1][1] * rstd * g4.w + b4.w);
+                    *reinterpret_cast<half4*>(y + ((int64_t)(b * H + ho) * W + wo) * y_cpitch + y_coff + c4 * 4) = o;
+                }
+        }
+    }
+}
+bool dwconv7_ln_supported(int C) { return C == 64 || C == 192 || C == 384 || C == 768 || C == 1536; }
+
+template <int C4, bool WF32, int THREADS, bool PAIR>
+static int launch_dwln(const half_t* x, const half_t* w, const float* bias, const float* gamma, const float* beta, float eps, half_t* y, int B, int H,
+                       int W, unsigned x_bytes, int x_cpitch, int x_coff, int y_cpitch, int y_coff, int w_pitch, hipStream_t s) {
+    constexpr int S = THREADS / C4;
+    const size_t lds = dwln_lds_bytes(C4 * 4, WF32, THREADS);
+    const int64_t total = (int64_t)B * ((H + DWLN_T - 1) / DWLN_T) * ((W + DWLN_R - 1) / DWLN_R);
+    const int64_t need = (total + S - 1) / S;
+    const int grid = (int)(need < 256 ? need : 256);
+    static std::atomic<uint64_t> optin{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(optin.load(std::memory_order_acquire) & bit)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv7_ln_kernel<C4, WF32, THREADS, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        optin.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((dwconv7_ln_kernel<C4, WF32, THREADS, PAIR>), dim3(grid), dim3(THREADS), lds, s, x, w, bias, gamma, beta, eps, y, B, H, W, x_bytes,
+                       x_cpitch, x_coff, y_cpitch, y_coff, w_pitch);
+    return (int)hipGetLastError();
+}
+int launch_dwconv7_ln(const half_t* x, const half_t* w, const float* bias, const float* gamma, const float* beta, float eps, half_t* y, int B,
+                      int H, int W, int C, int x_cpitch, int x_coff, int y_cpitch, int y_coff, int w_pitch, hipStream_t s) {
+    const size_t xb = ((size_t)B * H * W * x_cpitch + x_coff) * 2;
+    if (!dwconv7_ln_supported(C) || xb >= DWLN_OOB) return (int)hipErrorInvalidValue;
+    static const int variant = [] { const char* e = getenv("HAVC_DWLN_VARIANT"); return e ? atoi(e) : 0; }();      // A/B switch (profiling)
+#define DWLN_ARGS x, w, bias, gamma, beta, eps, y, B, H, W, (unsigned)xb, x_cpitch, x_coff, y_cpitch, y_coff, w_pitch, s
+    switch (C) {
+        case 64: return launch_dwln<16, true, 768, false>(DWLN_ARGS);
+        case 192: return variant == 1 ? launch_dwln<48, true, 512, true>(DWLN_ARGS) : launch_dwln<48, true, 768, false>(DWLN_ARGS);
+        case 384: return variant == 1 ? launch_dwln<96, true, 512, true>(DWLN_ARGS) : launch_dwln<96, true, 768, false>(DWLN_ARGS);
+        case 768: return variant == 1 ? launch_dwln<192, true, 512, true>(DWLN_ARGS) : launch_dwln<192, true, 768, false>(DWLN_ARGS);
+        case 1536: return variant == 2 ? launch_dwln<384, false, 768, false>(DWLN_ARGS) : launch_dwln<384, false, 512, true>(DWLN_ARGS);
+    }
+#undef DWLN_ARGS
+    return (int)hipErrorInvalidValue;
 }
 
 // ---- multi-head attention on token / pixel buffers: O[b][q][h*D + :] = softmax_k(Q.K * scale) V, D = 32 ----

@@ -403,6 +403,13 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             e = launch_dwconv7((const half_t*)bufptr(n, op.src), wptr<half_t>(n, op.w_off), wptr<float>(n, op.bias_off), (half_t*)bufptr(n, op.dst),
                                batch, op.Hi, op.Wi, op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff, op.Kc, s);
             break;
+        case HAVC_OP_DWCONV7_LN:
+            if (op.w_off < 0 || op.scale_off < 0 || op.shift_off < 0 || !dwconv7_ln_supported(op.Ci))
+                return fail(c, HAVC_E_INVALID, "dwconv7+layernorm op: weights / gamma / beta / channel count");
+            e = launch_dwconv7_ln((const half_t*)bufptr(n, op.src), wptr<half_t>(n, op.w_off), wptr<float>(n, op.bias_off), wptr<float>(n, op.scale_off),
+                                  wptr<float>(n, op.shift_off), op.f0, (half_t*)bufptr(n, op.dst), batch, op.Hi, op.Wi, op.Ci, op.src_cpitch,
+                                  op.src_coff, op.dst_cpitch, op.dst_coff, op.Kc, s);
+            break;
         case HAVC_OP_LAYERNORM:
             if (op.scale_off < 0 || op.shift_off < 0) return fail(c, HAVC_E_INVALID, "layernorm op: gamma / beta");
             e = launch_layernorm_c((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), wptr<float>(n, op.scale_off),

@@ -95,6 +95,9 @@ int launch_planar_to_rgb8(const uint8_t* planes, uint8_t* rgb, int64_t npix, hip
 int launch_rgb8_to_planar(const uint8_t* rgb, uint8_t* planes, int64_t npix, hipStream_t s);
 int launch_dwconv7(const half_t* x, const half_t* w, const float* bias, half_t* y, int B, int H, int W, int C, int x_cpitch, int x_coff,
                    int y_cpitch, int y_coff, int w_pitch, hipStream_t s);
+bool dwconv7_ln_supported(int C);
+int launch_dwconv7_ln(const half_t* x, const half_t* w, const float* bias, const float* gamma, const float* beta, float eps, half_t* y, int B,
+                      int H, int W, int C, int x_cpitch, int x_coff, int y_cpitch, int y_coff, int w_pitch, hipStream_t s);
 int launch_layernorm_c(const half_t* x, half_t* y, const float* gamma, const float* beta, float eps, int64_t npix, int C, int x_cpitch,
                        int x_coff, int y_cpitch, int y_coff, hipStream_t s);
 int launch_mha32(const half_t* q, int q_cpitch, int q_coff, int q_tok, const half_t* kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,

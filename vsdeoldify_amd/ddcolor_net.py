@@ -14,6 +14,8 @@ How the graph maps onto the existing kernels:
 """
 import math
 
+import os
+
 import numpy as np
 
 from . import _native as nat
@@ -45,6 +47,7 @@ class DDColorGenerator:
         self.sd, self.depths, self.dec_layers = to_np(state_dict), tuple(depths), dec_layers
         self.pack, self._pc, self._vec = WeightPack(), {}, {}
         self._frozen = False
+        self.fuse_dwln = os.environ.get("HAVC_DD_FUSE_DWLN", "1") != "0"      # A/B switch: dwconv + LayerNorm as one kernel
         self.plan(64)
         self.blob = self.pack.blob()
         self._frozen = True
@@ -107,8 +110,12 @@ class DDColorGenerator:
                 p = f"{e}.stages.{i}.{j}"
                 wdw, bdw = self._vecs(p + ".dwconv", lambda p=p, x=x: (
                     self._dw_pack(sd[p + ".dwconv.weight"], x.span), sd[p + ".dwconv.bias"].astype(np.float32)))
-                b.dwconv7(p + ".dwconv", x, dbuf, wdw, bdw, x.span)
-                self._ln(b, p + ".norm", p + ".norm", dbuf, nbuf, 1e-6)
+                if self.fuse_dwln and c in (64, 192, 384, 768, 1536):          # channel counts the fused kernel is instantiated for
+                    g, be = self._vecs(p + ".norm", lambda p=p: (sd[p + ".norm.weight"].astype(np.float32), sd[p + ".norm.bias"].astype(np.float32)))
+                    b.dwconv7_ln(p + ".dwconv+norm", x, nbuf, wdw, bdw, x.span, g, be, 1e-6)
+                else:
+                    b.dwconv7(p + ".dwconv", x, dbuf, wdw, bdw, x.span)
+                    self._ln(b, p + ".norm", p + ".norm", dbuf, nbuf, 1e-6)
                 pc1 = self._lin(p + ".pwconv1", nbuf, sd[p + ".pwconv1.weight"], bias=sd[p + ".pwconv1.bias"])
                 b.conv(p + ".pwconv1", pc1, nbuf, hbuf, flags=nat.F_GELU)
                 pc2 = self._lin(p + ".pwconv2", hbuf, sd[p + ".pwconv2.weight"], bias=sd[p + ".pwconv2.bias"],

@@ -294,6 +294,13 @@ class PlanBuilder:
                         dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.span, Ho=y.H, Wo=y.W, Co=y.span, w_off=w_off, bias_off=bias_off,
                         Kc=w_pitch, kh=7, kw=7, flops=2 * x.H * x.W * x.C * 49)
 
+    def dwconv7_ln(self, name, x, y, w_off, bias_off, w_pitch, gamma_off, beta_off, eps):
+        """depthwise 7x7 + LayerNorm over the channels in one kernel (ConvNeXt block head; instantiated for the ConvNeXt widths)."""
+        assert x.span == y.span == x.C and x.C in (64, 192, 384, 768, 1536) and x.H == y.H and x.W == y.W
+        return self._op(name, type=nat.OP_DWCONV7_LN, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf, dst_coff=y.coff,
+                        dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.span, Ho=y.H, Wo=y.W, Co=y.span, w_off=w_off, bias_off=bias_off,
+                        Kc=w_pitch, kh=7, kw=7, scale_off=gamma_off, shift_off=beta_off, f0=eps, flops=2 * x.H * x.W * x.C * 49)
+
     def layernorm(self, name, x, y, gamma_off, beta_off, eps):
         assert x.C == y.C and x.H * x.W == y.H * y.W
         return self._op(name, type=nat.OP_LAYERNORM, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf, dst_coff=y.coff,
