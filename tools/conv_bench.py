@@ -14,6 +14,13 @@ SHAPES = {  # name: (Cin, Cout, k, stride, pad, H, W, flags)
     "tailA320": (320, 256, 3, 1, 1, 560, 560, nat.F_RELU_PRE),      # stagger experiment: no extra column fragment, 640-byte pitch
     "tailB272": (256, 259, 3, 1, 1, 560, 560, nat.F_RELU_PRE),      #   extra column fragment, 512-byte input pitch
     "tailC264": (259, 256, 3, 1, 1, 560, 560, nat.F_RELU_PRE),      #   no extra fragment, K = 38 stages, 640-byte pitch
+    "pw1_s0": (192, 768, 1, 1, 0, 128, 128, nat.F_GELU),           # DDColor ConvNeXt MLP (pwconv1 + GELU, pwconv2 + layer scale + residual)
+    "pw2_s0": (768, 192, 1, 1, 0, 128, 128, nat.F_AFFINE),
+    "pw1_s1": (384, 1536, 1, 1, 0, 64, 64, nat.F_GELU),
+    "pw2_s1": (1536, 384, 1, 1, 0, 64, 64, nat.F_AFFINE),
+    "pw1_s2": (768, 3072, 1, 1, 0, 32, 32, nat.F_GELU),
+    "pw1n_s2": (768, 3072, 1, 1, 0, 32, 32, 0),
+    "pw2_s2": (3072, 768, 1, 1, 0, 32, 32, nat.F_AFFINE),
     "l7conv": (320, 256, 3, 1, 1, 280, 280, nat.F_RELU_PRE | nat.F_AFFINE),
     "l6conv": (768, 512, 3, 1, 1, 140, 140, nat.F_RELU_PRE | nat.F_AFFINE),
     "l5conv": (1024, 512, 3, 1, 1, 70, 70, nat.F_RELU_PRE | nat.F_AFFINE),
@@ -84,7 +91,7 @@ if __name__ == "__main__":
     filt = sys.argv[3] if len(sys.argv) > 3 else ""
     cfgs = [int(c) for c in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
     ctx = get_context(0)
-    names = list(SHAPES) + [n + "+res" for n in SHAPES if n.startswith("e") and "c3" in n]
+    names = list(SHAPES) + [n + "+res" for n in SHAPES if (n.startswith("e") and "c3" in n) or n.startswith("pw2")]
     filts = [f for f in filt.split(",") if f]
     for name in names:
         if filts and not any(f in name for f in filts):

@@ -1,6 +1,6 @@
 """DDColor on the GPU: accuracy against the oracle at a small size and throughput / per-op profile at input_size 512
 (BASELINE.json config 3).  Usage: python tools/ddcolor_bench.py [S] [batch] [--acc]"""
-import sys, os, time
+import os, sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from vsdeoldify_amd.ddcolor import DDColorRuntime
@@ -44,6 +44,15 @@ for i, n in enumerate(net.names):
 for g, (tt, f, k) in kinds.items():
     print(f"{g:34s} {k:4d} ops {tt:8.3f} ms avg {1e3*tt/k:7.1f} us  {f/tt/1e9 if tt else 0:7.1f} TF/s  cfgs {sorted(set(c for c, n in zip(net.cfgs(), net.names) if n.startswith('encoder.arch.stages.2.') and n.endswith(g.split()[-1])))}")
 order = np.argsort(-ms)
-for i in order[:14]:
+for i in order[:int(os.environ.get('TOP', '14'))]:
     o = net.plan_ops[i]
     print(f"{net.names[i]:58s} {ms[i]:8.3f} ms  t{o['type']} {o['Ci']}->{o['Npad']} k{o['kh']} {o['Hi']}x{o['Wi']}")
+
+if os.environ.get("KINDS"):
+    import re
+    kk = collections.OrderedDict()
+    for i, n in enumerate(net.names):
+        key = re.sub(r"\.\d+", ".*", n)
+        a = kk.setdefault(key, [0.0, 0]); a[0] += ms[i]; a[1] += 1
+    for key, (tt, k) in sorted(kk.items(), key=lambda kv: -kv[1][0]):
+        print(f"{key:70s} {k:3d} ops {tt:8.3f} ms  avg {1e3*tt/k:7.1f} us")

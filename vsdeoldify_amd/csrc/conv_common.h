@@ -7,6 +7,21 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
+// GELU in its exact form 0.5 v (1 + erf(v / sqrt 2)) (nn.GELU() of the ConvNeXt block).  erf by Abramowitz & Stegun 7.1.26
+// (|error| < 1.5e-7 + the 1-ulp v_rcp / v_exp): three orders below the fp16 rounding of the stored result, and half the
+// instructions of libm's two-branch erff -- the epilogue of pwconv1 evaluates 0.4 G of these per frame.  One definition for every
+// conv kernel, so all tile configurations keep producing the same bytes.
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float x = fabsf(v) * 0.70710678118654752f;
+    const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-x * x);
+    return 0.5f * v * (1.0f + copysignf(e, v));
+}
+
 // output pixel index of GEMM row m (identity unless the conv scatters with an output step: ConvTranspose parity convs)
 __device__ __forceinline__ int64_t out_pixel(const ConvArgs& p, int m, int HoWo) {
     if (p.oss == 1) return m;
@@ -45,7 +60,7 @@ __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v a
     }
     if (p.flags & HAVC_F_GELU) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.f + erff(v[r] * 0.70710678118654752f));
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
     }
     if (p.flags & HAVC_F_AFFINE) {
         const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);

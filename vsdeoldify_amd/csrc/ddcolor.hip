@@ -53,42 +53,49 @@ int launch_dwconv7(const half_t* x, const half_t* w, const float* bias, half_t* 
     return (int)hipGetLastError();
 }
 
-// ---- LayerNorm over the C channels of every pixel / token (biased variance, two passes in registers), one wave per pixel ----
-// C <= 2048 (4 x 16-byte chunks per lane).  Channels C .. C8*8-1 (padding) are written as 0.
+// ---- LayerNorm over the C channels of every pixel / token (biased variance, two passes in registers) ----
+// LP lanes share a pixel (up to 4 16-byte chunks per lane), 64 / LP pixels per wave: C = 192 -> 8 lanes x 3 chunks, 8 pixels per wave
+// (one wave per pixel left 40 of 64 lanes idle there).  C <= 2048.  Channels C .. C8*8-1 (padding) are written as 0.
+template <int LP>
 __global__ void layernorm_c_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, int64_t npix, int C, int x_cpitch, int x_coff, int y_cpitch,
                                    int y_coff) {
-    const int lane = threadIdx.x & 63;
+    constexpr int PPW = 64 / LP;                               // pixels per wave
+    const int lane = threadIdx.x & 63, l = lane % LP, sub = lane / LP;
     const int C8 = (C + 7) / 8;
     const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t p = wave0; p < npix; p += nwaves) {
+    for (int64_t p0 = wave0 * PPW; p0 < npix; p0 += nwaves * PPW) {
+        const int64_t p = p0 + sub;
+        const bool live = p < npix;
         float v[4][8];
         float sum = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c8 = lane + k * 64;
-            if (c8 < C8) {
+            const int c8 = l + k * LP;
+            if (live && c8 < C8) {
                 const half8 h = *reinterpret_cast<const half8*>(x + p * x_cpitch + x_coff + c8 * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { v[k][e] = (c8 * 8 + e < C) ? (float)h[e] : 0.f; sum += v[k][e]; }
             }
         }
-        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+#pragma unroll
+        for (int o = LP / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         const float mean = sum / (float)C;
         float sq = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c8 = lane + k * 64;
-            if (c8 < C8)
+            const int c8 = l + k * LP;
+            if (live && c8 < C8)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (c8 * 8 + e < C) { const float d = v[k][e] - mean; sq += d * d; }
         }
-        for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+#pragma unroll
+        for (int o = LP / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
         const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int c8 = lane + k * 64;
-            if (c8 < C8) {
+            const int c8 = l + k * LP;
+            if (live && c8 < C8) {
                 half8 o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -103,8 +110,15 @@ __global__ void layernorm_c_kernel(const half_t* __restrict__ x, half_t* __restr
 int launch_layernorm_c(const half_t* x, half_t* y, const float* gamma, const float* beta, float eps, int64_t npix, int C, int x_cpitch,
                        int x_coff, int y_cpitch, int y_coff, hipStream_t s) {
     if (C > 2048) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm_c_kernel, dim3(grid_for_dd(npix, 4)), dim3(256), 0, s, x, y, gamma, beta, eps, npix, C, x_cpitch, x_coff,
-                       y_cpitch, y_coff);
+    const int need = ((C + 7) / 8 + 3) / 4;                    // lanes per pixel at 4 chunks per lane
+#define LN_LAUNCH(LP)                                                                                                                          \
+    hipLaunchKernelGGL(layernorm_c_kernel<LP>, dim3(grid_for_dd((npix + 64 / LP - 1) / (64 / LP), 4)), dim3(256), 0, s, x, y, gamma, beta, eps, npix, \
+                       C, x_cpitch, x_coff, y_cpitch, y_coff)
+    if (need <= 8) LN_LAUNCH(8);
+    else if (need <= 16) LN_LAUNCH(16);
+    else if (need <= 32) LN_LAUNCH(32);
+    else LN_LAUNCH(64);
+#undef LN_LAUNCH
     return (int)hipGetLastError();
 }
 
