@@ -74,6 +74,14 @@ enum havc_op_type {
                                 then the ICNR blur -> dst [4Hi][4Wi][Co]                                              */
     HAVC_OP_PREP_DDCOLOR = 16,  /* u8 RGB -> Lab L -> RGB of Lab(L,0,0) -> imagenet normalise -> fp16 C8 (dst) and a 3-channel
                                 slice of src2 @ res_coff (the refine conv's image input)                             */
+    HAVC_OP_FOLD_QUERIES = 18,  /* DDColor tail, step 1: M[o][c] = sum_q R[o][q] E[q][c] per frame, fp32.  src = token view of the colour
+                                embeddings E (Hi = 1, Wi = tokens per frame, Ci = channels), w_off = fp32 R [2][Kc] (Kc = row pitch,
+                                Ho = number of queries), dst = fp32 buffer [2][Ci] per frame.  Folds einsum(bqc,bchw->bqhw) and the
+                                1x1 refine conv into one 2 x C matrix (both are linear per pixel)                          */
+    HAVC_OP_SHUF4_BLUR_AB = 19, /* DDColor tail, step 3: PixelShuffle(4) + the ICNR blur of the 2-channel map that a FUSE_PROJ conv
+                                left in src (fp32 [Hi*Wi][16][2] per frame), + R_img . image + bias: src2 = fp16 image view
+                                (3 channels at res_coff, pitch res_cpitch), w_off = fp32 R_img [2][3], bias_off fp32 [2];
+                                dst = fp16 view [4Hi][4Wi] channels 0-1                                                   */
     HAVC_OP_DWCONV7_LN = 17,    /* DWCONV7 followed by LAYERNORM of its result, one kernel (ConvNeXt block head): fields of both
                                 ops (w_off / bias_off / Kc; scale_off gamma, shift_off beta, f0 eps); Ci = 64, 192, 384, 768 or 1536.
                                 The norm reads the fp32 conv result (the two-op form rounds it to fp16 in between)      */
@@ -88,6 +96,12 @@ enum havc_op_type {
 #define HAVC_F_OUT_TRANSPOSED 0x20 /* store as [b][n][pix_pitch] (V^T for attention)                       */
 #define HAVC_F_OUT_RGB8 0x40      /* SigmoidRange(f0,f1) -> *std+mean -> clamp01 -> trunc(*255) -> u8 RGB   */
 #define HAVC_F_LEAKY 0x80         /* RELU_* use LeakyReLU(f2)                                              */
+#define HAVC_F_FUSE_PROJ 0x2000   /* the conv output is NOT stored: every 256-channel column tile j of a pixel (after bias / ReLU, rounded
+                                     to fp16) is projected to 2 values with the per-frame fp32 matrix in buffer src2 ([2][256] per
+                                     frame, HAVC_OP_FOLD_QUERIES) and stored as fp32 in buffer aux0: [pixel][Npad / 256][2].
+                                     DDColor tail, step 2: einsum + refine conv applied BEFORE the shuffle / blur, which commute
+                                     with them -- the 4096-channel tensor (2.1 GB per 16 frames) never exists.  Npad % 256 == 0,
+                                     Ho * Wo % 16 == 0, no residual                                                         */
 #define HAVC_F_PS_BLUR 0x200      /* with OUT_PIXSHUF: the always-on blur of CustomPixelShuffle_ICNR (ReplicationPad(1,0,1,0) +
                                      AvgPool2d(2, 1), deoldify/unet.py:46-52) runs in the conv epilogue; the shuffled tensor is
                                      never stored.  Needs 1x1 stride-1 conv, Co % 64 == 0, weight rows packed as

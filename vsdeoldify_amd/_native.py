@@ -18,9 +18,11 @@ HAVC_OK, HAVC_E_INVALID, HAVC_E_OOM, HAVC_E_HIP, HAVC_E_NODEVICE = 0, -1, -2, -3
 OP_CONV, OP_MAXPOOL, OP_BLUR_RESIZE, OP_AFFINE, OP_ATTENTION, OP_PREP_RGB8, OP_COPY_CH = 1, 2, 3, 4, 5, 6, 7
 OP_SUBSAMPLE2, OP_PROJ2, OP_BILINEAR2, OP_PREP_LAB_L = 8, 9, 10, 11
 OP_DWCONV7, OP_LAYERNORM, OP_MHA, OP_PIXSHUF4_BLUR, OP_PREP_DDCOLOR, OP_DWCONV7_LN = 12, 13, 14, 15, 16, 17
+OP_FOLD_QUERIES, OP_SHUF4_BLUR_AB = 18, 19
 F_RELU_PRE, F_AFFINE, F_RESIDUAL, F_RELU_POST = 0x1, 0x2, 0x4, 0x8
 F_OUT_PIXSHUF, F_OUT_TRANSPOSED, F_OUT_RGB8, F_LEAKY, F_FUSE_RGB8, F_PS_BLUR = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 F_GELU, F_W_FROM_BUF = 0x400, 0x800
+F_FUSE_PROJ = 0x2000
 
 # numpy mirror of `struct havc_op` (natural C alignment; checked against sizeof in tests)
 OP_DTYPE = np.dtype([

@@ -177,6 +177,7 @@ static int pick_pipe(const ConvArgs& a) {
     if (!conv_pipe_supported(a, extra)) return 0;
     if (a.flags & HAVC_F_PS_BLUR) return extra ? 0 : 60;   // the epilogue needs the 16x16-pixel x (4 x 64)-column tile
     if (a.flags & HAVC_F_FUSE_RGB8) return 61;           // only the 256 x (256+16) tile sees every channel of a pixel
+    if (a.flags & HAVC_F_FUSE_PROJ) return (extra || a.Npad % 256) ? 0 : 60;   // the projection epilogue lives in the 256 x 256 tile
     if (a.Npad >= 256 && (a.Npad % 256 == 0 || extra)) {
         const int64_t blocks = (int64_t)((a.M + 255) / 256) * ((a.Npad - 16 * extra) / 256);
         if (blocks >= 160) return 60 + extra;
@@ -200,12 +201,13 @@ const char* conv_config_name(const ConvArgs& a) {
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {
+    if ((a.flags & HAVC_F_FUSE_PROJ) && a.cfg != 0 && a.cfg != 60) return (int)hipErrorInvalidValue;
     if (a.cfg >= 60) return launch_conv_pipe(a, a.cfg, s);
     if (a.cfg == 0) {
         const int pc = pick_pipe(a);
         if (pc) return launch_conv_pipe(a, pc, s);
     }
-    if (a.flags & (HAVC_F_FUSE_RGB8 | HAVC_F_PS_BLUR)) return (int)hipErrorInvalidValue;
+    if (a.flags & (HAVC_F_FUSE_RGB8 | HAVC_F_PS_BLUR | HAVC_F_FUSE_PROJ)) return (int)hipErrorInvalidValue;
     switch (a.cfg > 0 ? a.cfg - 1 : pick_config(a)) {
         case CFG_128x128: return launch_cfg<128, 128, 2, 2>(a, s);
         case CFG_128x64: return launch_cfg<128, 64, 2, 2>(a, s);

@@ -421,6 +421,62 @@ int launch_dwconv7_ln(const half_t* x, const half_t* w, const float* bias, const
     return (int)hipErrorInvalidValue;
 }
 
+// ---- DDColor tail: einsum(bqc,bchw->bqhw) and the 1x1 refine conv are both linear per pixel, and so are the shuffle and the blur in
+// front of them -- so they are applied in the other order.  Step 1 folds the colour embeddings E [queries][C] and the refine rows
+// R [2][queries] of a frame into ONE 2 x C matrix (fp32); step 2 is the FUSE_PROJ epilogue of the last_shuf conv (conv_pipe_epilogue
+// .inc); step 3 shuffles + blurs the resulting 2-channel map and adds the image term of the refine conv. ----
+__global__ void fold_queries_kernel(const half_t* __restrict__ e, int e_cpitch, int e_coff, int tok, const float* __restrict__ r, int r_pitch,
+                                    int nq, float* __restrict__ out, int C) {
+    const int b = blockIdx.y, c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const half_t* eb = e + (int64_t)b * tok * e_cpitch + e_coff + c;
+    float a0 = 0.f, a1 = 0.f;
+    for (int q = 0; q < nq; ++q) {
+        const float v = (float)eb[(int64_t)q * e_cpitch];
+        a0 = fmaf(r[q], v, a0);
+        a1 = fmaf(r[r_pitch + q], v, a1);
+    }
+    out[((int64_t)b * 2 + 0) * C + c] = a0;
+    out[((int64_t)b * 2 + 1) * C + c] = a1;
+}
+int launch_fold_queries(const half_t* e, int e_cpitch, int e_coff, int tok, const float* r, int r_pitch, int nq, float* out, int B, int C,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(fold_queries_kernel, dim3((C + 63) / 64, B), dim3(64), 0, s, e, e_cpitch, e_coff, tok, r, r_pitch, nq, out, C);
+    return (int)hipGetLastError();
+}
+
+// proj: fp32 [B][Hi*Wi][16][2] (sub-pixel dy*4+dx of the shuffle) -> y[b][Y][X][0..1] = 0.25 * (the 2x2 window ending at (Y, X), replicate-
+// padded on the top / left: ReplicationPad2d((1,0,1,0)) + AvgPool2d(2, 1)) + R_img . img[Y][X] + bias
+__global__ void shuf4_blur_ab_kernel(const float* __restrict__ proj, const half_t* __restrict__ img, int img_cpitch, int img_coff,
+                                     const float* __restrict__ rimg, const float* __restrict__ bias, half_t* __restrict__ y, int y_cpitch,
+                                     int y_coff, int B, int Hi, int Wi) {
+    const int Ho = Hi * 4, Wo = Wi * 4;
+    const int64_t total = (int64_t)B * Ho * Wo;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int X = (int)(i % Wo);
+        const int64_t t = i / Wo;
+        const int Y = (int)(t % Ho), b = (int)(t / Ho);
+        const int y0 = max(Y - 1, 0), x0 = max(X - 1, 0);
+        auto ld = [&](int ay, int ax) -> float2 {
+            return *reinterpret_cast<const float2*>(proj + ((((int64_t)b * Hi + (ay >> 2)) * Wi + (ax >> 2)) * 16 + (ay & 3) * 4 + (ax & 3)) * 2);
+        };
+        const float2 v00 = ld(y0, x0), v01 = ld(y0, X), v10 = ld(Y, x0), v11 = ld(Y, X);
+        const half_t* ip = img + i * img_cpitch + img_coff;
+        const float i0 = (float)ip[0], i1 = (float)ip[1], i2 = (float)ip[2];
+        const float a = (v00.x + v01.x + v10.x + v11.x) * 0.25f + (rimg[0] * i0 + rimg[1] * i1 + rimg[2] * i2) + bias[0];
+        const float bb = (v00.y + v01.y + v10.y + v11.y) * 0.25f + (rimg[3] * i0 + rimg[4] * i1 + rimg[5] * i2) + bias[1];
+        half_t* yp = y + i * y_cpitch + y_coff;
+        yp[0] = (half_t)a;
+        yp[1] = (half_t)bb;
+    }
+}
+int launch_shuf4_blur_ab(const float* proj, const half_t* img, int img_cpitch, int img_coff, const float* rimg, const float* bias, half_t* y,
+                         int y_cpitch, int y_coff, int B, int Hi, int Wi, hipStream_t s) {
+    hipLaunchKernelGGL(shuf4_blur_ab_kernel, dim3(grid_for_dd((int64_t)B * Hi * 4 * Wi * 4)), dim3(256), 0, s, proj, img, img_cpitch, img_coff, rimg,
+                       bias, y, y_cpitch, y_coff, B, Hi, Wi);
+    return (int)hipGetLastError();
+}
+
 // ---- multi-head attention on token / pixel buffers: O[b][q][h*D + :] = softmax_k(Q.K * scale) V, D = 32 ----
 // One wave per (frame, head, query); lanes stride over the keys with a private online softmax, merged at the end.
 // Q rows live at q + (b * q_stride_tok + i) * q_cpitch + q_coff + h * 32; K / V likewise with their own offsets.

@@ -290,6 +290,18 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                 a.fuse_w = a.scale; a.fuse_b = a.shift; a.scale = a.shift = nullptr;
                 a.fuse_rgb = (uint8_t*)bufptr(n, op.aux0);
             }
+            uint64_t proj_wf = 0, proj_of = 0;                 // FUSE_PROJ: bytes per frame of the projection matrix / of the output
+            if (op.flags & HAVC_F_FUSE_PROJ) {
+                if ((op.Npad & 255) || ((op.Ho * op.Wo) & 15) || (op.flags & (HAVC_F_RESIDUAL | HAVC_F_W_FROM_BUF | HAVC_F_OUT_PIXSHUF)) || op.src2 < 0 ||
+                    op.src2 >= (int)n->bufs.size() || op.aux0 < 0 || op.aux0 >= (int)n->bufs.size())
+                    return fail(c, HAVC_E_INVALID, "conv op: FUSE_PROJ needs Npad % 256 == 0, Ho*Wo % 16 == 0, a matrix buffer (src2) and an output buffer (aux0)");
+                proj_wf = (uint64_t)n->bufdesc[op.src2].elems_per_frame * n->bufdesc[op.src2].elem_bytes;
+                proj_of = (uint64_t)n->bufdesc[op.aux0].elems_per_frame * n->bufdesc[op.aux0].elem_bytes;
+                if (proj_wf != 2 * 256 * 4 || proj_of < (uint64_t)op.Ho * op.Wo * (op.Npad / 256) * 8)
+                    return fail(c, HAVC_E_INVALID, "conv op: FUSE_PROJ buffers: fp32 [2][256] matrix per frame, fp32 [Ho*Wo][Npad/256][2] output");
+                a.fuse_w = (const float*)bufptr(n, op.src2);
+                a.fuse_out = (float*)bufptr(n, op.aux0);
+            }
             a.res = (op.flags & HAVC_F_RESIDUAL) ? (const half_t*)bufptr(n, op.src2) : nullptr;
             a.y = bufptr(n, op.dst);
             a.x_cpitch = op.src_cpitch; a.x_coff = op.src_coff;
@@ -346,6 +358,10 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                     if (r0) a.res = (const half_t*)(r0 + (uint64_t)f0 * rf);
                     if (wf) a.w = (const half_t*)(w0 + (uint64_t)f0 * wf);
                     if (rgb0) a.fuse_rgb = rgb0 + (uint64_t)f0 * op.Ho * op.Wo * 3;
+                    if (proj_wf) {
+                        a.fuse_w = (const float*)((const char*)bufptr(n, op.src2) + (uint64_t)f0 * proj_wf);
+                        a.fuse_out = (float*)((char*)bufptr(n, op.aux0) + (uint64_t)f0 * proj_of);
+                    }
                     a.M = nb * rows_per_frame;
                     a.x_bytes = (unsigned)std::min<uint64_t>(xf * (uint64_t)nb + 256, 0xEFFFFFFFull);
                     e = launch_conv(a, s);
@@ -409,6 +425,21 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             e = launch_dwconv7_ln((const half_t*)bufptr(n, op.src), wptr<half_t>(n, op.w_off), wptr<float>(n, op.bias_off), wptr<float>(n, op.scale_off),
                                   wptr<float>(n, op.shift_off), op.f0, (half_t*)bufptr(n, op.dst), batch, op.Hi, op.Wi, op.Ci, op.src_cpitch,
                                   op.src_coff, op.dst_cpitch, op.dst_coff, op.Kc, s);
+            break;
+        case HAVC_OP_FOLD_QUERIES:
+            if (op.w_off < 0 || op.Ho < 1 || op.Ho > op.Kc || op.Ho > op.Wi || (op.Ci & 7) || n->bufdesc[op.dst].elem_bytes != 4 ||
+                (uint64_t)n->bufdesc[op.dst].elems_per_frame < (uint64_t)2 * op.Ci)
+                return fail(c, HAVC_E_INVALID, "fold-queries op: R weights, query count, fp32 [2][Ci] destination");
+            e = launch_fold_queries((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, op.Wi, wptr<float>(n, op.w_off), op.Kc, op.Ho,
+                                    (float*)bufptr(n, op.dst), batch, op.Ci, s);
+            break;
+        case HAVC_OP_SHUF4_BLUR_AB:
+            if (op.w_off < 0 || op.bias_off < 0 || op.src2 < 0 || n->bufdesc[op.src].elem_bytes != 4 ||
+                (uint64_t)n->bufdesc[op.src].elems_per_frame < (uint64_t)op.Hi * op.Wi * 32)
+                return fail(c, HAVC_E_INVALID, "shuffle+blur(ab) op: weights, image view, fp32 [Hi*Wi][16][2] source");
+            e = launch_shuf4_blur_ab((const float*)bufptr(n, op.src), (const half_t*)bufptr(n, op.src2), op.res_cpitch, op.res_coff,
+                                     wptr<float>(n, op.w_off), wptr<float>(n, op.bias_off), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
+                                     batch, op.Hi, op.Wi, s);
             break;
         case HAVC_OP_LAYERNORM:
             if (op.scale_off < 0 || op.shift_off < 0) return fail(c, HAVC_E_INVALID, "layernorm op: gamma / beta");
@@ -861,7 +892,7 @@ int havc_net_autotune(havc_net* n, int batch, int* n_changed) {
     const havc_stats keep = c->stats;
     for (size_t i = 0; i < n->ops.size() && rc == HAVC_OK; ++i) {
         havc_op& op = n->ops[i];
-        if (op.type != HAVC_OP_CONV || (op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_OUT_RGB8))) continue;   // one legal config each
+        if (op.type != HAVC_OP_CONV || (op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_OUT_RGB8 | HAVC_F_FUSE_PROJ))) continue;   // one legal config each
         const std::vector<int64_t> sig = {op.flags, op.Hi, op.Wi, op.Ci, op.Ho, op.Wo, op.Co, op.kh, op.kw, op.stride, op.pad, op.dil, op.Kc,
                                           op.Npad, op.src_cpitch, op.dst_cpitch, op.res_cpitch, op.aux1, op.out_step};
         auto it = seen.find(sig);

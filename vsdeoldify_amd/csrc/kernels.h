@@ -35,6 +35,7 @@ struct ConvArgs {
     const float* fuse_w;   // FUSE_RGB8: fp32 [3][Npad] weights of the fused 1x1 conv, fuse_b: its 3 biases
     const float* fuse_b;
     uint8_t* fuse_rgb;     // FUSE_RGB8: u8 RGB output [M][3]
+    float* fuse_out;       // FUSE_PROJ: fp32 output [M][Npad / 256][2]; fuse_w = fp32 [frame][2][256]
     unsigned x_bytes;      // size of the input allocation (buffer descriptor range; OOB lanes read zeros)
     unsigned w_bytes;      // Npad * Kc * 16
 };
@@ -98,6 +99,10 @@ int launch_dwconv7(const half_t* x, const half_t* w, const float* bias, half_t* 
 bool dwconv7_ln_supported(int C);
 int launch_dwconv7_ln(const half_t* x, const half_t* w, const float* bias, const float* gamma, const float* beta, float eps, half_t* y, int B,
                       int H, int W, int C, int x_cpitch, int x_coff, int y_cpitch, int y_coff, int w_pitch, hipStream_t s);
+int launch_fold_queries(const half_t* e, int e_cpitch, int e_coff, int tok, const float* r, int r_pitch, int nq, float* out, int B, int C,
+                        hipStream_t s);
+int launch_shuf4_blur_ab(const float* proj, const half_t* img, int img_cpitch, int img_coff, const float* rimg, const float* bias, half_t* y,
+                         int y_cpitch, int y_coff, int B, int Hi, int Wi, hipStream_t s);
 int launch_layernorm_c(const half_t* x, half_t* y, const float* gamma, const float* beta, float eps, int64_t npix, int C, int x_cpitch,
                        int x_coff, int y_cpitch, int y_coff, hipStream_t s);
 int launch_mha32(const half_t* q, int q_cpitch, int q_coff, int q_tok, const half_t* kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,

@@ -47,6 +47,7 @@ class DDColorGenerator:
         self.sd, self.depths, self.dec_layers = to_np(state_dict), tuple(depths), dec_layers
         self.pack, self._pc, self._vec = WeightPack(), {}, {}
         self._frozen = False
+        self.fuse_tail = os.environ.get("HAVC_DD_FUSE_TAIL", "1") != "0"      # A/B switch: einsum + refine folded into the last_shuf conv
         self.fuse_dwln = os.environ.get("HAVC_DD_FUSE_DWLN", "1") != "0"      # A/B switch: dwconv + LayerNorm as one kernel
         self.plan(64)
         self.blob = self.pack.blob()
@@ -161,10 +162,12 @@ class DDColorGenerator:
             perm = (np.arange(cps)[None, :] * 16 + np.arange(16)[:, None]).reshape(-1)
             return pack_conv(self.pack, W[perm], up.cmap, up.span, bias=sh[perm])
         pcl = self._conv(p, make_last)
-        t4 = b.tensor(up.H, up.W, pcl.Cout)
-        b.conv(p + ".conv", pcl, up, t4, flags=nat.F_RELU_PRE)
-        img_feat = b.tensor(S, S, pcl.Cout // 16)
-        b.pixshuf4_blur(p + ".shuf+blur", t4, img_feat)
+        last_in = up
+        if not self.fuse_tail:
+            t4 = b.tensor(up.H, up.W, pcl.Cout)
+            b.conv(p + ".conv", pcl, up, t4, flags=nat.F_RELU_PRE)
+            img_feat = b.tensor(S, S, pcl.Cout // 16)
+            b.pixshuf4_blur(p + ".shuf+blur", t4, img_feat)
 
         # ---- colour decoder ----
         d = "decoder.color_decoder"
@@ -235,15 +238,34 @@ class DDColorGenerator:
             nxt = tok(E)
             b.conv(key, self._lin(key, emb, sd[key + ".weight"], bias=sd[key + ".bias"]), emb, nxt, flags=nat.F_RELU_PRE if k < 2 else 0)
             emb = nxt
-        logits = View(coarse_buf, 8, coarse_pitch, S, S, QUERIES, 104)
-        b.conv_dyn(d + ".einsum", img_feat, emb, logits, QUERIES)
-
-        # ---- refine: spectral 1x1 conv on cat[logits, normalised image] ----
-        coarse = View(coarse_buf, 0, coarse_pitch, S, S, QUERIES + 3, 112, np.concatenate([8 + np.arange(QUERIES), np.arange(3)]))
-        pcr = self._conv("refine_net.0.0", lambda: pack_conv(self.pack, conv_weight(sd, "refine_net.0.0"), coarse.cmap, coarse.span,
-                                                             bias=sd["refine_net.0.0.bias"]))
         ab = b.tensor(S, S, 2)
-        b.conv("refine_net.0.0", pcr, coarse, ab)
+        if self.fuse_tail:
+            # einsum(bqc,bchw->bqhw) and the refine conv are linear per pixel and commute with the shuffle and the blur: fold the colour
+            # embeddings and the refine rows into one 2 x 256 matrix per frame, apply it to every 256-channel sub-pixel group in the
+            # epilogue of the last_shuf conv (its 4096-channel output, the shuffled / blurred 256-channel map and the 100 logit planes
+            # are never stored), then shuffle + blur the 2-channel result and add the image term of the refine conv.
+            assert pcl.Cout == 16 * E and pcl.Npad == pcl.Cout
+
+            def make_refine():
+                Wr = conv_weight(sd, "refine_net.0.0").astype(np.float32).reshape(2, QUERIES + 3)
+                rq = np.zeros((2, 104), np.float32)
+                rq[:, :QUERIES] = Wr[:, :QUERIES]
+                return rq, np.ascontiguousarray(Wr[:, QUERIES:]), sd["refine_net.0.0.bias"].astype(np.float32)
+            rq_off, rimg_off, rb_off = self._vecs("refine_net.0.0/fold", make_refine)
+            m2 = b.buf(2 * E, 4)
+            b.fold_queries(d + ".fold", emb, QUERIES, rq_off, 104, m2)
+            proj = b.buf(last_in.H * last_in.W * 16 * 2, 4)
+            b.conv(p + ".conv+proj", pcl, last_in, proj, flags=nat.F_RELU_PRE | nat.F_FUSE_PROJ, proj=(m2, proj))
+            b.shuf4_blur_ab("refine_net.0.0", proj, last_in.H, last_in.W, View(coarse_buf, 0, coarse_pitch, S, S, 3, 8), rimg_off, rb_off, ab,
+                            flops=2 * S * S * (E * QUERIES + 2 * (QUERIES + 3)))      # algorithmic work of the einsum + refine conv it stands for
+        else:
+            logits = View(coarse_buf, 8, coarse_pitch, S, S, QUERIES, 104)
+            b.conv_dyn(d + ".einsum", img_feat, emb, logits, QUERIES)
+            # ---- refine: spectral 1x1 conv on cat[logits, normalised image] ----
+            coarse = View(coarse_buf, 0, coarse_pitch, S, S, QUERIES + 3, 112, np.concatenate([8 + np.arange(QUERIES), np.arange(3)]))
+            pcr = self._conv("refine_net.0.0", lambda: pack_conv(self.pack, conv_weight(sd, "refine_net.0.0"), coarse.cmap, coarse.span,
+                                                                 bias=sd["refine_net.0.0.bias"]))
+            b.conv("refine_net.0.0", pcr, coarse, ab)
         ops, bufs = b.finish()
         return ops, bufs, in_buf, ab.buf, b.names, consts
 

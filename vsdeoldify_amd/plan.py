@@ -207,7 +207,7 @@ class PlanBuilder:
         return len(self.ops) - 1
 
     def conv(self, name, pc, x, y, stride=1, pad=0, dil=1, flags=0, res=None, tag=None, f=(0, 0, 0, 0), Co=None,
-             aux0=0, pad_w=None, out_hw=None, out_step=1, out_oy=0, out_ox=0):
+             aux0=0, pad_w=None, out_hw=None, out_step=1, out_oy=0, out_ox=0, proj=None):
         """y may be a View (fp16 NHWC / pixel-shuffled target) or a raw buffer id (RGB8 / transposed).
         out_step=2 scatters output pixel (ho, wo) to (2*ho + out_oy, 2*wo + out_ox) of y (ConvTranspose parity convs,
         which also use dil=-1, asymmetric pad (pad_w) and an explicit out_hw)."""
@@ -238,6 +238,9 @@ class PlanBuilder:
         if res is not None:
             assert flags & nat.F_RESIDUAL
             kw.update(src2=res.buf, res_coff=res.coff, res_cpitch=res.cpitch)
+        if proj is not None:                                   # (matrix buffer, output buffer) of HAVC_F_FUSE_PROJ
+            assert flags & nat.F_FUSE_PROJ and res is None and pc.Npad % 256 == 0 and (Ho * Wo) % 16 == 0
+            kw.update(src2=proj[0], aux0=proj[1], dst=proj[1], Co=pc.Npad)
         return self._op(name, tag, **kw)
 
     def maxpool(self, name, x, y):
@@ -300,6 +303,18 @@ class PlanBuilder:
         return self._op(name, type=nat.OP_DWCONV7_LN, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf, dst_coff=y.coff,
                         dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.span, Ho=y.H, Wo=y.W, Co=y.span, w_off=w_off, bias_off=bias_off,
                         Kc=w_pitch, kh=7, kw=7, scale_off=gamma_off, shift_off=beta_off, f0=eps, flops=2 * x.H * x.W * x.C * 49)
+
+    def fold_queries(self, name, emb, n_queries, r_off, r_pitch, dst_buf):
+        """M[o][c] = sum_q R[o][q] emb[q][c] (fp32 [2][C] per frame in dst_buf): einsum + refine conv folded, DDColor tail."""
+        assert emb.H == 1 and emb.span == emb.C
+        return self._op(name, type=nat.OP_FOLD_QUERIES, src=emb.buf, src_coff=emb.coff, src_cpitch=emb.cpitch, dst=dst_buf, Hi=1, Wi=emb.W,
+                        Ci=emb.C, Ho=n_queries, Wo=1, Co=emb.C, w_off=r_off, Kc=r_pitch, flops=2 * 2 * n_queries * emb.C)
+
+    def shuf4_blur_ab(self, name, proj_buf, Hi, Wi, img, rimg_off, bias_off, y, flops=0):
+        """PixelShuffle(4) + blur of the projected 2-channel map + R_img . image + bias -> y channels 0-1."""
+        assert y.H == 4 * Hi and y.W == 4 * Wi and img.H == y.H and img.W == y.W
+        return self._op(name, type=nat.OP_SHUF4_BLUR_AB, src=proj_buf, src2=img.buf, res_coff=img.coff, res_cpitch=img.cpitch, dst=y.buf,
+                        dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=Hi, Wi=Wi, Ci=2, Ho=y.H, Wo=y.W, Co=2, w_off=rimg_off, bias_off=bias_off, flops=flops)
 
     def layernorm(self, name, x, y, gamma_off, beta_off, eps):
         assert x.C == y.C and x.H * x.W == y.H * y.W
