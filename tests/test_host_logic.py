@@ -174,11 +174,26 @@ def test_ddcolor_plan_shapes_and_flops():
     from vsdeoldify_amd import _native as nat
     from vsdeoldify_amd.ddcolor_net import DDColorGenerator, TOK
     from vsdeoldify_amd.synth import synth_ddcolor_state_dict
-    g = DDColorGenerator(synth_ddcolor_state_dict(1, depths=(1, 1, 1, 1), dec_layers=3), depths=(1, 1, 1, 1), dec_layers=3)
+    sd = synth_ddcolor_state_dict(1, depths=(1, 1, 1, 1), dec_layers=3)
+    g = DDColorGenerator(sd, depths=(1, 1, 1, 1), dec_layers=3)
     ops, bufs, i, o, names, consts = g.plan(128)
     assert names[0] == "prep" and names[-1] == "refine_net.0.0"
-    e = ops[names.index("decoder.color_decoder.einsum")]
+    # default tail: einsum + refine folded into the epilogue of the last_shuf conv (no 4096-channel / logits tensors in the plan)
+    assert "decoder.color_decoder.einsum" not in names and "decoder.last_shuf.shuf+blur" not in names
+    cp = ops[names.index("decoder.last_shuf.conv+proj")]
+    assert cp["flags"] & nat.F_FUSE_PROJ and cp["Npad"] == 4096 and cp["src2"] >= 0 and cp["aux0"] >= 0
+    assert bufs[int(cp["src2"])]["elem_bytes"] == 4 and bufs[int(cp["src2"])]["elems_per_frame"] == 2 * 256
+    assert ops[names.index("decoder.color_decoder.fold")]["type"] == nat.OP_FOLD_QUERIES and ops[-1]["type"] == nat.OP_SHUF4_BLUR_AB
+    # op-by-op tail (HAVC_DD_FUSE_TAIL=0): the einsum conv reads its weights from the token buffer; same algorithmic FLOPs either way
+    os.environ["HAVC_DD_FUSE_TAIL"] = "0"
+    try:
+        g0 = DDColorGenerator(sd, depths=(1, 1, 1, 1), dec_layers=3)
+    finally:
+        os.environ.pop("HAVC_DD_FUSE_TAIL")
+    ops0, _, _, _, names0, _ = g0.plan(128)
+    e = ops0[names0.index("decoder.color_decoder.einsum")]
     assert e["flags"] & nat.F_W_FROM_BUF and e["Npad"] == TOK and e["Kc"] == 32 and e["src2"] >= 0
+    assert abs(float(ops["flops"].sum()) / float(ops0["flops"].sum()) - 1) < 1e-3
     mh = [op for op, n in zip(ops, names) if n.endswith(".attn")]
     assert len(mh) == 6 and all(op["type"] == nat.OP_MHA and op["aux1"] >= 0 for op in mh)
     assert {int(op["Ho"]) for op in mh} == {100, 8 * 8, 16 * 16, 32 * 32}                 # self-attention + the three feature levels
