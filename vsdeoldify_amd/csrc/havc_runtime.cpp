@@ -902,7 +902,9 @@ int havc_net_autotune(havc_net* n, int batch, int* n_changed) {
         // 256 x 256 tile beats every narrower one by 30 %)
         if (op.Npad % 256 == 0 || op.Npad % 256 >= 192) { for (int k : {60, 71, 90, 91, 96, 97}) cand.push_back(k); }
         if (op.Npad % 256 == 16) cand.push_back(61);
-        if (op.Npad % 128 == 0 || op.Npad % 128 >= 96) { for (int k : {70, 72, 93, 95, 98}) cand.push_back(k); }
+        // 128-wide tiles for every wide layer: the DynamicUnetDeep (artistic) channel counts 304 / 320 / 672 / 1344 fit no tile exactly and
+        // a partly empty last tile on the pipelined kernel still beats the register-staged kernels there
+        if (op.Npad % 128 == 0 || op.Npad % 128 >= 96 || op.Npad > 256) { for (int k : {70, 72, 93, 95, 98}) cand.push_back(k); }
         if (op.Npad <= 16) cand = {0};                                     // thin N: the 128x16 kernel only
         else { cand.push_back(1); cand.push_back(2); cand.push_back(3); cand.push_back(7); }   // register-staged 128x128 / 128x64 / 64x64 / 64x128
         const int before = op.reserved;
