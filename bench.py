@@ -300,6 +300,27 @@ def extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds):
     dt = time.perf_counter() - t0
     res["batch1"] = {"value": round(k / dt, 2), "unit": "frames/s", "ms_per_call": round(dt / k * 1e3, 3),
                      "how": "ModelImageRender('stable', rf=35).get_transformed_image(PIL 560x560), one blocking call per frame (H2D + 2 passes + D2H)"}
+    # ---- the same per-frame call from 16 threads (VapourSynth's worker pool) through ONE coalescing render: havc_batcher ----
+    import threading
+    T, K = 16, 6
+    rc = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, coalesce=T)
+    imgs = [Image.fromarray(np.ascontiguousarray(frames[i % len(frames)][:S, :S])) for i in range(T)]
+
+    def worker(t, n):
+        for _ in range(n):
+            rc.get_transformed_image(imgs[t])
+    for n in (1, K):                                           # warm-up round, then the timed one
+        ts = [threading.Thread(target=worker, args=(t, n)) for t in range(T)]
+        t0 = time.perf_counter()
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        dt = time.perf_counter() - t0
+    calls, batches = rc._batcher(S, True).stats()
+    res["per_frame_calls_16_threads"] = {"value": round(T * K / dt, 2), "unit": "frames/s", "calls": calls, "batches": batches,
+                                         "how": "16 Python threads, each one blocking get_transformed_image(PIL 560x560) per frame, one "
+                                                "ModelImageRender(coalesce=16): concurrent calls merged into batches by havc_batcher"}
     return res
 
 

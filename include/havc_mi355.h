@@ -208,6 +208,20 @@ int havc_net_get_cfg(havc_net* net, int op_index);
 int havc_deoldify_frames(havc_ctx* ctx, havc_net* video, havc_net* second, float video_weight, int post_process,
                          const uint8_t* rgb_in, uint8_t* rgb_out, int n_frames);
 
+/* ---- frame coalescer for the per-frame call shape --------------------------------------------------------------------------------
+ * The reference calls ModelImageRender.get_transformed_image once per frame, from the std.ModifyFrame selectors of several VapourSynth
+ * worker threads (vsslib/vsmodels.py:201-230).  havc_batcher_submit is that call for a frame already S x S (host u8 RGB in / out,
+ * blocking, thread-safe): concurrent callers are merged into ONE havc_deoldify_frames over up to max_batch frames -- the first caller to
+ * arrive leads, waits at most wait_us microseconds (or until `callers` requests are queued; 0 = until the batch is full), runs the
+ * batch and hands every caller its frame.  The bytes are those of a call of its own (results do not depend on the batch size).
+ * ctypes releases the GIL around the call, so Python threads coalesce too.  havc_batcher_free waits for callers in flight. */
+typedef struct havc_batcher havc_batcher;
+int havc_batcher_create(havc_ctx* ctx, havc_net* video, havc_net* second, float video_weight, int post_process, int wait_us, int callers,
+                        havc_batcher** out);
+int havc_batcher_submit(havc_batcher* b, const uint8_t* rgb_in, uint8_t* rgb_out);
+int havc_batcher_stats(havc_batcher* b, int64_t* calls, int64_t* batches);
+void havc_batcher_free(havc_batcher* b);
+
 /* havc_zhang_frames replaces ModelColorization.colorize_frame (colorization/__init__.py:76-95) with
  * preprocess_img / postprocess_tens (colorization/colorizers/util.py:25-55): PIL BICUBIC squash to 256x256, skimage
  * rgb2lab L of the original and of the squashed frame, eccv16 / siggraph17 forward at 256x256 (the plan of `net`),

@@ -172,3 +172,43 @@ def test_worker_contexts_run_concurrently_and_share_weights(ctx):
         t.join()
     assert not errs, errs
     assert all(np.array_equal(got[i], want[i]) for i in range(6))
+
+
+def test_coalesced_per_frame_calls_match_separate_calls(ctx):
+    """The reference's call shape is ONE get_transformed_image per frame from each VapourSynth worker thread.  A render built with
+    coalesce=N merges the concurrent calls of N threads into batches (havc_batcher): every caller gets exactly the bytes of a call of
+    its own, and fewer batches than calls were run."""
+    import threading
+    from PIL import Image
+    from tests.test_gpu_deoldify import make_frame
+    from vsdeoldify_amd.render import ModelImageRender
+    sds = {"video": synth_state_dict("wide", 1), "stable": synth_state_dict("wide", 2)}
+    T, K = 6, 4
+    frames = [make_frame(64, 300 + i) for i in range(T * K)]
+    ref = ModelImageRender(None, "stable", 4, 0.5, state_dicts=sds)
+    want = [np.asarray(ref.get_transformed_image(Image.fromarray(f))) for f in frames]
+    shared = ModelImageRender(None, "stable", 4, 0.5, state_dicts=sds, coalesce=T)
+    got, errs = {}, []
+
+    def run(t):
+        try:
+            for k in range(K):
+                i = t * K + k
+                got[i] = np.asarray(shared.get_transformed_image(Image.fromarray(frames[i])))
+        except Exception as e:                                                     # pragma: no cover
+            errs.append(e)
+    ts = [threading.Thread(target=run, args=(t,)) for t in range(T)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert all(np.array_equal(got[i], want[i]) for i in range(T * K))
+    calls, batches = shared._batcher(64, True).stats()
+    assert calls == T * K and batches < calls, (calls, batches)
+    # a lone caller is served after the wait window, alone
+    one = np.asarray(shared.get_transformed_image(Image.fromarray(frames[0])))
+    assert np.array_equal(one, want[0])
+    # frames of another size bypass the batcher (host Pillow stretch, as the reference)
+    odd = Image.fromarray(make_frame(64, 1)).resize((80, 48))
+    assert shared.get_transformed_image(odd).size == (80, 48)

@@ -116,6 +116,10 @@ SYMBOLS = [
     ("havc_dev_upload", _I, [_P, _P, _P, _SZ]),
     ("havc_dev_download", _I, [_P, _P, _P, _SZ]),
     ("havc_dev_copy", _I, [_P, _P, _P, _SZ]),
+    ("havc_batcher_create", _I, [_P, _P, _P, _F, _I, _I, _I, C.POINTER(_P)]),
+    ("havc_batcher_submit", _I, [_P, _P, _P]),
+    ("havc_batcher_stats", _I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("havc_batcher_free", None, [_P]),
     ("havc_tag_timing_enable", _I, [_P, _I, _I]),
     ("havc_tag_timing_read", _I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 ]
@@ -304,3 +308,39 @@ class Net:
         ms = np.zeros(len(self.ops), dtype=np.float32)
         check(self.ctx.lib.havc_net_profile(self.h, batch, as_ptr(ms), len(ms)), self.ctx.h)
         return ms
+
+
+class Batcher:
+    """havc_batcher: merges concurrent per-frame calls (one per VapourSynth worker thread, vsslib/vsmodels.py:201-230) into batches."""
+
+    def __init__(self, ctx, video, second, video_weight, post_process=True, wait_us=200, callers=0):
+        self.ctx, self.S = ctx, video.S
+        h = C.c_void_p()
+        check(ctx.lib.havc_batcher_create(ctx.h, video.h, second.h if second else None, float(video_weight), 1 if post_process else 0,
+                                          int(wait_us), int(callers), C.byref(h)), ctx.h)
+        self.h = h
+        self._nets = (video, second)                           # keep the nets alive as long as the batcher
+
+    def submit(self, frame):
+        """uint8 [S, S, 3] -> uint8 [S, S, 3]; blocks until the batch this frame rode in is done (the GIL is released meanwhile)"""
+        frame = np.ascontiguousarray(frame, dtype=np.uint8)
+        assert frame.shape == (self.S, self.S, 3)
+        out = np.empty_like(frame)
+        check(self.ctx.lib.havc_batcher_submit(self.h, as_ptr(frame), as_ptr(out)), self.ctx.h)
+        return out
+
+    def stats(self):
+        a, b = C.c_int64(0), C.c_int64(0)
+        self.ctx.lib.havc_batcher_stats(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def close(self):
+        if getattr(self, "h", None) and self.ctx.h:
+            self.ctx.lib.havc_batcher_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -10,6 +10,9 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <chrono>
+#include <deque>
+#include <condition_variable>
 #include <string>
 #include <vector>
 
@@ -1061,6 +1064,99 @@ int havc_deoldify_frames(havc_ctx* c, havc_net* video, havc_net* second, float v
     }
     c->stats.frames += n_frames;
     return out_dev ? HAVC_OK : t.finish();
+}
+
+// ---- frame coalescer: the reference calls get_transformed_image ONCE PER FRAME from several VapourSynth worker threads (vsmodels.py:201-230,
+// one call per std.ModifyFrame selector).  A batch of one leaves the encoder at 5 blocks on 256 CUs; here concurrent callers are
+// merged: the first caller to arrive leads, waits up to wait_us (or until `callers` requests are queued), runs ONE havc_deoldify_frames
+// over everything queued and hands every caller its frame.  Bytes are those of a call of its own (all tile configurations and batch sizes
+// produce the same result).  ----
+struct havc_batcher {
+    havc_ctx* ctx = nullptr;
+    havc_net *video = nullptr, *second = nullptr;
+    float video_weight = 0.f;
+    int post_process = 1, S = 0, max_batch = 1, wait_us = 200, callers = 0;
+    size_t fb = 0;
+    struct Req { const uint8_t* in; uint8_t* out; int rc; bool done; };
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Req*> q;
+    bool leader = false;
+    uint8_t *h_in = nullptr, *h_out = nullptr;                 // pinned [max_batch][S * S * 3]
+    int64_t calls = 0, batches = 0;
+};
+
+int havc_batcher_create(havc_ctx* c, havc_net* video, havc_net* second, float video_weight, int post_process, int wait_us, int callers,
+                        havc_batcher** out) {
+    if (!c || !video || !out || video->ctx != c || (second && (second->ctx != c || second->S != video->S)))
+        return fail(c, HAVC_E_INVALID, "batcher_create: bad args / nets of another ctx or size");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    auto* b = new havc_batcher();
+    b->ctx = c; b->video = video; b->second = second; b->video_weight = video_weight; b->post_process = post_process;
+    b->S = video->S;
+    b->max_batch = second ? std::min(video->max_batch, second->max_batch) : video->max_batch;
+    b->wait_us = wait_us < 0 ? 0 : wait_us;
+    b->callers = callers;
+    b->fb = (size_t)b->S * b->S * 3;
+    if (hipHostMalloc((void**)&b->h_in, b->fb * b->max_batch, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&b->h_out, b->fb * b->max_batch, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        if (b->h_in) (void)hipHostFree(b->h_in);
+        delete b;
+        return fail(c, HAVC_E_OOM, "batcher_create: pinned staging");
+    }
+    *out = b;
+    return HAVC_OK;
+}
+
+void havc_batcher_free(havc_batcher* b) {
+    if (!b) return;
+    {
+        std::unique_lock<std::mutex> lk(b->m);
+        b->cv.wait(lk, [&] { return !b->leader && b->q.empty(); });
+    }
+    (void)hipHostFree(b->h_in);
+    (void)hipHostFree(b->h_out);
+    delete b;
+}
+
+int havc_batcher_stats(havc_batcher* b, int64_t* calls, int64_t* batches) {
+    if (!b) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(b->m);
+    if (calls) *calls = b->calls;
+    if (batches) *batches = b->batches;
+    return HAVC_OK;
+}
+
+int havc_batcher_submit(havc_batcher* b, const uint8_t* rgb_in, uint8_t* rgb_out) {
+    if (!b || !rgb_in || !rgb_out) return HAVC_E_INVALID;
+    havc_batcher::Req r{rgb_in, rgb_out, HAVC_OK, false};
+    std::unique_lock<std::mutex> lk(b->m);
+    b->q.push_back(&r);
+    ++b->calls;
+    b->cv.notify_all();                                        // a leader collecting its batch re-checks the queue length
+    while (!r.done) {
+        if (b->leader) { b->cv.wait(lk); continue; }
+        b->leader = true;
+        const int want = b->callers > 0 ? std::min(b->callers, b->max_batch) : b->max_batch;
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(b->wait_us);
+        while ((int)b->q.size() < want && b->cv.wait_until(lk, deadline) != std::cv_status::timeout) {}
+        std::vector<havc_batcher::Req*> batch;
+        while (!b->q.empty() && (int)batch.size() < b->max_batch) { batch.push_back(b->q.front()); b->q.pop_front(); }
+        lk.unlock();
+        const int n = (int)batch.size();
+        for (int i = 0; i < n; ++i) memcpy(b->h_in + (size_t)i * b->fb, batch[i]->in, b->fb);
+        const int rc = havc_deoldify_frames(b->ctx, b->video, b->second, b->video_weight, b->post_process, b->h_in, b->h_out, n);
+        if (rc == HAVC_OK)
+            for (int i = 0; i < n; ++i) memcpy(batch[i]->out, b->h_out + (size_t)i * b->fb, b->fb);
+        lk.lock();
+        for (auto* q : batch) { q->rc = rc; q->done = true; }
+        ++b->batches;
+        b->leader = false;
+        b->cv.notify_all();
+    }
+    return r.rc;
 }
 
 int havc_pil_resize(havc_ctx* c, const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int resample) {

@@ -10,6 +10,7 @@ synthetic weights).  There is no CPU path: construction raises if the HIP librar
 """
 import logging
 import os
+import threading
 
 import numpy as np
 
@@ -88,19 +89,27 @@ class GeneratorRuntime:
             self.weights.close()
 
 
+_batcher_lock = threading.Lock()
+
+
 class ModelImageRender:
     """Drop-in for vsdeoldify.deoldify.visualize.ModelImageRender."""
 
     def __init__(self, package_dir=None, modelname="video", render_factor=24, video_weight=0, device_index=0,
-                 state_dicts=None, max_batch=1, worker=0):
+                 state_dicts=None, max_batch=1, worker=0, coalesce=0):
         """`worker`: index of the per-thread context on this GPU (get_context): renders built with different worker indices run
-        concurrently from different threads and share the packed weights."""
+        concurrently from different threads and share the packed weights.
+        `coalesce` = N > 0: ONE render shared by N caller threads (the reference's per-frame call shape under VapourSynth's thread pool):
+        their concurrent get_transformed_image calls for frames already at the render size are merged into batches of up to
+        max(max_batch, N) frames (havc_batcher); results are those of separate calls."""
         self.package_dir = package_dir
         self._modelname = modelname
         self._video_weight = video_weight
         self._render_factor = render_factor
-        self._max_batch = max_batch
+        self._max_batch = max(max_batch, coalesce)
         self._worker = worker
+        self._coalesce = coalesce
+        self._batchers = {}
         self.ctx = get_context(device_index, worker)
         second = None if modelname == "video" else ("stable" if modelname == "stable" else "artistic")
         self._video = self._runtime("video", state_dicts)
@@ -176,6 +185,8 @@ class ModelImageRender:
         img_orig = img_orig.convert("RGB") if img_orig.mode != "RGB" else img_orig
         if img_orig.size == (S, S):
             try:
+                if self._coalesce:
+                    return Image.fromarray(self._batcher(S, post_process).submit(np.asarray(img_orig)))
                 out = self.render_square_batch(np.asarray(img_orig)[None], post_process)[0]
                 return Image.fromarray(out)
             except nat.HavcOutOfMemory:
@@ -195,6 +206,19 @@ class ModelImageRender:
             return Image.fromarray(outs[0])
         from .imfilters import blend_np
         return Image.fromarray(blend_np(self.ctx, outs[1], outs[0], self._video_weight))
+
+    def _batcher(self, S, post_process):
+        key = (S, bool(post_process))
+        b = self._batchers.get(key)
+        if b is None:
+            with _batcher_lock:
+                b = self._batchers.get(key)
+                if b is None:
+                    v = self._video.net(S, self._max_batch)
+                    s = self._second.net(S, self._max_batch) if self._second else None
+                    b = self._batchers[key] = nat.Batcher(self.ctx, v, s, self._video_weight, post_process, callers=self._coalesce,
+                                                          wait_us=int(os.environ.get("HAVC_COALESCE_WAIT_US", "300")))
+        return b
 
     def _raw_colors(self, sq):
         S = sq.shape[0]
