@@ -248,3 +248,41 @@ def test_sharded_clip_runner_returns_the_clip_in_frame_order_gloo(n):
     shapes = [r[1] for r in res if r[1] is not None]
     assert shapes == [(n, 6, 8, 3)]
     assert sorted(sum(r[2]) for r in res) == sorted([len(range(0, n, 2)), len(range(1, n, 2))])
+
+
+def _sharded_fail_worker(rank, world, port, q):
+    import os
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vsdeoldify_amd import sharded
+
+    def stub(t):
+        if rank == 1:
+            raise MemoryError("rank 1 out of memory")
+        return t
+    frames = torch.from_numpy(np.zeros((4, 6, 8, 3), np.uint8)) if rank == 0 else None
+    try:
+        sharded.colorize_clip_sharded(frames, stub, dist, rank, world, "cpu")
+        q.put("no error")
+    except RuntimeError as e:
+        q.put("raised: " + str(e)[:60])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_clip_runner_failure_on_one_rank_raises_everywhere_and_nobody_hangs():
+    """a rank whose colorizer throws still joins the gather; the failure is then raised on EVERY rank (world_size 2, gloo)"""
+    import torch.multiprocessing as mp
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    ps = [ctxm.Process(target=_sharded_fail_worker, args=(r, 2, 29671, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r.startswith("raised: colorize_clip_sharded") for r in res), res

@@ -100,10 +100,18 @@ def colorize_clip_sharded(frames, colorize_fn, dist=None, rank=0, world_size=1, 
             scatter_list.append(s)
     dist.scatter(shard, scatter_list, src=0)
     out = torch.zeros_like(shard)
+    failure = None
     if mine:
-        out[:len(mine)] = colorize_fn(shard[:len(mine)].contiguous())
+        try:
+            out[:len(mine)] = colorize_fn(shard[:len(mine)].contiguous())
+        except Exception as e:                       # a failing rank still takes part in the collectives below: nobody hangs
+            failure = e
     gather_list = [torch.empty_like(out) for _ in range(world_size)] if rank == 0 else None
     dist.gather(out, gather_list, dst=0)
+    flag = torch.tensor([1 if failure is not None else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    if int(flag.item()):
+        raise RuntimeError(f"colorize_clip_sharded: a rank failed to colour its shard (rank {rank}: {failure!r})") from failure
     if rank != 0:
         return None
     result = torch.empty((n, h, w, c), dtype=torch.uint8, device=device)
