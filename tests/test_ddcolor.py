@@ -201,3 +201,25 @@ def test_gpu_dwconv7_layernorm_fused_kernel(ctx, C, H, W):
     assert err.max() < 6e-3 and err.mean() < 6e-4, (float(err.max()), float(err.mean()))           # fp16 output rounding: |y| < 8
     err2 = np.abs(outs[False] - ref)
     assert err.mean() <= err2.mean() * 1.05                       # the fused form norms the fp32 conv result: never less accurate
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S", [32, 96])
+def test_gpu_ddcolor_frames_do_not_depend_on_the_batch(ctx, S):
+    """A frame colours identically alone and inside a batch, also where a 256-pixel GEMM tile of the folded tail spans several frames
+    (S = 32: 64 low-res pixels per frame, four frames per tile; S = 96: 576 pixels, tiles straddle frame boundaries) and where the fused
+    block head sees 1 x 1 and 3 x 3 feature maps."""
+    from vsdeoldify_amd.ddcolor import DDColorRuntime
+    sd = synth_ddcolor_state_dict(4, **SMALL)
+    rt = DDColorRuntime(ctx, sd, **SMALL)
+    try:
+        r = np.random.default_rng(S)
+        frames = r.integers(0, 256, (5, S, S, 1), dtype=np.uint8).repeat(3, -1)
+        together = rt.colorize(frames, max_batch=5)
+        alone = np.stack([rt.colorize(frames[i:i + 1], max_batch=1)[0] for i in range(5)])
+        assert np.array_equal(together, alone)
+        want = np.stack([D.colorize_frame(sd, f, **SMALL) for f in frames[:2]])
+        d = np.abs(together[:2].astype(int) - want.astype(int))
+        assert (d <= 2).mean() > 0.98 and d.max() <= 16, (float((d <= 2).mean()), int(d.max()))
+    finally:
+        rt.close()
