@@ -76,7 +76,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
     ap.add_argument("--clip-frames", type=int, default=16, help="distinct synthetic frames resident per GPU")
-    ap.add_argument("--config", default="c2", choices=["c2", "c4"], help="c2 = BASELINE configs[1] (headline), c4 = configs[3] (DeOldify+DDColor merge)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"],
+                    help="c2 = BASELINE configs[1] (headline), c3 = configs[2] (DDColor large, input 512), c4 = configs[3] (DeOldify+DDColor merge)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sustained / PCIe-inclusive / batch-1 legs")
     ap.add_argument("--sustain-seconds", type=float, default=30.0)
@@ -102,8 +103,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))   # nccl == RCCL on ROCm
 
-    if args.config == "c4":
-        return bench_c4(args, rank, local_rank, world, dist)
+    if args.config in ("c3", "c4"):
+        return bench_c4(args, rank, local_rank, world, dist, ddcolor_only=args.config == "c3")
 
     from vsdeoldify_amd import _native as nat
     from vsdeoldify_amd.clip import ClipColorizer, synthetic_gray_frame
@@ -324,8 +325,10 @@ def extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds):
     return res
 
 
-def bench_c4(args, rank, local_rank, world, dist):
-    """BASELINE configs[3]: HAVC DeOldify + DDColor merge (combine_method=2) on a 1080p clip, defaults of HAVC_colorizer:
+def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
+    """ddcolor_only (--config c3): BASELINE configs[2], DDColor large at input 512 on a 1080p clip (HAVC_colorizer method=1,
+    ddcolor_p=[1,32,..] => input_size = trunc(32/2)*32 = 512, vsmodels.py:302): Spline64 squash -> DDColor -> Spline64 back + luma.
+    Otherwise BASELINE configs[3]: HAVC DeOldify + DDColor merge (combine_method=2) on a 1080p clip, defaults of HAVC_colorizer:
     deoldify_p=[0,24,..] (video model, 384x384), ddcolor_p=[1,24,..] (artistic, input 384), mweight=0.4 -- device-resident graph:
     Spline64 squash -> DynamicUnetWide pass + DDColor pass -> Image.blend -> Spline64 back + luma of the source.
     DDColor's parity is UNPINNED (external wheel; oracle/ddcolor.py restates the published architecture)."""
@@ -334,9 +337,13 @@ def bench_c4(args, rank, local_rank, world, dist):
     from vsdeoldify_amd.device import DeviceImage
     from vsdeoldify_amd.havc import HAVCFrameColorizer
     from vsdeoldify_amd.synth import synth_ddcolor_state_dict, synth_state_dict
-    col = HAVCFrameColorizer(method=2, mweight=0.4, deoldify_p=(0, 24, 1.0, 0.0), ddcolor_p=(1, 24, 1.0, 0.0, True), device_index=local_rank,
-                             state_dicts={"video": synth_state_dict("wide", 1)}, ddcolor_state_dict=synth_ddcolor_state_dict(1),
-                             max_batch=args.batch)
+    if ddcolor_only:
+        col = HAVCFrameColorizer(method=1, ddcolor_p=(1, 32, 1.0, 0.0, True), device_index=local_rank,
+                                 ddcolor_state_dict=synth_ddcolor_state_dict(1), max_batch=args.batch)
+    else:
+        col = HAVCFrameColorizer(method=2, mweight=0.4, deoldify_p=(0, 24, 1.0, 0.0), ddcolor_p=(1, 24, 1.0, 0.0, True), device_index=local_rank,
+                                 state_dicts={"video": synth_state_dict("wide", 1)}, ddcolor_state_dict=synth_ddcolor_state_dict(1),
+                                 max_batch=args.batch)
     ctx = col.ctx
     frames = np.stack([synthetic_gray_frame(rank * args.batch + i, WIDTH, HEIGHT) for i in range(args.batch)])
     clip = DeviceImage.from_numpy(ctx, frames)
@@ -366,14 +373,17 @@ def bench_c4(args, rank, local_rank, world, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total = args.steps * args.batch * world
-    gflop_frame = st.total_flops / max(st.frames / 2, 1) / 1e9 if st.frames else 0.0        # both models count `frames`
-    out = {"metric": "colorized frames/sec/GPU @1080p (HAVC DeOldify+DDColor merge, combine_method=2)", "value": round(total / elapsed, 3),
+    gflop_frame = st.total_flops / max(st.frames / (1 if ddcolor_only else 2), 1) / 1e9 if st.frames else 0.0        # every model counts `frames`
+    out = {"metric": "colorized frames/sec/GPU @1080p (DDColor large, input 512)" if ddcolor_only else
+                     "colorized frames/sec/GPU @1080p (HAVC DeOldify+DDColor merge, combine_method=2)", "value": round(total / elapsed, 3),
            "unit": "frames/s (sum over n_gpus)", "n_gpus": world, "value_per_gpu": round(total / elapsed / world, 3), "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "f16", "data": "synthetic",
-           "config": {"workload": "HAVC DeOldify+DDColor merge (combine_method=2) 1080p, frame-sharded (BASELINE.json configs[3])",
-                      "frames_per_step_per_gpu": args.batch, "deoldify": "video, rf=24 (384x384)", "ddcolor": "artistic, input 384 (parity UNPINNED)",
-                      "mweight": 0.4, "algorithmic_gflop_per_frame": round(gflop_frame, 2), "device_resident": True,
+           "config": {"workload": "DDColor modelsize=large, 512 input, 1080p clip (BASELINE.json configs[2])" if ddcolor_only else
+                                  "HAVC DeOldify+DDColor merge (combine_method=2) 1080p, frame-sharded (BASELINE.json configs[3])",
+                      "frames_per_step_per_gpu": args.batch, "deoldify": None if ddcolor_only else "video, rf=24 (384x384)",
+                      "ddcolor": "artistic, input %d (parity UNPINNED)" % (512 if ddcolor_only else 384),
+                      "mweight": None if ddcolor_only else 0.4, "algorithmic_gflop_per_frame": round(gflop_frame, 2), "device_resident": True,
                       "parallelism": f"frame-sharded x{world}, weight replica per GPU, no collective"},
            "whole_path_tflops": round(total * gflop_frame * 1e9 / elapsed / 1e12 / world, 2)}
     if dist is not None:
