@@ -218,6 +218,8 @@ int havc_deoldify_frames(havc_ctx* ctx, havc_net* video, havc_net* second, float
 typedef struct havc_batcher havc_batcher;
 int havc_batcher_create(havc_ctx* ctx, havc_net* video, havc_net* second, float video_weight, int post_process, int wait_us, int callers,
                         havc_batcher** out);
+/* the same for per-frame DDColor (kind 1: havc_ddcolor_frames) and Zhang (kind 2: havc_zhang_frames) calls on width x height frames */
+int havc_batcher_create_frames(havc_ctx* ctx, int kind, havc_net* net, int width, int height, int wait_us, int callers, havc_batcher** out);
 int havc_batcher_submit(havc_batcher* b, const uint8_t* rgb_in, uint8_t* rgb_out);
 int havc_batcher_stats(havc_batcher* b, int64_t* calls, int64_t* batches);
 void havc_batcher_free(havc_batcher* b);

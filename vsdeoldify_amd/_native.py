@@ -117,6 +117,7 @@ SYMBOLS = [
     ("havc_dev_download", _I, [_P, _P, _P, _SZ]),
     ("havc_dev_copy", _I, [_P, _P, _P, _SZ]),
     ("havc_batcher_create", _I, [_P, _P, _P, _F, _I, _I, _I, C.POINTER(_P)]),
+    ("havc_batcher_create_frames", _I, [_P, _I, _P, _I, _I, _I, _I, C.POINTER(_P)]),
     ("havc_batcher_submit", _I, [_P, _P, _P]),
     ("havc_batcher_stats", _I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("havc_batcher_free", None, [_P]),
@@ -313,18 +314,25 @@ class Net:
 class Batcher:
     """havc_batcher: merges concurrent per-frame calls (one per VapourSynth worker thread, vsslib/vsmodels.py:201-230) into batches."""
 
-    def __init__(self, ctx, video, second, video_weight, post_process=True, wait_us=200, callers=0):
-        self.ctx, self.S = ctx, video.S
+    def __init__(self, ctx, video, second=None, video_weight=0.0, post_process=True, wait_us=200, callers=0, kind=0, frame_hw=None):
+        """kind 0: DeOldify (video [+ second] nets, S x S frames); 1: DDColor, 2: Zhang (`video` = the net, frames of frame_hw)"""
+        self.ctx = ctx
         h = C.c_void_p()
-        check(ctx.lib.havc_batcher_create(ctx.h, video.h, second.h if second else None, float(video_weight), 1 if post_process else 0,
-                                          int(wait_us), int(callers), C.byref(h)), ctx.h)
+        if kind == 0:
+            self.shape = (video.S, video.S, 3)
+            check(ctx.lib.havc_batcher_create(ctx.h, video.h, second.h if second else None, float(video_weight), 1 if post_process else 0,
+                                              int(wait_us), int(callers), C.byref(h)), ctx.h)
+        else:
+            self.shape = (int(frame_hw[0]), int(frame_hw[1]), 3)
+            check(ctx.lib.havc_batcher_create_frames(ctx.h, int(kind), video.h, self.shape[1], self.shape[0], int(wait_us), int(callers),
+                                                     C.byref(h)), ctx.h)
         self.h = h
         self._nets = (video, second)                           # keep the nets alive as long as the batcher
 
     def submit(self, frame):
         """uint8 [S, S, 3] -> uint8 [S, S, 3]; blocks until the batch this frame rode in is done (the GIL is released meanwhile)"""
         frame = np.ascontiguousarray(frame, dtype=np.uint8)
-        assert frame.shape == (self.S, self.S, 3)
+        assert frame.shape == self.shape, (frame.shape, self.shape)
         out = np.empty_like(frame)
         check(self.ctx.lib.havc_batcher_submit(self.h, as_ptr(frame), as_ptr(out)), self.ctx.h)
         return out

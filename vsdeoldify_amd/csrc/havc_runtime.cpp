@@ -1073,6 +1073,8 @@ int havc_deoldify_frames(havc_ctx* c, havc_net* video, havc_net* second, float v
 // produce the same result).  ----
 struct havc_batcher {
     havc_ctx* ctx = nullptr;
+    int kind = 0;                                              // 0 DeOldify (video [+ second]), 1 DDColor, 2 Zhang: `video` is the net
+    int width = 0, height = 0;                                 // frame size (kinds 1, 2; kind 0: S x S)
     havc_net *video = nullptr, *second = nullptr;
     float video_weight = 0.f;
     int post_process = 1, S = 0, max_batch = 1, wait_us = 200, callers = 0;
@@ -1105,6 +1107,28 @@ int havc_batcher_create(havc_ctx* c, havc_net* video, havc_net* second, float vi
         if (b->h_in) (void)hipHostFree(b->h_in);
         delete b;
         return fail(c, HAVC_E_OOM, "batcher_create: pinned staging");
+    }
+    *out = b;
+    return HAVC_OK;
+}
+
+int havc_batcher_create_frames(havc_ctx* c, int kind, havc_net* net, int width, int height, int wait_us, int callers, havc_batcher** out) {
+    if (!c || !net || !out || net->ctx != c || (kind != 1 && kind != 2) || width <= 0 || height <= 0)
+        return fail(c, HAVC_E_INVALID, "batcher_create_frames: kind 1 (DDColor) or 2 (Zhang), a net of this ctx, a frame size");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    auto* b = new havc_batcher();
+    b->ctx = c; b->kind = kind; b->video = net; b->width = width; b->height = height; b->S = net->S;
+    b->max_batch = net->max_batch;
+    b->wait_us = wait_us < 0 ? 0 : wait_us;
+    b->callers = callers;
+    b->fb = (size_t)width * height * 3;
+    if (hipHostMalloc((void**)&b->h_in, b->fb * b->max_batch, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&b->h_out, b->fb * b->max_batch, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        if (b->h_in) (void)hipHostFree(b->h_in);
+        delete b;
+        return fail(c, HAVC_E_OOM, "batcher_create_frames: pinned staging");
     }
     *out = b;
     return HAVC_OK;
@@ -1147,7 +1171,9 @@ int havc_batcher_submit(havc_batcher* b, const uint8_t* rgb_in, uint8_t* rgb_out
         lk.unlock();
         const int n = (int)batch.size();
         for (int i = 0; i < n; ++i) memcpy(b->h_in + (size_t)i * b->fb, batch[i]->in, b->fb);
-        const int rc = havc_deoldify_frames(b->ctx, b->video, b->second, b->video_weight, b->post_process, b->h_in, b->h_out, n);
+        const int rc = b->kind == 0   ? havc_deoldify_frames(b->ctx, b->video, b->second, b->video_weight, b->post_process, b->h_in, b->h_out, n)
+                       : b->kind == 1 ? havc_ddcolor_frames(b->ctx, b->video, b->h_in, b->h_out, n, b->width, b->height)
+                                      : havc_zhang_frames(b->ctx, b->video, b->h_in, b->h_out, n, b->width, b->height);
         if (rc == HAVC_OK)
             for (int i = 0; i < n; ++i) memcpy(batch[i]->out, b->h_out + (size_t)i * b->fb, b->fb);
         lk.lock();
