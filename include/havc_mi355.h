@@ -107,7 +107,8 @@ enum havc_op_type {
                                      never stored.  Needs 1x1 stride-1 conv, Co % 64 == 0, weight rows packed as
                                      (c / 64) * 256 + q * 64 + c % 64 (plan.py pack_conv pixshuf="blur"): a 256-column tile then
                                      holds all four sub-pixels of 64 channels, and GEMM rows are 16x16 pixel tiles that
-                                     overlap by one row / column (the blur's top-left halo).                              */
+                                     overlap by one row / column (the blur's top-left halo).  Co = channels per sub-pixel in
+                                     the packed rows (a multiple of 64: zero rows pad other counts), aux0 = channels stored.  */
 #define HAVC_F_GELU 0x400         /* exact (erf) GELU at the RELU_PRE position (ConvNeXt pwconv1)                            */
 #define HAVC_F_W_FROM_BUF 0x800   /* conv weights are ACTIVATIONS: buffer src2 holds, per frame, fp16 [Npad][Kc * 8] rows (the colour
                                      embeddings of DDColor's einsum(bqc,bchw->bqhw)); launched once per frame; no residual  */

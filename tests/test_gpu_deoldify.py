@@ -147,3 +147,23 @@ def test_fused_shuffle_blur_is_bit_identical(ctx, sds, S):
         finally:
             rt.close()
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_fused_shuffle_blur_with_padded_channel_counts_deep(ctx):
+    """DynamicUnetDeep (artistic): 300 / 336 channels per sub-pixel are padded to 320 / 384 zero weight rows so that the fused
+    shuffle + blur epilogue applies; only the real channels are stored (the image channels behind them in the tail tensor survive).
+    Exactly the bytes of the three-pass path."""
+    from vsdeoldify_amd.synth import synth_state_dict
+    sd = synth_state_dict("deep", 3)
+    S = 272
+    frames = np.stack([make_frame(S, 50), make_frame(S, 51)])
+    outs = []
+    for fuse in (True, False):
+        rt = GeneratorRuntime(ctx, sd, "deep", fuse_blur=fuse)
+        try:
+            names = rt.net(S, 2).names
+            assert ("layers.8+blur" in names) == fuse and ("layers.8.blur" in names) != fuse
+            outs.append(raw_gpu(ctx, rt, frames))
+        finally:
+            rt.close()
+    assert np.array_equal(outs[0], outs[1])

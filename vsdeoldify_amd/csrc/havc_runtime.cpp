@@ -283,6 +283,8 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                 if (!(op.flags & HAVC_F_OUT_PIXSHUF) || op.kh != 1 || op.kw != 1 || op.stride != 1 || op.pad != 0 || (op.Co & 63) ||
                     op.Npad != 4 * op.Co || (op.Npad & 255) || op.out_step > 1 || (op.flags & (HAVC_F_RESIDUAL | HAVC_F_RELU_POST)))
                     return fail(c, HAVC_E_INVALID, "conv op: PS_BLUR needs a 1x1 stride-1 pixel-shuffle conv with Co % 64 == 0");
+                if (op.aux0 < 0 || (op.aux0 & 7) || op.aux0 > op.Co) return fail(c, HAVC_E_INVALID, "conv op: PS_BLUR aux0 = stored channels (multiple of 8, <= Co)");
+                a.cstore = op.aux0;
                 a.tiles_y = (op.Ho + 14) / 15;
                 a.tiles_x = (op.Wo + 14) / 15;
                 rows_per_frame = a.tiles_y * a.tiles_x * 256;
@@ -320,7 +322,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             a.flags = op.flags;
             if (c->nt_store_bytes && (uint64_t)batch * n->bufdesc[op.dst].elems_per_frame * n->bufdesc[op.dst].elem_bytes >= c->nt_store_bytes)
                 a.flags |= HAVC_F_NT_STORE;
-            a.pix_pitch = op.aux0;
+            a.pix_pitch = (op.flags & HAVC_F_PS_BLUR) ? 0 : op.aux0;
             a.C8a = (op.aux1 > 0 && op.aux1 < op.Ci / 8) ? op.aux1 : op.Ci / 8;
             a.f0 = op.f0; a.f1 = op.f1; a.f2 = op.f2;
             a.cfg = op.reserved;

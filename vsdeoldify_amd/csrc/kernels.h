@@ -35,6 +35,7 @@ struct ConvArgs {
     const float* fuse_w;   // FUSE_RGB8: fp32 [3][Npad] weights of the fused 1x1 conv, fuse_b: its 3 biases
     const float* fuse_b;
     uint8_t* fuse_rgb;     // FUSE_RGB8: u8 RGB output [M][3]
+    int cstore;            // PS_BLUR: channels actually stored per pixel (the packed rows may be padded to a multiple of 64); 0 = all
     float* fuse_out;       // FUSE_PROJ: fp32 output [M][Npad / 256][2]; fuse_w = fp32 [frame][2][256]
     unsigned x_bytes;      // size of the input allocation (buffer descriptor range; OOB lanes read zeros)
     unsigned w_bytes;      // Npad * Kc * 16

@@ -77,14 +77,19 @@ class DeoldifyGenerator:
         the size, and everything is packed once in the constructor's dry run."""
         if not self._frozen:
             pc = self._conv(key, lambda: make(True))
-            if self.fuse_blur and (pc.Cout // 4) % 64 == 0 and pc.Cout % 256 == 0:
+            if self.fuse_blur and self._blur_pad_ok(pc.Cout // 4):
                 self._conv(key + "#blur", lambda: make("blur"))
         return self._pc[key + ("#blur" if fuse else "")]
 
     def _fuse_blur(self, x, up_c, out_hw):
         """HAVC_F_PS_BLUR applies when the blur is not followed by a resize, the channel count tiles by 64 and the 15/16
         tile overlap wastes little (H >= 128: 280 -> 19 tiles of 15 = 1.8 %, 140 -> 7 %, 70 -> 7 % but M is tiny there)."""
-        return self.fuse_blur and 2 * x.H == out_hw and up_c % 64 == 0 and (4 * up_c) % 256 == 0 and x.H >= 128
+        return self.fuse_blur and 2 * x.H == out_hw and self._blur_pad_ok(up_c) and x.H >= 128
+
+    @staticmethod
+    def _blur_pad_ok(up_c):
+        """channels per sub-pixel are padded to a multiple of 64 with zero weight rows: worth it up to ~15 % padding (300 -> 320, 336 -> 384)"""
+        return up_c % 4 == 0 and pad_to(up_c, 64) <= 1.15 * up_c
 
     def _vecs(self, key, fn):
         if key not in self._vec:

@@ -144,16 +144,26 @@ def pack_conv(pack, W, cmap, Ci, bias=None, scale=None, shift=None, pixshuf=Fals
         # packed row q*cps + c  <-  original row c*4 + q   (PixelShuffle(2): q = dy*2 + dx)
         perm = (np.arange(cps)[None, :] * 4 + np.arange(4)[:, None]).reshape(-1)
         if pixshuf == "blur":
-            # HAVC_F_PS_BLUR: packed row (c // 64) * 256 + q * 64 + c % 64: one 256-column tile = 4 sub-pixels x 64 channels
-            assert cps % 64 == 0
+            # HAVC_F_PS_BLUR: packed row (c // 64) * 256 + q * 64 + c % 64: one 256-column tile = 4 sub-pixels x 64 channels.  A channel
+            # count that is not a multiple of 64 (DynamicUnetDeep: 300, 336) is padded with zero rows to the next one; the epilogue
+            # stores only the real channels (op.aux0).
+            cpp = pad_to(cps, 64)
             cc = np.arange(cps)
-            perm = np.empty(Cout, np.int64)
+            Npad = 4 * cpp
+            W2 = np.zeros((Npad,) + Wt.shape[1:], np.float32)
+            vs = [None if v is None else np.zeros(Npad, np.float32) for v in (bias, scale, shift)]
             for q in range(4):
-                perm[(cc // 64) * 256 + q * 64 + cc % 64] = cc * 4 + q
-        Wt = Wt[perm]
-        bias = None if bias is None else bias[perm]
-        scale = None if scale is None else scale[perm]
-        shift = None if shift is None else shift[perm]
+                rows = (cc // 64) * 256 + q * 64 + cc % 64
+                W2[rows] = Wt[cc * 4 + q]
+                for dst, src in zip(vs, (bias, scale, shift)):
+                    if dst is not None:
+                        dst[rows] = src[cc * 4 + q]
+            Wt, (bias, scale, shift) = W2, vs
+        else:
+            Wt = Wt[perm]
+            bias = None if bias is None else bias[perm]
+            scale = None if scale is None else scale[perm]
+            shift = None if shift is None else shift[perm]
     # K order (must match havc_net_create's K table).  Main segment = chunks [0, C8a) of every tap, remainder segment =
     # chunks [C8a, C8); each segment padded to a multiple of 8 chunks (259 = 256 + 3: 32 chunks x 9 taps, then 9 single
     # chunks of x0).  When C8a is a multiple of 8 the main segment is ordered CHANNEL-GROUP MAJOR: for every group of 8
@@ -229,7 +239,9 @@ class PlanBuilder:
                 assert y.H == 2 * Ho and y.W == 2 * Wo and pc.Cout == 4 * y.C and y.C % 4 == 0, name
                 kw["Co"] = y.C
                 if flags & nat.F_PS_BLUR:
-                    assert pc.kh == 1 and stride == 1 and pad == 0 and y.C % 64 == 0 and pc.Npad % 256 == 0, name
+                    assert pc.kh == 1 and stride == 1 and pad == 0 and pc.Npad == 4 * pad_to(y.C, 64), name
+                    kw["Co"] = pc.Npad // 4                    # channels per sub-pixel in the packed rows (zero rows beyond y.C)
+                    kw["aux0"] = y.span                        # channels actually stored
             else:
                 assert y.H == Ho * out_step and y.W == Wo * out_step and y.C == pc.Cout, (name, y.H, Ho, y.C, pc.Cout)
                 kw["Co"] = y.span
