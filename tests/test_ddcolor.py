@@ -54,6 +54,23 @@ def test_convnext_pieces_match_transformers():
     assert torch.allclose(r2, m2, atol=5e-5), float((r2 - m2).abs().max())
 
 
+def test_oracle_attention_matches_torch_multihead_attention():
+    """An independent pin for the colour decoder (its source is not in the reference tree): the oracle's multi-head attention
+    against torch.nn.MultiheadAttention on random weights."""
+    torch.manual_seed(0)
+    E, H = 256, 8
+    m = torch.nn.MultiheadAttention(E, H, batch_first=True).eval()
+    sd = {"a.in_proj_weight": m.in_proj_weight.detach(), "a.in_proj_bias": m.in_proj_bias.detach(),
+          "a.out_proj.weight": m.out_proj.weight.detach(), "a.out_proj.bias": m.out_proj.bias.detach()}
+    with torch.no_grad():
+        m.in_proj_bias.normal_(0, 0.1); m.out_proj.bias.normal_(0, 0.1)
+        sd["a.in_proj_bias"], sd["a.out_proj.bias"] = m.in_proj_bias.detach(), m.out_proj.bias.detach()
+        q, k, v = torch.randn(2, 100, E), torch.randn(2, 333, E), torch.randn(2, 333, E)
+        want = m(q, k, v, need_weights=False)[0]
+        got = D.mha(sd, "a", q, k, v, heads=H)
+    assert torch.allclose(got, want, atol=2e-5, rtol=1e-5), float((got - want).abs().max())
+
+
 def test_oracle_forward_shapes_and_determinism():
     sd = synth_ddcolor_state_dict(1, **SMALL)
     x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(0))
