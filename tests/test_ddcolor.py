@@ -177,14 +177,14 @@ def test_gpu_ddcolor_full_depth_end_to_end(ctx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("C,H,W", [(192, 13, 10), (384, 8, 8), (768, 7, 9), (1536, 5, 6), (64, 3, 2)])
-def test_gpu_dwconv7_layernorm_fused_kernel(ctx, C, H, W):
+@pytest.mark.parametrize("C,H,W,B", [(192, 13, 10, 3), (384, 8, 8, 3), (768, 7, 9, 3), (1536, 5, 6, 3), (64, 3, 2, 3), (192, 64, 64, 17)])
+def test_gpu_dwconv7_layernorm_fused_kernel(ctx, C, H, W, B):
     """ConvNeXt block head (depthwise 7x7 + bias, LayerNorm over channels) as ONE kernel against torch fp32 and against the two-kernel
-    form; sizes that are not multiples of the 2 x 4 patch, every LDS weight format (fp32 up to 768 channels, fp16 above)."""
+    form; sizes that are not multiples of the 4 x 4 patch, every LDS weight format (fp32 up to 768 channels, fp16 above), and a launch
+    whose 256 persistent blocks each walk more than one group of patches (17 frames of 64 x 64)."""
     from vsdeoldify_amd import _native as nat
     from vsdeoldify_amd.ddcolor_net import DDColorGenerator
     from vsdeoldify_amd.plan import PlanBuilder, WeightPack
-    B = 3
     r = np.random.default_rng(C + H)
     Wt = (r.standard_normal((C, 1, 7, 7)) / 7).astype(np.float32)
     bias, gamma, beta = (r.standard_normal(C).astype(np.float32) * s + o for s, o in ((0.1, 0), (0.2, 1), (0.1, 0)))

@@ -174,7 +174,8 @@ def test_worker_contexts_run_concurrently_and_share_weights(ctx):
     assert all(np.array_equal(got[i], want[i]) for i in range(6))
 
 
-def test_coalesced_per_frame_calls_match_separate_calls(ctx):
+@pytest.mark.parametrize("coalesce", [6, 2])
+def test_coalesced_per_frame_calls_match_separate_calls(ctx, coalesce):
     """The reference's call shape is ONE get_transformed_image per frame from each VapourSynth worker thread.  A render built with
     coalesce=N merges the concurrent calls of N threads into batches (havc_batcher): every caller gets exactly the bytes of a call of
     its own, and fewer batches than calls were run."""
@@ -187,7 +188,7 @@ def test_coalesced_per_frame_calls_match_separate_calls(ctx):
     frames = [make_frame(64, 300 + i) for i in range(T * K)]
     ref = ModelImageRender(None, "stable", 4, 0.5, state_dicts=sds)
     want = [np.asarray(ref.get_transformed_image(Image.fromarray(f))) for f in frames]
-    shared = ModelImageRender(None, "stable", 4, 0.5, state_dicts=sds, coalesce=T)
+    shared = ModelImageRender(None, "stable", 4, 0.5, state_dicts=sds, coalesce=coalesce)      # 2: more caller threads than a batch holds
     got, errs = {}, []
 
     def run(t):
