@@ -347,6 +347,15 @@ int havc_dev_copy(havc_ctx* ctx, void* d_dst, const void* d_src, size_t nbytes);
  * havc_memory_similarity returns the dense similarity [B][N][HW] (get_similarity alone; memory consolidation uses it). */
 int havc_memory_read_topk(havc_ctx* ctx, const float* mk, const float* ms, const float* qk, const float* qe, const float* mv, float* out, int B,
                           int CK, int CV, int N, int HW, int top_k);
+/* the same with the row sums of the sparse affinity, usage [B][N] (do_softmax(..., return_usage=True), memory_util.py:63-64: what
+ * MemoryManager.match_memory hands to KeyValueMemoryStore.update_usage, memory_manager.py:111-120,131-135).  Accumulated in 64-bit fixed
+ * point, so the sums (and the long-term prototypes chosen from them) do not depend on the order of the atomics.  usage may be NULL. */
+int havc_memory_read_topk_usage(havc_ctx* ctx, const float* mk, const float* ms, const float* qk, const float* qe, const float* mv, float* out,
+                                float* usage, int B, int CK, int CV, int N, int HW, int top_k);
+/* memory consolidation (memory_manager.py:264-283): similarity of the N candidates against P prototype keys (qk / qe [B][CK][P]),
+ * dense softmax over the candidates (no top-k), readout mv @ affinity -> out [B][CV][P].  CV <= 2048. */
+int havc_memory_dense_readout(havc_ctx* ctx, const float* mk, const float* ms, const float* qk, const float* qe, const float* mv, float* out, int B,
+                              int CK, int CV, int N, int P);
 int havc_memory_similarity(havc_ctx* ctx, const float* mk, const float* ms, const float* qk, const float* qe, float* sim, int B, int CK, int N, int HW);
 /* havc_local_correlation replaces the SpatialCorrelationSampler call of LocalGatedPropagation (colormnet/model/attention.py:827-835;
  * kernel_size 1, patch_size 2 max_dis + 1, dilation_patch = dilation): q, k [n][C][H][W] ->

@@ -99,3 +99,25 @@ def test_gpu_local_attention_matches_oracle(ctx, n, C, Cv, h, w, R, dil):
     assert torch.allclose(agg, ref_agg, rtol=1e-4, atol=1e-5), float((agg - ref_agg).abs().max())
     ref_c = O.local_correlation(q, k, R, dil)
     assert torch.allclose(M.local_correlation(q, k, R, dil), ref_c, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device", ["cpu", "cuda"])
+def test_gpu_local_gated_propagation_module_matches_the_executed_reference(device):
+    """the torch-module adapter (vsdeoldify_amd/colormnet_torch.py): a reference state_dict loads as is; forward = HIP correlation /
+    softmax / aggregation + the module's own depthwise conv and Linear; output and attention as recorded from the reference module."""
+    import torch
+    from vsdeoldify_amd.colormnet_torch import LocalGatedPropagation
+    if device == "cuda" and not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "colormnet_local.npz"))
+    m = LocalGatedPropagation(d_qk=64, d_vu=64, num_head=1, dilation=1, use_linear=False, dropout=0, d_att=64, max_dis=7, expand_ratio=1, enable_corr=False)
+    sd = {"relative_emb_k.weight": torch.from_numpy(g["rel_w"]).reshape(225, 64, 1, 1), "relative_emb_k.bias": torch.from_numpy(g["rel_b"]),
+          "dw_conv.conv.weight": torch.from_numpy(g["dw_w"]), "projection.weight": torch.from_numpy(g["proj_w"]), "projection.bias": torch.from_numpy(g["proj_b"])}
+    m.load_state_dict(sd)
+    m = m.to(device).eval()
+    q, k, v = (torch.from_numpy(g[n]).to(device) for n in ("q", "k", "v"))
+    out, attn = m(q, k, v, None, (q.shape[2], q.shape[3]))
+    assert np.abs(out.cpu().numpy() - g["out"]).max() < 2e-4 and np.abs(attn.cpu().numpy() - g["attn"]).max() < 1e-5
+    with pytest.raises(NotImplementedError):
+        LocalGatedPropagation(d_qk=64, d_vu=64, num_head=2, use_linear=False)

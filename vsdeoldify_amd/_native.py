@@ -108,6 +108,8 @@ SYMBOLS = [
     ("havc_planar_to_rgb8", _I, [_P, C.POINTER(_P), _I, _P, _I, _I]),
     ("havc_rgb8_to_planar", _I, [_P, _P, C.POINTER(_P), _I, _I, _I]),
     ("havc_memory_read_topk", _I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
+    ("havc_memory_read_topk_usage", _I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
+    ("havc_memory_dense_readout", _I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     ("havc_memory_similarity", _I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I]),
     ("havc_local_correlation", _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F]),
     ("havc_local_attention", _I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I]),

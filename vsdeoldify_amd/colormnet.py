@@ -7,9 +7,9 @@
   local_attention        LocalGatedPropagation.forward (use_linear=False, one head) up to agg_value (attention.py:783-856)
 
 Operands are fp32 in the reference's layouts: numpy arrays, CPU torch tensors (staged by the library) or CUDA / ROCm torch
-tensors of the ctx's GPU (used in place through their device pointer: nothing is copied).  The rest of the ColorMNet network
-(DINOv2 / ResNet50 key encoder, value encoder, decoder, the memory bookkeeping) is not built yet: sequential in time, one clip
-per GPU (replicas only).  No CPU fallback."""
+tensors of the ctx's GPU (used in place through their device pointer: nothing is copied).  The memory bookkeeping on top of these is
+colormnet_memory.py (MemoryManager), the torch-module adapter colormnet_torch.py; the encoders / decoder of ColorMNet are not built
+(sequential in time, one clip per GPU: replicas only).  No CPU fallback."""
 import ctypes as C
 
 import numpy as np

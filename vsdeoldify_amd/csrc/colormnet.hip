@@ -147,6 +147,89 @@ __global__ void __launch_bounds__(256) mem_readout_kernel(const float* __restric
     }
 }
 
+// ---- usage of every memory element: the row sums of the sparse affinity (do_softmax(..., return_usage=True), memory_util.py:63-64;
+// MemoryManager.match_memory feeds them to KeyValueMemoryStore.update_usage).  Accumulated as 2^-40 fixed point in 64-bit integers:
+// integer adds commute, so the sums do not depend on the order the atomics land in (fp32 atomics would make the choice of the
+// long-term prototypes, a top-k over these sums, run-to-run dependent). ----
+__global__ void mem_usage_accum_kernel(const int* __restrict__ idx, const float* __restrict__ wgt, unsigned long long* __restrict__ acc, int N, int HW,
+                                       int K) {
+    const int b = blockIdx.y;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i >= (int64_t)K * HW) return;
+    const float w = wgt[(int64_t)b * K * HW + i];
+    if (w > 0.f) atomicAdd(acc + (int64_t)b * N + idx[(int64_t)b * K * HW + i], (unsigned long long)((double)w * 1099511627776.0 + 0.5));
+}
+__global__ void mem_usage_final_kernel(const unsigned long long* __restrict__ acc, float* __restrict__ usage, int64_t total) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < total) usage[i] = (float)((double)acc[i] * (1.0 / 1099511627776.0));
+}
+}  // namespace
+int launch_mem_usage(const int* idx, const float* wgt, unsigned long long* acc, float* usage, int B, int N, int HW, int K, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * N * 8, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(mem_usage_accum_kernel, dim3(cdiv((int64_t)K * HW, 256), B), dim3(256), 0, s, idx, wgt, acc, N, HW, K);
+    hipLaunchKernelGGL(mem_usage_final_kernel, dim3(cdiv((int64_t)B * N, 256)), dim3(256), 0, s, acc, usage, (int64_t)B * N);
+    return (int)hipGetLastError();
+}
+namespace {
+
+// ---- dense softmax over the memory axis + readout (memory consolidation, memory_manager.py:264-283: do_softmax(similarity) without
+// top-k, then v @ affinity).  sim [B][N][P] (P prototypes), mv [B][CV][N] -> out [B][CV][P].  One block per (prototype, batch):
+// column max and sum of exp by a block reduction, then every thread owns value channels. ----
+__global__ void __launch_bounds__(256) mem_dense_readout_kernel(const float* __restrict__ sim, const float* __restrict__ mv, float* __restrict__ out,
+                                                                int CV, int N, int P) {
+    __shared__ float red[256];
+    __shared__ float wbuf[1024];
+    const int p = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float* col = sim + (int64_t)b * N * P + p;
+    float m = -INFINITY;
+    for (int n = tid; n < N; n += 256) m = fmaxf(m, col[(int64_t)n * P]);
+    red[tid] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] = fmaxf(red[tid], red[tid + o]); __syncthreads(); }
+    m = red[0];
+    __syncthreads();
+    float sum = 0.f;
+    for (int n = tid; n < N; n += 256) sum += expf(col[(int64_t)n * P] - m);
+    red[tid] = sum;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+    const float inv = 1.0f / red[0];
+    __syncthreads();
+    // out[cv] = sum_n mv[cv][n] * exp(sim[n] - m) / sum: weights of 1024 memory elements at a time through LDS
+    float acc[8];                                                   // CV <= 2048: thread owns channels tid, tid + 256, ...
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+    for (int n0 = 0; n0 < N; n0 += 1024) {
+        const int nn = N - n0 < 1024 ? N - n0 : 1024;
+        for (int i = tid; i < nn; i += 256) wbuf[i] = expf(col[(int64_t)(n0 + i) * P] - m) * inv;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int cv = tid + k * 256;
+            if (cv < CV) {
+                const float* row = mv + ((int64_t)b * CV + cv) * N + n0;
+                float a = acc[k];
+                for (int i = 0; i < nn; ++i) a = fmaf(row[i], wbuf[i], a);
+                acc[k] = a;
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int cv = tid + k * 256;
+        if (cv < CV) out[((int64_t)b * CV + cv) * P + p] = acc[k];
+    }
+}
+}  // namespace
+int launch_mem_dense_readout(const float* sim, const float* mv, float* out, int B, int CV, int N, int P, hipStream_t s) {
+    if (CV > 2048) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(mem_dense_readout_kernel, dim3(P, B), dim3(256), 0, s, sim, mv, out, CV, N, P);
+    return (int)hipGetLastError();
+}
+namespace {
+
 // ---- local correlation (attention.py:827-835): out[n][(dy+R)*ws+(dx+R)][y*w+x] = sum_c q[n][c][y][x] k[n][c][y+dy*dil][x+dx*dil] ----
 // Block = 8 x 8 query pixels; K halo tile ((8 + 2 R dil)^2 pixels) staged in LDS 16 channels at a time; thread = pixel p (tid & 63)
 // and a quarter of the window rows (tid >> 6): for its rows dy it keeps the ws accumulators of one row at a time.

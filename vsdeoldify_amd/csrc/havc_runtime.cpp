@@ -1716,6 +1716,11 @@ static int stage_in_f(havc_ctx* c, int slot, const void* p, size_t nbytes, const
 
 int havc_memory_read_topk(havc_ctx* c, const float* mk, const float* ms, const float* qk, const float* qe, const float* mv, float* out, int B, int CK,
                           int CV, int N, int HW, int top_k) {
+    return havc_memory_read_topk_usage(c, mk, ms, qk, qe, mv, out, nullptr, B, CK, CV, N, HW, top_k);
+}
+
+int havc_memory_read_topk_usage(havc_ctx* c, const float* mk, const float* ms, const float* qk, const float* qe, const float* mv, float* out,
+                                float* usage, int B, int CK, int CV, int N, int HW, int top_k) {
     if (!c || !mk || !qk || !mv || !out || B < 1 || CK < 1 || CV < 1 || N < 1 || HW < 1 || top_k < 1 || top_k > 64)
         return fail(c, HAVC_E_INVALID, "memory_read_topk: bad args (top_k 1..64)");
     std::lock_guard<std::mutex> lk(c->mu);
@@ -1735,6 +1740,38 @@ int havc_memory_read_topk(havc_ctx* c, const float* mk, const float* ms, const f
     if (!e) e = launch_mem_topk_readout((const float*)c->scratch[8], d_mv, (int*)c->scratch[9], (float*)c->scratch[10], (float*)d_out, B, CV, N, HW, top_k, c->stream);
     c->stats.launches += 3;
     if (e) return hip_fail(c, (hipError_t)e, "memory_read_topk");
+    if (usage) {                                               // row sums of the sparse affinity (do_softmax(..., return_usage=True))
+        uint8_t* d_us;
+        bool uhost;
+        if ((rc = ensure_scratch(c, 11, (size_t)B * N * 8)) || (rc = stage_out_ptr(c, 6, usage, (size_t)B * N * 4, &d_us, &uhost))) return rc;
+        e = launch_mem_usage((const int*)c->scratch[9], (const float*)c->scratch[10], (unsigned long long*)c->scratch[11], (float*)d_us, B, N, HW, top_k,
+                             c->stream);
+        c->stats.launches += 2;
+        if (e) return hip_fail(c, (hipError_t)e, "memory_read_topk (usage)");
+        if ((rc = stage_out(c, usage, d_us, (size_t)B * N * 4, uhost))) return rc;
+    }
+    return stage_out(c, out, d_out, fo, host);
+}
+
+int havc_memory_dense_readout(havc_ctx* c, const float* mk, const float* ms, const float* qk, const float* qe, const float* mv, float* out, int B, int CK,
+                              int CV, int N, int P) {
+    if (!c || !mk || !qk || !mv || !out || B < 1 || CK < 1 || CV < 1 || CV > 2048 || N < 1 || P < 1)
+        return fail(c, HAVC_E_INVALID, "memory_dense_readout: bad args (CV <= 2048)");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t fmk = (size_t)B * CK * N * 4, fq = (size_t)B * CK * P * 4, fms = (size_t)B * N * 4, fmv = (size_t)B * CV * N * 4, fo = (size_t)B * CV * P * 4;
+    const float *d_mk, *d_ms = nullptr, *d_qk, *d_qe = nullptr, *d_mv;
+    uint8_t* d_out;
+    bool host;
+    int rc;
+    if ((rc = stage_in_f(c, 0, mk, fmk, &d_mk)) || (rc = stage_in_f(c, 1, qk, fq, &d_qk)) || (rc = stage_in_f(c, 3, mv, fmv, &d_mv)) ||
+        (ms && (rc = stage_in_f(c, 4, ms, fms, &d_ms))) || (qe && (rc = stage_in_f(c, 5, qe, fq, &d_qe))) || (rc = stage_out_ptr(c, 2, out, fo, &d_out, &host)) ||
+        (rc = ensure_scratch(c, 8, (size_t)B * N * P * 4)))
+        return rc;
+    int e = launch_mem_similarity(d_mk, d_ms, d_qk, d_qe, (float*)c->scratch[8], B, CK, N, P, c->stream);
+    if (!e) e = launch_mem_dense_readout((const float*)c->scratch[8], d_mv, (float*)d_out, B, CV, N, P, c->stream);
+    c->stats.launches += 2;
+    if (e) return hip_fail(c, (hipError_t)e, "memory_dense_readout");
     return stage_out(c, out, d_out, fo, host);
 }
 
