@@ -80,30 +80,36 @@ __global__ void __launch_bounds__(256) mem_similarity_kernel(const float* __rest
 // read with consecutive threads on consecutive queries (coalesced rows); the running top-k set lives in LDS ([k][thread]) with
 // its minimum cached in registers.  Output: idx [B][k][HW], w [B][k][HW] (w = exp(v) / sum exp(v), no max subtraction: the
 // reference's top-k branch has none). ----
-constexpr int TOPK_MAX = 64, TOPK_THREADS = 128;
-__global__ void __launch_bounds__(TOPK_THREADS) mem_topk_kernel(const float* __restrict__ sim, int* __restrict__ idx, float* __restrict__ wgt, int N,
-                                                                int HW, int K) {
+constexpr int TOPK_MAX = 64, TOPK_THREADS = 64, TOPK_MAXSPLIT = 64;
+// Two levels, so that the scan of the N memory elements is spread over the chip (one thread per query alone is HW / 64 = 26 blocks at
+// 30 x 54 features): level 1 = block (64 queries, one slice of the memory axis) keeps the slice's top-k per query; level 2 = the same
+// selection over the S x k survivors, then the softmax weights.  SRC_IDX: the values come with their memory indices (level 2).
+template <bool SRC_IDX, bool FINAL>
+__global__ void __launch_bounds__(TOPK_THREADS) mem_topk_kernel(const float* __restrict__ sim, const int* __restrict__ src_idx, int* __restrict__ idx,
+                                                                float* __restrict__ wgt, int N, int HW, int K, int slice_len) {
     extern __shared__ float sh[];                                   // val [K][T], then idx [K][T]
     float* val = sh;
     int* ind = reinterpret_cast<int*>(sh + K * TOPK_THREADS);
-    const int b = blockIdx.y, t = threadIdx.x, q = blockIdx.x * TOPK_THREADS + t;
+    const int b = blockIdx.z, sl = blockIdx.y, S = gridDim.y, t = threadIdx.x, q = blockIdx.x * TOPK_THREADS + t;
     if (q >= HW) return;
+    const int n0 = sl * slice_len, n1 = min(N, n0 + slice_len), cnt = max(n1 - n0, 0);
     const float* s = sim + (int64_t)b * N * HW + q;
-    const int first = N < K ? N : K;
+    const int* si = SRC_IDX ? src_idx + (int64_t)b * N * HW + q : nullptr;
+    const int first = cnt < K ? cnt : K;
     float vmin = INFINITY;
     int pmin = 0;
     for (int j = 0; j < first; ++j) {
-        const float v = s[(int64_t)j * HW];
+        const float v = s[(int64_t)(n0 + j) * HW];
         val[j * TOPK_THREADS + t] = v;
-        ind[j * TOPK_THREADS + t] = j;
+        ind[j * TOPK_THREADS + t] = SRC_IDX ? si[(int64_t)(n0 + j) * HW] : n0 + j;
         if (v < vmin) { vmin = v; pmin = j; }
     }
     for (int j = first; j < K; ++j) { val[j * TOPK_THREADS + t] = -INFINITY; ind[j * TOPK_THREADS + t] = 0; }
-    for (int n = first; n < N; ++n) {
+    for (int n = n0 + first; n < n1; ++n) {
         const float v = s[(int64_t)n * HW];
         if (v > vmin) {                                             // replace the current minimum, then find the new one
             val[pmin * TOPK_THREADS + t] = v;
-            ind[pmin * TOPK_THREADS + t] = n;
+            ind[pmin * TOPK_THREADS + t] = SRC_IDX ? si[(int64_t)n * HW] : n;
             vmin = INFINITY;
             for (int j = 0; j < K; ++j) {
                 const float u = val[j * TOPK_THREADS + t];
@@ -111,9 +117,18 @@ __global__ void __launch_bounds__(TOPK_THREADS) mem_topk_kernel(const float* __r
             }
         }
     }
+    if (!FINAL) {                                                   // survivors of this slice, query-major: [B][HW][S * K]
+        for (int j = 0; j < K; ++j) {
+            const int64_t o = ((int64_t)b * HW + q) * ((int64_t)S * K) + (int64_t)sl * K + j;
+            wgt[o] = val[j * TOPK_THREADS + t];                     // -inf marks an empty slot
+            idx[o] = ind[j * TOPK_THREADS + t];
+        }
+        return;
+    }
     float sum = 0.f;
     for (int j = 0; j < first; ++j) {
-        const float e = expf(val[j * TOPK_THREADS + t]);
+        const float v = val[j * TOPK_THREADS + t];
+        const float e = v == -INFINITY ? 0.f : expf(v);            // exp(v) / sum exp(v), no max subtraction (memory_util.py:44-47)
         val[j * TOPK_THREADS + t] = e;
         sum += e;
     }
@@ -121,6 +136,51 @@ __global__ void __launch_bounds__(TOPK_THREADS) mem_topk_kernel(const float* __r
         const int64_t o = ((int64_t)b * K + j) * HW + q;
         idx[o] = ind[j * TOPK_THREADS + t];
         wgt[o] = j < first ? val[j * TOPK_THREADS + t] / sum : 0.f;
+    }
+}
+
+// level 2: one wave per query picks the K largest of its M = S * K survivors (K rounds of a wave-wide arg-max over the LDS copy; ties go
+// to the earlier slice, as in a single scan) and turns them into softmax weights.
+__global__ void __launch_bounds__(64) mem_topk_merge_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx, int* __restrict__ idx,
+                                                            float* __restrict__ wgt, int M, int HW, int K) {
+    extern __shared__ float sh[];
+    float* cv = sh;
+    int* ci = reinterpret_cast<int*>(sh + M);
+    __shared__ float sel_v[TOPK_MAX];
+    __shared__ int sel_i[TOPK_MAX];
+    const int q = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int64_t base = ((int64_t)b * HW + q) * M;
+    for (int i = lane; i < M; i += 64) { cv[i] = cand_val[base + i]; ci[i] = cand_idx[base + i]; }
+    __syncthreads();
+    for (int k = 0; k < K; ++k) {
+        float best = -INFINITY;
+        int pos = M;
+        for (int i = lane; i < M; i += 64) {
+            const float v = cv[i];
+            if (v > best) { best = v; pos = i; }                    // ascending i: the earliest of equal values
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o);
+            const int op = __shfl_xor(pos, o);
+            if (ov > best || (ov == best && op < pos)) { best = ov; pos = op; }
+        }
+        if (lane == 0) {
+            sel_v[k] = best;
+            sel_i[k] = pos < M ? ci[pos] : 0;
+            if (pos < M) cv[pos] = -INFINITY;
+        }
+        __syncthreads();
+    }
+    const float v = lane < K ? sel_v[lane] : -INFINITY;
+    const float e = v == -INFINITY ? 0.f : expf(v);                // exp(v) / sum exp(v), no max subtraction (memory_util.py:44-47)
+    float sum = e;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane < K) {
+        const int64_t o = ((int64_t)b * K + lane) * HW + q;
+        idx[o] = sel_i[lane];
+        wgt[o] = sum > 0.f ? e / sum : 0.f;
     }
 }
 
@@ -292,34 +352,65 @@ __global__ void __launch_bounds__(256) local_corr_kernel(const float* __restrict
 }
 
 // ---- logits = corr + relative_emb(q) - 1e8 [window position outside the image]; softmax over the window (attention.py:806-846) ----
-// in place on the correlation buffer [n][ws*ws][h*w]; one thread per pixel (coalesced across pixels for every window position).
-__global__ void local_softmax_kernel(float* __restrict__ qk, const float* __restrict__ q, const float* __restrict__ rel_w, const float* __restrict__ rel_b,
-                                     int C, int H, int W, int R, int dil, int n_total) {
+// in place on the correlation buffer [n][ws*ws][h*w].  Block = 16 pixels x 16 groups of window positions (thread (p, g) owns positions
+// g, g + 16, ...: 15 of the 225): the 1x1 relative-embedding conv (225 x C MACs per pixel) and the softmax are spread over 16 threads
+// per pixel, the pixel's q vector is shared through LDS, maxima / sums are combined across the groups in a fixed order.
+constexpr int LS_PIX = 16, LS_GRP = 16, LS_MAXPOS = 15, LS_MAXC = 256;
+__global__ void __launch_bounds__(LS_PIX* LS_GRP) local_softmax_kernel(float* __restrict__ qk, const float* __restrict__ q, const float* __restrict__ rel_w,
+                                                                       const float* __restrict__ rel_b, int C, int H, int W, int R, int dil, int n_total) {
+    __shared__ float qs[LS_MAXC][LS_PIX];
+    __shared__ float red[LS_GRP][LS_PIX];
     const int ws = 2 * R + 1, WW = ws * ws, HWp = H * W;
-    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (i >= (int64_t)n_total * HWp) return;
-    const int n = (int)(i / HWp), p = (int)(i - (int64_t)n * HWp), y = p / W, x = p - y * W;
+    const int tid = threadIdx.x, pl = tid & (LS_PIX - 1), g = tid / LS_PIX;
+    const int64_t i = blockIdx.x * (int64_t)LS_PIX + pl;
+    const bool live = i < (int64_t)n_total * HWp;
+    const int n = live ? (int)(i / HWp) : 0, p = live ? (int)(i - (int64_t)n * HWp) : 0, y = p / W, x = p - y * W;
+    for (int c = g; c < C; c += LS_GRP) qs[c][pl] = live ? q[((int64_t)n * C + c) * HWp + p] : 0.f;
+    __syncthreads();
     float* col = qk + (int64_t)n * WW * HWp + p;
-    const float* qp = q + (int64_t)n * C * HWp + p;
+    float v[LS_MAXPOS];
     float mx = -INFINITY;
-    for (int d = 0; d < WW; ++d) {
-        float r = rel_b[d];
-        for (int c = 0; c < C; ++c) r += rel_w[d * C + c] * qp[(int64_t)c * HWp];
-        const int yy = y + (d / ws - R) * dil, xx = x + (d % ws - R) * dil;
-        const bool inside = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        float v = col[(int64_t)d * HWp] + r;
-        if (!inside) v -= 1e8f;
-        col[(int64_t)d * HWp] = v;
-        mx = fmaxf(mx, v);
+#pragma unroll
+    for (int j = 0; j < LS_MAXPOS; ++j) {
+        const int d = g + j * LS_GRP;
+        v[j] = -INFINITY;
+        if (d < WW && live) {
+            float r = rel_b[d];
+            const float* wr = rel_w + (int64_t)d * C;
+            for (int c = 0; c < C; ++c) r += wr[c] * qs[c][pl];
+            const int yy = y + (d / ws - R) * dil, xx = x + (d % ws - R) * dil;
+            float t = col[(int64_t)d * HWp] + r;
+            if (!((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)) t -= 1e8f;
+            v[j] = t;
+            mx = fmaxf(mx, t);
+        }
     }
+    red[g][pl] = mx;
+    __syncthreads();
+    mx = red[0][pl];
+#pragma unroll
+    for (int k = 1; k < LS_GRP; ++k) mx = fmaxf(mx, red[k][pl]);
+    __syncthreads();
     float sum = 0.f;
-    for (int d = 0; d < WW; ++d) {
-        const float e = expf(col[(int64_t)d * HWp] - mx);
-        col[(int64_t)d * HWp] = e;
+#pragma unroll
+    for (int j = 0; j < LS_MAXPOS; ++j) {
+        const float e = v[j] == -INFINITY ? 0.f : expf(v[j] - mx);
+        v[j] = e;
         sum += e;
     }
+    red[g][pl] = sum;
+    __syncthreads();
+    sum = red[0][pl];
+#pragma unroll
+    for (int k = 1; k < LS_GRP; ++k) sum += red[k][pl];
     const float inv = 1.f / sum;
-    for (int d = 0; d < WW; ++d) col[(int64_t)d * HWp] *= inv;
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < LS_MAXPOS; ++j) {
+            const int d = g + j * LS_GRP;
+            if (d < WW) col[(int64_t)d * HWp] = v[j] * inv;
+        }
+    }
 }
 
 // ---- agg[p][n][cv] = sum_d attn[n][d][p] v[n][cv][p + d]  (local2global + matmul of attention.py:850-853, without the dense map) ----
@@ -374,9 +465,24 @@ int launch_mem_similarity(const float* mk, const float* ms, const float* qk, con
     return (int)hipGetLastError();
 }
 
-int launch_mem_topk_readout(const float* sim, const float* mv, int* idx, float* wgt, float* out, int B, int CV, int N, int HW, int K, hipStream_t s) {
+int mem_topk_splits(int N) {                                  // slices of the memory axis at level 1 (1 = single level)
+    const int S = (N + 255) / 256;
+    return S < 2 ? 1 : (S > TOPK_MAXSPLIT ? TOPK_MAXSPLIT : S);
+}
+// cand_val / cand_idx: workspace of B * S * K * HW floats / ints each (S = mem_topk_splits(N)); unused when S == 1
+int launch_mem_topk_readout(const float* sim, const float* mv, int* idx, float* wgt, float* cand_val, int* cand_idx, float* out, int B, int CV, int N,
+                            int HW, int K, hipStream_t s) {
     if (K < 1 || K > TOPK_MAX) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(mem_topk_kernel, dim3(cdiv(HW, TOPK_THREADS), B), dim3(TOPK_THREADS), (size_t)K * TOPK_THREADS * 8, s, sim, idx, wgt, N, HW, K);
+    const int S = mem_topk_splits(N);
+    const size_t lds = (size_t)K * TOPK_THREADS * 8;
+    if (S == 1) {
+        hipLaunchKernelGGL((mem_topk_kernel<false, true>), dim3(cdiv(HW, TOPK_THREADS), 1, B), dim3(TOPK_THREADS), lds, s, sim, nullptr, idx, wgt, N, HW, K, N);
+    } else {
+        const int len = (N + S - 1) / S;
+        hipLaunchKernelGGL((mem_topk_kernel<false, false>), dim3(cdiv(HW, TOPK_THREADS), S, B), dim3(TOPK_THREADS), lds, s, sim, nullptr, cand_idx, cand_val, N,
+                           HW, K, len);
+        hipLaunchKernelGGL(mem_topk_merge_kernel, dim3(HW, B), dim3(64), (size_t)S * K * 8, s, cand_val, cand_idx, idx, wgt, S * K, HW, K);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(mem_readout_kernel, dim3(cdiv(HW, 64), cdiv(CV, 64), B), dim3(256), 0, s, mv, idx, wgt, out, CV, N, HW, K);
@@ -393,7 +499,9 @@ int launch_local_correlation(const float* q, const float* k, float* out, int n, 
 }
 
 int launch_local_softmax(float* qk, const float* q, const float* rel_w, const float* rel_b, int n, int C, int H, int W, int R, int dil, hipStream_t s) {
-    hipLaunchKernelGGL(local_softmax_kernel, dim3(cdiv((int64_t)n * H * W, 128)), dim3(128), 0, s, qk, q, rel_w, rel_b, C, H, W, R, dil, n);
+    const int ws = 2 * R + 1;
+    if (C > LS_MAXC || ws * ws > LS_GRP * LS_MAXPOS) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(local_softmax_kernel, dim3(cdiv((int64_t)n * H * W, LS_PIX)), dim3(LS_PIX * LS_GRP), 0, s, qk, q, rel_w, rel_b, C, H, W, R, dil, n);
     return (int)hipGetLastError();
 }
 

@@ -1734,10 +1734,13 @@ int havc_memory_read_topk_usage(havc_ctx* c, const float* mk, const float* ms, c
         (ms && (rc = stage_in_f(c, 4, ms, fms, &d_ms))) || (qe && (rc = stage_in_f(c, 5, qe, fq, &d_qe))) || (rc = stage_out_ptr(c, 2, out, fo, &d_out, &host)))
         return rc;
     // scratch 8: similarity [B][N][HW]; 9: top-k indices; 10: top-k weights
-    if ((rc = ensure_scratch(c, 8, (size_t)B * N * HW * 4)) || (rc = ensure_scratch(c, 9, (size_t)B * top_k * HW * 4)) ||
-        (rc = ensure_scratch(c, 10, (size_t)B * top_k * HW * 4))) return rc;
+    // scratch 9 / 10 also hold the level-1 survivors of the two-level top-k behind the final lists: [B][k][HW] + [B][S][k][HW]
+    const size_t lst = (size_t)B * top_k * HW, cand = lst * (mem_topk_splits(N) > 1 ? mem_topk_splits(N) : 0);
+    if ((rc = ensure_scratch(c, 8, (size_t)B * N * HW * 4)) || (rc = ensure_scratch(c, 9, (lst + cand) * 4)) ||
+        (rc = ensure_scratch(c, 10, (lst + cand) * 4))) return rc;
     int e = launch_mem_similarity(d_mk, d_ms, d_qk, d_qe, (float*)c->scratch[8], B, CK, N, HW, c->stream);
-    if (!e) e = launch_mem_topk_readout((const float*)c->scratch[8], d_mv, (int*)c->scratch[9], (float*)c->scratch[10], (float*)d_out, B, CV, N, HW, top_k, c->stream);
+    if (!e) e = launch_mem_topk_readout((const float*)c->scratch[8], d_mv, (int*)c->scratch[9], (float*)c->scratch[10], (float*)c->scratch[10] + lst,
+                                        (int*)c->scratch[9] + lst, (float*)d_out, B, CV, N, HW, top_k, c->stream);
     c->stats.launches += 3;
     if (e) return hip_fail(c, (hipError_t)e, "memory_read_topk");
     if (usage) {                                               // row sums of the sparse affinity (do_softmax(..., return_usage=True))
