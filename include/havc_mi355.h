@@ -338,7 +338,7 @@ int havc_dev_upload(havc_ctx* ctx, void* d_dst, const void* h_src, size_t nbytes
 int havc_dev_download(havc_ctx* ctx, void* h_dst, const void* d_src, size_t nbytes);
 int havc_dev_copy(havc_ctx* ctx, void* d_dst, const void* d_src, size_t nbytes);      /* device -> device, enqueued on the ctx stream */
 
-/* ---- ColorMNet exemplar path, first kernels (fp32, the reference's tensor layouts, host or device pointers) ----
+/* ---- ColorMNet exemplar path: the memory kernels (fp32, the reference's tensor layouts, host or device pointers) ----
  * havc_memory_read_topk replaces get_similarity + do_softmax(top_k) + readout (colormnet/model/memory_util.py:7-80) as
  * MemoryManager.match_memory calls them once per frame (colormnet/inference/memory_manager.py:58-150, top_k = 30):
  *   mk [B][CK][N] memory keys, ms [B][N] shrinkage or NULL, qk [B][CK][HW] query keys, qe [B][CK][HW] selection or NULL,
