@@ -130,3 +130,35 @@ def test_gpu_model_colorization_frame(ctx, model, hw):
     assert got.shape == img.shape and de.mean() < 0.5 and np.percentile(de, 99) < 2.5 and (d <= 1).mean() >= 0.97, \
         (de.mean(), np.percentile(de, 99), (d <= 1).mean(), d.max())
     mc.close()
+
+
+@gpu
+def test_gpu_model_colorization_coalesced_calls(ctx):
+    """colorize_frame from several threads through ModelColorization(coalesce=N): merged into batches (havc_batcher kind 2), every caller
+    gets the bytes of a call of its own."""
+    import threading
+    from vsdeoldify_amd.colorization import ModelColorization
+    sd = synth_zhang_state_dict("eccv16", 9)
+    imgs = [frame(120, 160, 300 + i) for i in range(8)]
+    mc = ModelColorization("eccv16", True, state_dict=sd)
+    want = [mc.colorize_frame(im) for im in imgs]
+    mc.close()
+    mc = ModelColorization("eccv16", True, state_dict=sd, coalesce=4)
+    got, errs = {}, []
+
+    def run(t):
+        try:
+            for i in (t, t + 4):
+                got[i] = mc.colorize_frame(imgs[i])
+        except Exception as e:                                                     # pragma: no cover
+            errs.append(e)
+    ts = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    assert all(np.array_equal(got[i], want[i]) for i in range(8))
+    calls, batches = mc._batchers[(120, 160)].stats()
+    assert calls == 8 and batches < 8
+    mc.close()

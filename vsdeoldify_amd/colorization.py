@@ -7,6 +7,7 @@ colorization/__init__.py:81).  Weights: the reference downloads them with model_
 (`$TORCH_HOME/hub/checkpoints/<file>.pth`) or injected as a state dict (tests / offline).  No CPU path.
 """
 import os
+import threading
 
 import numpy as np
 
@@ -18,6 +19,9 @@ CHECKPOINTS = {"eccv16": "colorization_release_v2-9b330a0b.pth", "siggraph17": "
 NET_SIZE = 256
 
 
+_batcher_lock = threading.Lock()
+
+
 class ModelColorization:
     _instance = None
     _initialized = False
@@ -27,7 +31,8 @@ class ModelColorization:
             cls._instance = super().__new__(cls)
         return cls._instance
 
-    def __init__(self, model="siggraph17", use_gpu=True, device_index=0, state_dict=None, max_batch=1):
+    def __init__(self, model="siggraph17", use_gpu=True, device_index=0, state_dict=None, max_batch=1, coalesce=0):
+        """coalesce = N > 0: colorize_frame calls made concurrently by N threads are merged into batches (havc_batcher, kind 2)"""
         if not use_gpu:
             raise nat.NativeLibraryError("vsdeoldify_amd.ModelColorization is MI355X only (use_gpu=False is not supported)")
         if self._initialized and self.colorizer_model == model and state_dict is None:
@@ -36,7 +41,8 @@ class ModelColorization:
             self.close()
         self.colorizer_model, self.use_gpu = model, use_gpu
         self.ctx = get_context(device_index)
-        self._colorize_init(state_dict, max_batch)
+        self._coalesce, self._batchers = coalesce, {}
+        self._colorize_init(state_dict, max(max_batch, coalesce))
         self._initialized = True
 
     def _colorize_init(self, state_dict, max_batch):
@@ -56,6 +62,9 @@ class ModelColorization:
             self.net.autotune(max_batch)
 
     def close(self):
+        for b in getattr(self, "_batchers", {}).values():
+            b.close()
+        self._batchers = {}
         if getattr(self, "net", None):
             self.net.close()
             self.weights.close()
@@ -74,6 +83,16 @@ class ModelColorization:
         img = np.asarray(frame_i)
         if img.ndim == 2:                                   # load_img_rgb, colorizers/util.py:15-18
             img = np.tile(img[:, :, None], 3)
+        if self._coalesce:
+            key = img.shape[:2]
+            b = self._batchers.get(key)
+            if b is None:
+                with _batcher_lock:
+                    b = self._batchers.get(key)
+                    if b is None:
+                        b = self._batchers[key] = nat.Batcher(self.ctx, self.net, kind=2, frame_hw=key, callers=self._coalesce,
+                                                              wait_us=int(os.environ.get("HAVC_COALESCE_WAIT_US", "300")))
+            return b.submit(img)
         return self.colorize_frames(img[None])[0]
 
 
