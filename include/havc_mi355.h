@@ -197,7 +197,10 @@ int havc_net_profile(havc_net* net, int batch, float* ms_per_op, int n_ops);
  * speed.  Costs about a second per net; *n_changed (may be NULL) = ops whose configuration differs from the heuristic's.
  * havc_net_get_cfg returns the configuration id an op will run with (0 = heuristic). */
 int havc_net_autotune(havc_net* net, int batch, int* n_changed);
+int havc_device_name(havc_ctx* ctx, char* buf, int nbuf);      /* "<marketing name>/<gcn arch>/<compute units>": keys the tuning cache */
 int havc_net_get_cfg(havc_net* net, int op_index);
+/* restore a configuration found by an earlier havc_net_autotune (a host-side cache); refuses ids that are not legal for the op */
+int havc_net_set_cfg(havc_net* net, int op_index, int cfg);
 
 /* ---- frame-in / frame-out entry points (host buffers, blocking) ---------------------------------
  * havc_deoldify_frames replaces ModelImageRender.get_transformed_image (deoldify/visualize.py:118-137)

@@ -282,3 +282,32 @@ def test_halo_conv_kernel_identical_to_pipe_kernel(ctx, shape):
     spec.loader.exec_module(hc)
     ref, got = hc.check(shape)
     assert np.isfinite(got).all() and np.array_equal(ref, got)
+
+
+def test_tuning_cache_round_trip(ctx, tmp_path, monkeypatch):
+    """Net.autotune remembers its result across processes (a file per plan / batch / device / library build under HAVC_TUNE_CACHE):
+    the second net of the same plan restores the configurations without measuring; a damaged file is ignored; "0" disables."""
+    import os
+    from vsdeoldify_amd.render import GeneratorRuntime
+    from vsdeoldify_amd.synth import synth_state_dict
+    monkeypatch.setenv("HAVC_AUTOTUNE", "1")
+    monkeypatch.setenv("HAVC_TUNE_CACHE", str(tmp_path))
+    sd = synth_state_dict("wide", 1)
+
+    def tuned_cfgs():
+        rt = GeneratorRuntime(ctx, sd, "wide")
+        try:
+            return rt.net(96, 2).cfgs()
+        finally:
+            rt.close()
+    first = tuned_cfgs()
+    files = list(tmp_path.iterdir())
+    assert len(files) == 1 and any(c != 0 for c in first)
+    assert tuned_cfgs() == first                                                   # restored
+    files[0].write_bytes(b"\x00" * 7)                                              # damaged: measured again, rewritten
+    again = tuned_cfgs()
+    assert len(again) == len(first) and files[0].stat().st_size == 4 * len(first)
+    monkeypatch.setenv("HAVC_TUNE_CACHE", "0")
+    files[0].unlink()
+    tuned_cfgs()
+    assert not list(tmp_path.iterdir())

@@ -80,7 +80,9 @@ SYMBOLS = [
     ("havc_net_run_ops", _I, [_P, _I, _I, _I]),
     ("havc_net_profile", _I, [_P, _I, _P, _I]),
     ("havc_net_autotune", _I, [_P, _I, C.POINTER(_I)]),
+    ("havc_device_name", _I, [_P, C.c_char_p, _I]),
     ("havc_net_get_cfg", _I, [_P, _I]),
+    ("havc_net_set_cfg", _I, [_P, _I, _I]),
     ("havc_deoldify_frames", _I, [_P, _P, _P, _F, _I, _P, _P, _I]),
     ("havc_zhang_frames", _I, [_P, _P, _P, _P, _I, _I, _I]),
     ("havc_ddcolor_frames", _I, [_P, _P, _P, _P, _I, _I, _I]),
@@ -201,6 +203,11 @@ class Context:
     def synchronize(self):
         check(self.lib.havc_synchronize(self.h), self.h)
 
+    def device_name(self):
+        buf = C.create_string_buffer(256)
+        check(self.lib.havc_device_name(self.h, buf, 256), self.h)
+        return buf.value.decode()
+
     # ---- device memory for resident clips ----
     def dev_alloc(self, nbytes):
         p = C.c_void_p()
@@ -296,13 +303,52 @@ class Net:
         check(self.ctx.lib.havc_net_run_rgb8(self.h, d_in, d_out, batch), self.ctx.h)
 
     def autotune(self, batch=None):
-        """measure the conv tile configurations once and keep the fastest per op (same bytes, only speed changes)"""
+        """measure the conv tile configurations once and keep the fastest per op (same bytes, only speed changes).  The result is
+        remembered across processes in ~/.cache/havc_mi355/tune (HAVC_TUNE_CACHE=0 disables, or names another directory): keyed by
+        the plan, the batch, the device name and the library build, restored through havc_net_set_cfg (which refuses stale ids)."""
         if getattr(self, "_tuned", False):
             return 0
+        batch = int(batch or self.max_batch)
+        path = self._tune_cache_path(batch)
+        if path and os.path.isfile(path):
+            try:
+                cfgs = np.fromfile(path, dtype=np.int32)
+                if len(cfgs) == len(self.ops) and all(self.ctx.lib.havc_net_set_cfg(self.h, i, int(c)) == 0 for i, c in enumerate(cfgs)):
+                    self._tuned = True
+                    return int((cfgs != 0).sum())
+            except OSError:
+                pass
+            for i in range(len(self.ops)):                    # a stale / foreign file: back to the heuristic, then measure
+                self.ctx.lib.havc_net_set_cfg(self.h, i, 0)
         n = C.c_int(0)
-        check(self.ctx.lib.havc_net_autotune(self.h, int(batch or self.max_batch), C.byref(n)), self.ctx.h)
+        check(self.ctx.lib.havc_net_autotune(self.h, batch, C.byref(n)), self.ctx.h)
         self._tuned = True
+        if path:
+            try:
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                tmp = f"{path}.{os.getpid()}.tmp"
+                np.asarray(self.cfgs(), dtype=np.int32).tofile(tmp)
+                os.replace(tmp, path)
+            except OSError:
+                pass
         return n.value
+
+    def _tune_cache_path(self, batch):
+        import hashlib
+        root = os.environ.get("HAVC_TUNE_CACHE", os.path.join(os.path.expanduser("~"), ".cache", "havc_mi355", "tune"))
+        if root in ("0", ""):
+            return None
+        try:
+            st = os.stat(LIB_PATH)
+        except OSError:
+            return None
+        ops = self.ops.copy()
+        ops["reserved"] = 0
+        for f in ("w_off", "bias_off", "scale_off", "shift_off", "tag"):
+            ops[f] = 0                                        # weight offsets / labels do not change what is fastest
+        h = hashlib.sha1(ops.tobytes() + self.bufs.tobytes())
+        h.update(f"{batch}|{self.ctx.device_name()}|{st.st_size}|{st.st_mtime_ns}".encode())
+        return os.path.join(root, h.hexdigest() + ".i32")
 
     def cfgs(self):
         return [self.ctx.lib.havc_net_get_cfg(self.h, i) for i in range(len(self.ops))]

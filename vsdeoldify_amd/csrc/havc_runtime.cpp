@@ -882,6 +882,32 @@ int havc_net_run_ops(havc_net* n, int first_op, int n_ops, int batch) {
 
 // Per-op choice of the conv tile configuration by measurement.  Every candidate computes the same bytes (same packed K order,
 // same MFMA sequence per output), so tuning never changes a result; ops with the same shape signature are tuned once.
+// tile configurations an op may run with (all produce the same bytes); empty = the op has exactly one legal configuration
+static std::vector<int> tune_candidates(const havc_op& op) {
+    if (op.type != HAVC_OP_CONV || (op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_OUT_RGB8 | HAVC_F_FUSE_PROJ))) return {};
+    std::vector<int> cand = {0};
+    if (op.Npad <= 16) return cand;                                        // thin N: the 128x16 kernel only
+    // column tiles of 256 / 128 channels: also when the last tile is >= 75 % full (ConvNeXt pwconv2 at stage 0, 768 -> 192: the
+    // 256 x 256 tile beats every narrower one by 30 %)
+    if (op.Npad % 256 == 0 || op.Npad % 256 >= 192) { for (int k : {60, 71, 90, 91, 96, 97}) cand.push_back(k); }
+    if (op.Npad % 256 == 16) cand.push_back(61);
+    // 128-wide tiles for every wide layer: the DynamicUnetDeep (artistic) channel counts 304 / 320 / 672 / 1344 fit no tile exactly and
+    // a partly empty last tile on the pipelined kernel still beats the register-staged kernels there
+    if (op.Npad % 128 == 0 || op.Npad % 128 >= 96 || op.Npad > 256) { for (int k : {70, 72, 93, 95, 98}) cand.push_back(k); }
+    for (int k : {1, 2, 3, 7}) cand.push_back(k);                          // register-staged 128x128 / 128x64 / 64x64 / 64x128
+    return cand;
+}
+
+int havc_net_set_cfg(havc_net* n, int op_index, int cfg) {
+    if (!n || op_index < 0 || op_index >= (int)n->ops.size()) return HAVC_E_INVALID;
+    const std::vector<int> cand = tune_candidates(n->ops[op_index]);
+    if (std::find(cand.begin(), cand.end(), cfg) == cand.end())
+        return cfg == 0 ? HAVC_OK : fail(n->ctx, HAVC_E_INVALID, "net_set_cfg: not a legal tile configuration for this op");
+    std::lock_guard<std::mutex> lk(n->ctx->mu);
+    n->ops[op_index].reserved = cfg;
+    return HAVC_OK;
+}
+
 int havc_net_autotune(havc_net* n, int batch, int* n_changed) {
     if (!n) return HAVC_E_INVALID;
     havc_ctx* c = n->ctx;
@@ -897,21 +923,12 @@ int havc_net_autotune(havc_net* n, int batch, int* n_changed) {
     const havc_stats keep = c->stats;
     for (size_t i = 0; i < n->ops.size() && rc == HAVC_OK; ++i) {
         havc_op& op = n->ops[i];
-        if (op.type != HAVC_OP_CONV || (op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_OUT_RGB8 | HAVC_F_FUSE_PROJ))) continue;   // one legal config each
+        if (tune_candidates(op).empty()) continue;                          // not a conv, or one legal config
         const std::vector<int64_t> sig = {op.flags, op.Hi, op.Wi, op.Ci, op.Ho, op.Wo, op.Co, op.kh, op.kw, op.stride, op.pad, op.dil, op.Kc,
                                           op.Npad, op.src_cpitch, op.dst_cpitch, op.res_cpitch, op.aux1, op.out_step};
         auto it = seen.find(sig);
         if (it != seen.end()) { if (op.reserved != it->second) { op.reserved = it->second; ++changed; } continue; }
-        std::vector<int> cand = {0};
-        // column tiles of 256 / 128 channels: also when the last tile is >= 75 % full (ConvNeXt pwconv2 at stage 0, 768 -> 192: the
-        // 256 x 256 tile beats every narrower one by 30 %)
-        if (op.Npad % 256 == 0 || op.Npad % 256 >= 192) { for (int k : {60, 71, 90, 91, 96, 97}) cand.push_back(k); }
-        if (op.Npad % 256 == 16) cand.push_back(61);
-        // 128-wide tiles for every wide layer: the DynamicUnetDeep (artistic) channel counts 304 / 320 / 672 / 1344 fit no tile exactly and
-        // a partly empty last tile on the pipelined kernel still beats the register-staged kernels there
-        if (op.Npad % 128 == 0 || op.Npad % 128 >= 96 || op.Npad > 256) { for (int k : {70, 72, 93, 95, 98}) cand.push_back(k); }
-        if (op.Npad <= 16) cand = {0};                                     // thin N: the 128x16 kernel only
-        else { cand.push_back(1); cand.push_back(2); cand.push_back(3); cand.push_back(7); }   // register-staged 128x128 / 128x64 / 64x64 / 64x128
+        const std::vector<int> cand = tune_candidates(op);
         const int before = op.reserved;
         int best = before;
         float best_ms = 1e30f;
@@ -939,6 +956,14 @@ int havc_net_autotune(havc_net* n, int batch, int* n_changed) {
     c->err.clear();
     if (n_changed) *n_changed = changed;
     return rc;
+}
+
+int havc_device_name(havc_ctx* c, char* buf, int nbuf) {
+    if (!c || !buf || nbuf < 2) return HAVC_E_INVALID;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->dev) != hipSuccess) return fail(c, HAVC_E_HIP, "hipGetDeviceProperties failed");
+    snprintf(buf, (size_t)nbuf, "%s/%s/%d", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return HAVC_OK;
 }
 
 int havc_net_get_cfg(havc_net* n, int op_index) {
