@@ -105,7 +105,7 @@ def test_conv_tile_configurations_are_bit_identical(ctx, flags, with_res):
         assert np.array_equal(o.view(np.uint16), base.view(np.uint16)), f"cfg {cfg} differs from the heuristic's choice"
 
 
-@pytest.mark.parametrize("cout", [192, 224, 96, 320, 304])
+@pytest.mark.parametrize("cout", [192, 224, 96, 320, 304, 64])
 def test_conv_tile_configurations_with_a_ragged_last_column_tile(ctx, cout):
     """channel counts that leave the 256- / 128-wide column tiles partly empty (ConvNeXt pwconv2 at stage 0: 768 -> 192): the tuner
     may still pick those tiles (<= 25 % of the tile idle), so they must produce the heuristic's bytes there too."""
@@ -116,6 +116,8 @@ def test_conv_tile_configurations_with_a_ragged_last_column_tile(ctx, cout):
     res = h16(r.standard_normal((2, cout, 18, 21)))
     kw = dict(bias=bias, pad=0, flags=nat.F_AFFINE | nat.F_RESIDUAL, res=res, scale=sc, shift=sh)
     cfgs = (0, 1, 60, 96, 97, 91, 71) if cout % 256 >= 192 else (0, 1, 70, 72, 93, 95, 98)       # 320, 304: DynamicUnetDeep widths
+    if cout % 64 == 0 and cout <= 192:
+        cfgs = cfgs + (99, 92)                                                                       # 64-wide pipelined tiles
     outs = {cfg: gu.conv_op(ctx, x, Wt, cfg=cfg, **kw)[1] for cfg in cfgs}
     for cfg, o in outs.items():
         assert np.array_equal(o.view(np.uint16), outs[0].view(np.uint16)), f"cfg {cfg} differs from the heuristic's choice"

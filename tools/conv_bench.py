@@ -45,6 +45,8 @@ SHAPES = {  # name: (Cin, Cout, k, stride, pad, H, W, flags)
     "e2_c3_1x1": (128, 512, 1, 1, 0, 70, 70, nat.F_RELU_POST),
     "e1_c3_1x1": (64, 256, 1, 1, 0, 140, 140, nat.F_RELU_POST),
     "e1_c1_1x1": (256, 64, 1, 1, 0, 140, 140, nat.F_RELU_PRE),
+    "e1_c2_3x3": (64, 64, 3, 1, 1, 140, 140, nat.F_RELU_PRE),
+    "stem7x7": (3, 64, 7, 2, 3, 560, 560, nat.F_RELU_PRE),
     "attn_qk": (512, 128, 1, 1, 0, 70, 70, 0),
     "l4ps": (2048, 2048, 1, 1, 0, 18, 18, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),
     "l5ps": (512, 2048, 1, 1, 0, 35, 35, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),

@@ -549,6 +549,8 @@ int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
         case 96: return launch_pipe<2, 4, 4, 0>(a, s);        // 128 x 256, 8 waves
         case 97: return launch_pipe<2, 4, 6, 0>(a, s);        // 192 x 256, 8 waves
         case 98: return launch_pipe<4, 2, 4, 0>(a, s);        // 256 x 128, 8 waves
+        case 99: return launch_pipe<4, 1, 4, 0>(a, s);        // 256 x  64, 4 waves: the 64-channel layers (ResNet layer1, the stem)
+        case 92: return launch_pipe<2, 1, 4, 0>(a, s);        // 128 x  64, 2 waves
         case 74: return launch_pipe<2, 2, 4, 0, 1>(a, s);     // ablations of cfg 70 (profiling only): no DMA in the loop
         case 75: return launch_pipe<2, 2, 4, 0, 4>(a, s);     //   no MFMA
         case 76: return launch_pipe<2, 2, 4, 0, 5>(a, s);     //   no epilogue

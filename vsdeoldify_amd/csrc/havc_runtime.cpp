@@ -894,6 +894,7 @@ static std::vector<int> tune_candidates(const havc_op& op) {
     // 128-wide tiles for every wide layer: the DynamicUnetDeep (artistic) channel counts 304 / 320 / 672 / 1344 fit no tile exactly and
     // a partly empty last tile on the pipelined kernel still beats the register-staged kernels there
     if (op.Npad % 128 == 0 || op.Npad % 128 >= 96 || op.Npad > 256) { for (int k : {70, 72, 93, 95, 98}) cand.push_back(k); }
+    if (op.Npad % 64 == 0 && op.Npad <= 192) { cand.push_back(99); cand.push_back(92); }      // 64-wide pipelined tiles (ResNet layer1, stem)
     for (int k : {1, 2, 3, 7}) cand.push_back(k);                          // register-staged 128x128 / 128x64 / 64x64 / 64x128
     return cand;
 }
