@@ -68,6 +68,10 @@ def patch_reference_colormnet(network, processor=None, device_index=0):
     network.short_term_attn = new
     old_mem = None
     if processor is not None:
+        import sys
         old_mem = processor.memory
         processor.memory = MemoryManager(processor.config, device_index=device_index)
+        mod = sys.modules.get(type(processor).__module__)          # InferenceCore.clear_memory() builds a fresh MemoryManager(config=...)
+        if mod is not None and hasattr(mod, "MemoryManager"):
+            mod.MemoryManager = MemoryManager
     return old, old_mem
