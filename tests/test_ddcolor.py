@@ -277,3 +277,15 @@ def test_gpu_ddcolor_coalesced_per_frame_calls(ctx):
         for b in shared._batchers.values():
             b.close()
         ref.rt.close(); shared.rt.close()
+
+
+def test_checkpoint_file_layouts_load(tmp_path):
+    """ddcolor_modelscope.pth / ddcolor_artistic.pth as published: {'params': state_dict} (or a bare state dict) of torch tensors under
+    the public key names -- what DDColorRender(model_dir=...) reads (the real files cannot be fetched here)."""
+    from vsdeoldify_amd.ddcolor import DDColorRender, load_state_dict
+    sd = synth_ddcolor_state_dict(6, **SMALL)
+    tsd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    for name, obj in ((DDColorRender.MODEL_FILES[0], {"params": tsd}), (DDColorRender.MODEL_FILES[1], tsd)):
+        torch.save(obj, tmp_path / name)
+        got = load_state_dict(str(tmp_path / name))
+        assert set(got) == set(sd) and all(np.array_equal(got[k], sd[k]) for k in sd)
