@@ -284,7 +284,7 @@ def test_checkpoint_file_layouts_load(tmp_path):
     the public key names -- what DDColorRender(model_dir=...) reads (the real files cannot be fetched here)."""
     from vsdeoldify_amd.ddcolor import DDColorRender, load_state_dict
     sd = synth_ddcolor_state_dict(6, **SMALL)
-    tsd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in sd.items()}
+    tsd = {k: torch.tensor(v) for k, v in sd.items()}
     for name, obj in ((DDColorRender.MODEL_FILES[0], {"params": tsd}), (DDColorRender.MODEL_FILES[1], tsd)):
         torch.save(obj, tmp_path / name)
         got = load_state_dict(str(tmp_path / name))
