@@ -4,6 +4,8 @@ Tolerances: activations are stored as fp16 and accumulated in fp32 on MFMA, so a
 from the fp32 oracle (fed the SAME fp16-rounded inputs and weights) by fp16 output rounding (2^-11 rel)
 plus accumulation-order noise: |diff| <= 2e-3 * max|ref| + 2e-3.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
