@@ -243,13 +243,15 @@ def test_gpu_ddcolor_frames_do_not_depend_on_the_batch(ctx, S):
 
 
 @pytest.mark.gpu
-def test_gpu_ddcolor_coalesced_per_frame_calls(ctx):
+def test_gpu_ddcolor_coalesced_per_frame_calls(ctx, monkeypatch):
     """colorize_frame from several threads through one DDColorRender(coalesce=N): the calls are merged into batches and every caller
     gets the bytes of a call of its own (a DDColor pass costs 7.7 ms alone and 1.2 ms per frame in a batch of 16)."""
     import threading
     from vsdeoldify_amd.ddcolor import DDColorRender
+    monkeypatch.setenv("HAVC_COALESCE_WAIT_US", "50000")     # a leader waits up to 50 ms for its batch to fill: coalescing is certain
     sd = synth_ddcolor_state_dict(5, **SMALL)
     T, K, S = 5, 3, 64
+    start = threading.Barrier(T)
     r = np.random.default_rng(3)
     frames = [r.integers(0, 256, (S, S, 1), dtype=np.uint8).repeat(3, -1) for _ in range(T * K)]
     ref = DDColorRender(model=1, input_size=S, state_dict=sd, **SMALL)
@@ -260,6 +262,7 @@ def test_gpu_ddcolor_coalesced_per_frame_calls(ctx):
 
         def run(t):
             try:
+                start.wait()
                 for k in range(K):
                     got[t * K + k] = shared.colorize_frame(frames[t * K + k])
             except Exception as e:                                                 # pragma: no cover

@@ -175,7 +175,7 @@ def test_worker_contexts_run_concurrently_and_share_weights(ctx):
 
 
 @pytest.mark.parametrize("coalesce", [6, 2])
-def test_coalesced_per_frame_calls_match_separate_calls(ctx, coalesce):
+def test_coalesced_per_frame_calls_match_separate_calls(ctx, coalesce, monkeypatch):
     """The reference's call shape is ONE get_transformed_image per frame from each VapourSynth worker thread.  A render built with
     coalesce=N merges the concurrent calls of N threads into batches (havc_batcher): every caller gets exactly the bytes of a call of
     its own, and fewer batches than calls were run."""
@@ -184,7 +184,9 @@ def test_coalesced_per_frame_calls_match_separate_calls(ctx, coalesce):
     from tests.test_gpu_deoldify import make_frame
     from vsdeoldify_amd.render import ModelImageRender
     sds = {"video": synth_state_dict("wide", 1), "stable": synth_state_dict("wide", 2)}
+    monkeypatch.setenv("HAVC_COALESCE_WAIT_US", "50000")     # a leader waits up to 50 ms for its batch to fill: coalescing is certain
     T, K = 6, 4
+    start = threading.Barrier(T)
     frames = [make_frame(64, 300 + i) for i in range(T * K)]
     ref = ModelImageRender(None, "stable", 4, 0.5, state_dicts=sds)
     want = [np.asarray(ref.get_transformed_image(Image.fromarray(f))) for f in frames]
@@ -193,6 +195,7 @@ def test_coalesced_per_frame_calls_match_separate_calls(ctx, coalesce):
 
     def run(t):
         try:
+            start.wait()
             for k in range(K):
                 i = t * K + k
                 got[i] = np.asarray(shared.get_transformed_image(Image.fromarray(frames[i])))

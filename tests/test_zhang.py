@@ -133,11 +133,13 @@ def test_gpu_model_colorization_frame(ctx, model, hw):
 
 
 @gpu
-def test_gpu_model_colorization_coalesced_calls(ctx):
+def test_gpu_model_colorization_coalesced_calls(ctx, monkeypatch):
     """colorize_frame from several threads through ModelColorization(coalesce=N): merged into batches (havc_batcher kind 2), every caller
     gets the bytes of a call of its own."""
     import threading
     from vsdeoldify_amd.colorization import ModelColorization
+    monkeypatch.setenv("HAVC_COALESCE_WAIT_US", "50000")     # a leader waits up to 50 ms for its batch to fill: coalescing is certain
+    start = threading.Barrier(4)
     sd = synth_zhang_state_dict("eccv16", 9)
     imgs = [frame(120, 160, 300 + i) for i in range(8)]
     mc = ModelColorization("eccv16", True, state_dict=sd)
@@ -148,6 +150,7 @@ def test_gpu_model_colorization_coalesced_calls(ctx):
 
     def run(t):
         try:
+            start.wait()
             for i in (t, t + 4):
                 got[i] = mc.colorize_frame(imgs[i])
         except Exception as e:                                                     # pragma: no cover
