@@ -74,8 +74,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
-    ap.add_argument("--clip-frames", type=int, default=16, help="distinct synthetic frames resident per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--clip-frames", type=int, default=32, help="distinct synthetic frames resident per GPU")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"],
                     help="c2 = BASELINE configs[1] (headline), c3 = configs[2] (DDColor large, input 512), c4 = configs[3] (DeOldify+DDColor merge)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,7 +157,10 @@ def main():
     total_frames = args.steps * args.batch * world
     S = RENDER_FACTOR * 16
     c = 259
-    conv_flops = 2.0 * args.batch * S * S * c * c * 9            # algorithmic FLOPs of ONE tail res-conv launch
+    # four tagged convs per step (two passes x two res-block convs); a conv whose operands exceed a 32-bit buffer descriptor runs as
+    # several equal launches (32 frames of the 560 x 560 tail = 2 x 16) and every launch has its own event pair
+    frames_per_launch = args.steps * args.batch * 4 / max(int(launches.value), 1)
+    conv_flops = 2.0 * frames_per_launch * S * S * c * c * 9     # algorithmic FLOPs of ONE tail res-conv launch
     achieved = conv_flops / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
     # HBM bytes per launch of the dominant kernel: NOT measured in this run (a PMC pass cannot share a run with the timing);
     # taken from the committed result of separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this same command
@@ -165,7 +168,7 @@ def main():
     traffic, traffic_source = None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
-        if pmc.get("frames_per_launch") == args.batch:
+        if pmc.get("frames_per_launch") == round(frames_per_launch):
             traffic = pmc["traffic_bytes_per_launch"]
             traffic_source = f"{PMC_FILE}: separate rocprofv3 --pmc passes of this command (tools/pmc_bench.sh), not this run"
     except Exception:
@@ -184,7 +187,7 @@ def main():
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
                      "kernel": "conv_pipe_kernel<2,4,8,1> (layers.10 res-block 3x3 259->259 @560x560, 2 launches/pass; the 2nd also runs layers.11/12 in its epilogue)",
-                     "launches_timed": int(launches.value), "avg_launch_ms": round(avg_ms.value, 4),
+                     "launches_timed": int(launches.value), "frames_per_launch": round(frames_per_launch, 2), "avg_launch_ms": round(avg_ms.value, 4),
                      "flops_per_launch": conv_flops},
         "gpu_ms_per_frame": round(st.total_ms / max(st.frames, 1), 4),
     }

@@ -347,7 +347,11 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                 const uint64_t rf = a.res ? (uint64_t)n->bufdesc[op.src2].elems_per_frame * n->bufdesc[op.src2].elem_bytes : 0;
                 int chunk = batch;
                 const uint64_t big = std::max(xf, std::max(yf, rf));
-                if (big * (uint64_t)batch > lim) chunk = (int)std::max<uint64_t>(1, lim / big);
+                if (big * (uint64_t)batch > lim) {
+                    chunk = (int)std::max<uint64_t>(1, lim / big);
+                    const int nch = (batch + chunk - 1) / chunk;           // equal launches (32 frames of the 560 x 560 tail: 16 + 16, not 18 + 14)
+                    chunk = (batch + nch - 1) / nch;
+                }
                 const char* w0 = (const char*)a.w;
                 uint64_t wf = 0;
                 if (op.flags & HAVC_F_W_FROM_BUF) {        // per-frame weights taken from an activation buffer: one launch per frame
@@ -358,6 +362,17 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                 uint8_t* rgb0 = a.fuse_rgb;
                 for (int f0 = 0; f0 < batch && e == 0; f0 += chunk) {
                     const int nb = std::min(chunk, batch - f0);
+                    if (timed && f0 > 0) {                                 // tag timing is per LAUNCH: close this pair, open the next
+                        HIP_TRY(c, hipEventRecord(evp.second, s));
+                        if (c->tag_used == c->tag_events.size()) {
+                            hipEvent_t ea, eb;
+                            HIP_TRY(c, hipEventCreate(&ea));
+                            HIP_TRY(c, hipEventCreate(&eb));
+                            c->tag_events.emplace_back(ea, eb);
+                        }
+                        evp = c->tag_events[c->tag_used++];
+                        HIP_TRY(c, hipEventRecord(evp.first, s));
+                    }
                     a.x = (const half_t*)(x0 + (uint64_t)f0 * xf);
                     a.y = y0 + (uint64_t)f0 * yf;
                     if (r0) a.res = (const half_t*)(r0 + (uint64_t)f0 * rf);
