@@ -376,3 +376,148 @@ def synth_ddcolor_state_dict(seed=0, depths=DDCOLOR_DEPTHS, dec_layers=9, querie
     out = OrderedDict((k, sd[k]) for k in spec)
     _CACHE[key] = out
     return out
+
+
+# ---- ColorMNet (reference modules colormnet/model/{network,modules,resnet,cbam,attention}.py) -----------------
+DINO_DIM, DINO_DEPTH, DINO_GRID = 384, 12, 37
+
+
+def colormnet_state_dict_spec(key_dim=64, value_dim=512, hidden_dim=64):
+    """name -> shape in the order of the reference's ColorMNet.state_dict() (checked against tests/golden/spec_colormnet.json,
+    which was dumped from the reference module tree; the DINOv2 backbone keys are those of the hub model, oracle/dinov2.py)."""
+    spec = OrderedDict()
+
+    def conv(p, co, ci, k, bias=True):
+        spec[p + ".weight"] = (co, ci, k, k)
+        if bias:
+            spec[p + ".bias"] = (co,)
+
+    def lin(p, co, ci):
+        spec[p + ".weight"], spec[p + ".bias"] = (co, ci), (co,)
+
+    def ln(p, c):
+        spec[p + ".weight"], spec[p + ".bias"] = (c,), (c,)
+
+    def trunk(p, kind, nblk, extra):
+        conv(p + ".conv1", 64, 3 + extra, 7, bias=False)
+        _bn(spec, p + ".bn1", 64)
+        inpl, exp = 64, (4 if kind == "bottleneck" else 1)
+        names = ("res2", "layer2", "layer3") if kind == "bottleneck" else ("layer1", "layer2", "layer3")
+        for li, (n, name) in enumerate(zip(nblk, names)):
+            planes = 64 * 2 ** li
+            for bi in range(n):
+                q = f"{p}.{name}.{bi}"
+                if kind == "bottleneck":
+                    conv(q + ".conv1", planes, inpl, 1, False); _bn(spec, q + ".bn1", planes)
+                    conv(q + ".conv2", planes, planes, 3, False); _bn(spec, q + ".bn2", planes)
+                    conv(q + ".conv3", planes * 4, planes, 1, False); _bn(spec, q + ".bn3", planes * 4)
+                else:
+                    conv(q + ".conv1", planes, inpl, 3, False); _bn(spec, q + ".bn1", planes)
+                    conv(q + ".conv2", planes, planes, 3, False); _bn(spec, q + ".bn2", planes)
+                if bi == 0 and (li > 0 or inpl != planes * exp):
+                    conv(q + ".downsample.0", planes * exp, inpl, 1, False); _bn(spec, q + ".downsample.1", planes * exp)
+                inpl = planes * exp
+
+    def fusion(p, x_in, g_in, mid, out):
+        conv(p + ".block1.downsample", mid, x_in + g_in, 3); conv(p + ".block1.conv1", mid, x_in + g_in, 3); conv(p + ".block1.conv2", mid, mid, 3)
+        lin(p + ".attention.ChannelGate.mlp.1", mid // 16, mid); lin(p + ".attention.ChannelGate.mlp.3", mid, mid // 16)
+        conv(p + ".attention.SpatialGate.spatial.conv", 1, 2, 7)
+        if mid != out:
+            conv(p + ".block2.downsample", out, mid, 3)
+        conv(p + ".block2.conv1", out, mid, 3); conv(p + ".block2.conv2", out, out, 3)
+
+    k = "key_encoder"
+    trunk(k, "bottleneck", (3, 4, 6), 0)
+    b = k + ".network2.backbone"
+    spec[b + ".cls_token"], spec[b + ".pos_embed"], spec[b + ".mask_token"] = (1, 1, DINO_DIM), (1, 1 + DINO_GRID ** 2, DINO_DIM), (1, DINO_DIM)
+    conv(b + ".patch_embed.proj", DINO_DIM, 3, 14)
+    for i in range(DINO_DEPTH):
+        q = f"{b}.blocks.{i}"
+        ln(q + ".norm1", DINO_DIM); lin(q + ".attn.qkv", 3 * DINO_DIM, DINO_DIM); lin(q + ".attn.proj", DINO_DIM, DINO_DIM)
+        spec[q + ".ls1.gamma"] = (DINO_DIM,)
+        ln(q + ".norm2", DINO_DIM); lin(q + ".mlp.fc1", 4 * DINO_DIM, DINO_DIM); lin(q + ".mlp.fc2", DINO_DIM, 4 * DINO_DIM)
+        spec[q + ".ls2.gamma"] = (DINO_DIM,)
+    ln(b + ".norm", DINO_DIM)
+    conv(k + ".network2.conv3", 4 * DINO_DIM, 4 * DINO_DIM, 1, False); _bn(spec, k + ".network2.bn3", 4 * DINO_DIM)
+    for name, dim in (("fuse1", 1024), ("fuse2", 512), ("fuse3", 256)):
+        p = f"{k}.{name}"
+        conv(p + ".encode_enc", dim, 4 * DINO_DIM, 3)
+        ln(p + ".norm1", dim); ln(p + ".norm2", dim)
+        spec[p + ".crossattn.temperature"] = (8, 1, 1)
+        for t in ("q", "k", "v"):
+            conv(f"{p}.crossattn.to_{t}", 2 * dim, dim, 1)
+            conv(f"{p}.crossattn.to_{t}_dw", 2 * dim, 1, 3)
+        conv(p + ".crossattn.to_out.0", dim, 2 * dim, 1)
+        ln(p + ".norm3", dim)
+    v = "value_encoder"
+    trunk(v, "basic", (2, 2, 2), 2)
+    fusion(v + ".fuser", 1024, 256, value_dim, value_dim)
+    if hidden_dim > 0:
+        conv(v + ".hidden_reinforce.transform", 3 * hidden_dim, value_dim + hidden_dim, 3)
+    conv("key_proj.key_proj", key_dim, 1024, 3); conv("key_proj.d_proj", 1, 1024, 3); conv("key_proj.e_proj", key_dim, 1024, 3)
+    conv("short_term_attn.relative_emb_k", 225, 64, 1)
+    conv("short_term_attn.dw_conv.conv", 2 * value_dim, 1, 5, False)
+    lin("short_term_attn.projection", 2 * value_dim, 2 * value_dim)
+    d = "decoder"
+    fusion(d + ".fuser", 1024, value_dim + hidden_dim, 512, 512)
+    if hidden_dim > 0:
+        conv(d + ".hidden_update.g16_conv", 256, 512, 1); conv(d + ".hidden_update.g8_conv", 256, 256, 1); conv(d + ".hidden_update.g4_conv", 256, 257, 1)
+        conv(d + ".hidden_update.transform", 3 * hidden_dim, 256 + hidden_dim, 3)
+    conv(d + ".up_16_8.skip_conv", 512, 512, 3)
+    conv(d + ".up_16_8.out_conv.downsample", 256, 512, 3); conv(d + ".up_16_8.out_conv.conv1", 256, 512, 3); conv(d + ".up_16_8.out_conv.conv2", 256, 256, 3)
+    conv(d + ".up_8_4.skip_conv", 256, 256, 3)
+    conv(d + ".up_8_4.out_conv.conv1", 256, 256, 3); conv(d + ".up_8_4.out_conv.conv2", 256, 256, 3)
+    conv(d + ".pred", 1, 256, 3)
+    return spec
+
+
+def synth_colormnet_state_dict(seed=0):
+    """Seeded synthetic ColorMNet weights (the checkpoint DINOv2FeatureV6_LocalAtten_s2_154000.pth cannot be fetched offline): every stage
+    stays O(1), the memory softmax / channel attention / gates are neither uniform nor saturated, tanh(ab) stays in its linear range."""
+    key = ("colormnet", int(seed))
+    if key in _CACHE:
+        return _CACHE[key]
+    spec = colormnet_state_dict_spec()
+    sd = OrderedDict()
+    for name, shape in spec.items():
+        r = _rng(seed, "colormnet." + name)
+        parent, leaf = name.rsplit(".", 1)
+        is_bn = (parent + ".running_mean") in spec
+        n = lambda s: (r.standard_normal(shape) * s).astype(np.float32)
+        fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        if leaf == "num_batches_tracked":
+            sd[name] = np.array(1000, np.int64)
+        elif is_bn:
+            last = parent.endswith((".bn3", ".downsample.1")) and "network2" not in parent or (parent.startswith("value_encoder.layer") and parent.endswith(".bn2"))
+            sd[name] = {"weight": r.uniform(0.8, 1.2, shape) * (0.5 if last else 1.0), "bias": r.standard_normal(shape) * 0.1,
+                        "running_mean": r.standard_normal(shape) * 0.1, "running_var": r.uniform(0.7, 1.3, shape)}[leaf].astype(np.float32)
+        elif leaf == "gamma":                                            # LayerScale
+            sd[name] = r.uniform(0.1, 0.5, shape).astype(np.float32)
+        elif leaf == "temperature":
+            sd[name] = r.uniform(4.0, 16.0, shape).astype(np.float32)
+        elif leaf in ("cls_token", "mask_token"):
+            sd[name] = n(0.5)
+        elif leaf == "pos_embed":
+            sd[name] = n(0.2)
+        elif leaf == "bias":
+            is_norm = len(spec[parent + ".weight"]) == 1
+            sd[name] = n(0.1 if is_norm else 0.05)
+        elif len(shape) == 1:                                            # LayerNorm / LayerNorm2d weight
+            sd[name] = r.uniform(0.8, 1.2, shape).astype(np.float32)
+        elif "_dw." in name or "dw_conv" in name:                         # depthwise 3x3 / 5x5
+            sd[name] = n(1.0 / np.sqrt(shape[2] * shape[3]) * 1.5)
+        elif name == "decoder.pred.weight":
+            sd[name] = n(0.2 / np.sqrt(fan_in))
+        elif name == "key_proj.key_proj.weight":
+            sd[name] = n(0.7 / np.sqrt(fan_in))
+        elif name.endswith("relative_emb_k.weight"):
+            sd[name] = n(0.1)
+        elif name.endswith(".conv2.weight") and (".block" in name or ".out_conv." in name):     # GroupResBlock second conv: damped residual branch
+            sd[name] = n(0.5 * np.sqrt(2.0 / fan_in))
+        elif any(t in name for t in (".to_q.", ".to_k.", ".to_v.", ".to_out.", ".attn.qkv", ".attn.proj", ".mlp.fc2", "projection", "d_proj", "e_proj",
+                                     "transform", "g16_conv", "g8_conv", "g4_conv", "encode_enc", "mlp.3", "spatial.conv", "patch_embed")):
+            sd[name] = n(1.0 / np.sqrt(fan_in))
+        else:                                                            # convs / linears followed by a ReLU or GELU
+            sd[name] = n(np.sqrt(2.0 / fan_in))
+    _CACHE[key] = sd
+    return sd
