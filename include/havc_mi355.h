@@ -82,6 +82,32 @@ enum havc_op_type {
                                 left in src (fp32 [Hi*Wi][16][2] per frame), + R_img . image + bias: src2 = fp16 image view
                                 (3 channels at res_coff, pitch res_cpitch), w_off = fp32 R_img [2][3], bias_off fp32 [2];
                                 dst = fp16 view [4Hi][4Wi] channels 0-1                                                   */
+    /* ---- ColorMNet network (colormnet/model/{modules,resnet,cbam,group_modules,basic}.py; csrc/colormnet_net.hip).  Ops of a ColorMNet plan
+       run in slices with DIFFERENT batch counts (image features: 1 frame; per-object features: one frame per object), so every op below
+       takes explicit broadcast flags: a broadcast operand is read from frame 0 whatever the batch index. ---- */
+    HAVC_OP_EW = 20,         /* element-wise / resample: kh = mode (0 copy, 1 bilinear align_corners=False with ratios f0 (rows) / f1 (cols) =
+                                source / destination as aten computes them, 2 area = mean over kw x kw blocks); flags HAVC_EW_*: SRC_BCAST,
+                                RES (+ src2 view, Ho x Wo), RES_BCAST, RELU (on the result), DUAL (also write relu(result) to buffer aux0 at
+                                channel offset aux1, pitch Kc).  F.interpolate / upsample_groups / downsample_groups / the `add` distributor /
+                                the ReLU GroupResBlock applies to its input (group_modules.py:14-93)                                     */
+    HAVC_OP_DWCONV = 21,     /* depthwise kh x kh (3 or 5), zero pad kh / 2, stride 1, bias_off optional; w_off: fp16 [kh*kh][Kc] (Kc = channel
+                                pitch): CrossChannelAttention to_*_dw (resnet.py:296-303), DWConv2d (basic.py:75-94)                     */
+    HAVC_OP_CHAN_ATTN = 22,  /* CrossChannelAttention core (resnet.py:310-331): q = src view, k = src2 view (res_coff / res_cpitch), kh = heads,
+                                Ci = heads * c channels; scale_off = temperature fp32 [heads]; aux0 / aux1 = fp32 scratch buffers (partial
+                                Gram [heads][S][c][c], partial norms [S][2][Ci]); dst = fp16 buffer [Ci][Kc * 8]: the block-diagonal softmax
+                                matrix, applied to v by a 1 x 1 conv with HAVC_F_W_FROM_BUF                                              */
+    HAVC_OP_MHA64 = 23,      /* multi-head self-attention, head dim 64: src = qkv token view (Hi = 1, Wi = tokens per frame, q at src_coff,
+                                k at res_coff, v at aux0, all in buffer src with pitch src_cpitch), Ho = live tokens, kh = heads, f0 = scale */
+    HAVC_OP_CBAM = 24,       /* CBAM (cbam.py:27-77) fused with the residual of FeatureFusionBlock (modules.py:35-39): dst = x (1 + channel
+                                gate x spatial gate) = g + CBAM(g); w_off = fp32 {W1 [C/16][C], b1, W2 [C][C/16], b2, w7 [2][49], b7};
+                                aux0 / aux1 = fp32 scratch (scale [C], comp [Hi*Wi][2]); flags HAVC_EW_DUAL: relu(dst) -> buffer src2 at
+                                res_coff, pitch res_cpitch                                                                               */
+    HAVC_OP_GRU = 25,        /* HiddenReinforcer / HiddenUpdater gates (modules.py:66-76): src = values view (3 Co channels), src2 = fp32 planar
+                                hidden [Co][Hi*Wi] per frame, dst = fp32 planar new hidden                                               */
+    HAVC_OP_PLANAR_IN = 26,  /* fp32 planar [Ci][Hi*Wi] per frame (flags & 1: pixel-major [Hi*Wi][Ci]; flags & 2: broadcast frame 0) in buffer
+                                src -> NHWC fp16 dst view (Co = stored channels, zeros above Ci)                                         */
+    HAVC_OP_PLANAR_OUT = 27, /* NHWC fp16 src view, Ci channels -> fp32 planar [Ci][Hi*Wi] per frame in buffer dst; kh = activation: 0 none,
+                                1 x^2 + 1, 2 sigmoid (KeyProjection, modules.py:226-229), 3 tanh (network.py:141)                        */
     HAVC_OP_DWCONV7_LN = 17,    /* DWCONV7 followed by LAYERNORM of its result, one kernel (ConvNeXt block head): fields of both
                                 ops (w_off / bias_off / Kc; scale_off gamma, shift_off beta, f0 eps); Ci = 64, 192, 384, 768 or 1536.
                                 The norm reads the fp32 conv result (the two-op form rounds it to fp16 in between)      */
@@ -118,6 +144,13 @@ enum havc_op_type {
                                      scale_off [3][Npad], bias at shift_off [3]) + OUT_RGB8 maths run in the epilogue and
                                      write u8 RGB to buffer aux0 (layers.10.1 + layers.11 + layers.12 of the generator);
                                      needs Npad == 272 (one 256+16 tile holds every channel of a pixel)              */
+
+/* flags of HAVC_OP_EW / HAVC_OP_CBAM */
+#define HAVC_EW_SRC_BCAST 1       /* the source view is read from frame 0 for every batch entry (image features shared by the objects) */
+#define HAVC_EW_RES 2             /* + src2 view                                                                                      */
+#define HAVC_EW_RES_BCAST 4       /* ... read from frame 0                                                                            */
+#define HAVC_EW_RELU 8            /* ReLU on the result                                                                               */
+#define HAVC_EW_DUAL 16           /* second, rectified copy of the result                                                             */
 
 typedef struct havc_op {
     int32_t type, flags;
@@ -185,6 +218,15 @@ void havc_net_free(havc_net* net);
  *                     d_out = device u8 RGB interleaved [batch][S][S][3] (raw colour, trunc(x*255),
  *                     i.e. BaseFilter._model_process output, deoldify/filters.py:45-68). */
 int havc_net_run_rgb8(havc_net* net, const uint8_t* d_in, uint8_t* d_out, int batch);
+/* Point activation buffer `buf` of the net at caller-owned device memory (>= batch * elems_per_frame * elem_bytes bytes; NULL restores the
+ * net's own allocation).  The ColorMNet step hands its per-frame tensors (keys, values, hidden state, multi-scale features: the reference's
+ * torch tensors, colormnet/inference/inference_core.py) to the plan and receives results this way, without a copy. */
+int havc_net_bind(havc_net* net, int buf, void* device_ptr);
+/* havc_net_run_ops without the blocking timer: the ops are only enqueued on the ctx stream */
+int havc_net_enqueue_ops(havc_net* net, int first_op, int n_ops, int batch);
+/* the ctx's HIP stream (hipStream_t), so that a caller can order its own device work with the library's: e.g.
+ * torch.cuda.ExternalStream(ptr) makes torch enqueue on the SAME stream and no host synchronisation is needed between the two */
+void* havc_get_stream(havc_ctx* ctx);
 /* debug / unit-test access to activation buffers (host <-> device, blocking) */
 int havc_net_upload(havc_net* net, int buf, const void* host, size_t nbytes);
 int havc_net_download(havc_net* net, int buf, void* host, size_t nbytes);
@@ -371,6 +413,12 @@ int havc_local_correlation(havc_ctx* ctx, const float* q, const float* k, float*
                            float q_scale);
 int havc_local_attention(havc_ctx* ctx, const float* q, const float* k, const float* v, const float* rel_w, const float* rel_b, float* agg,
                          float* attn, int n, int C, int CV, int H, int W, int max_dis, int dilation);
+
+/* ColorMNetRender's frame transforms (colormnet/colormnet_render.py:285-301,276-279; dataset/range_transform.py:24-47): u8 RGB [h][w][3] ->
+ * normalised Lab, three fp32 planes [3][h][w] ((L - 50) / 50, a / 110, b / 110; skimage rgb2lab restated in fp64: PARITY UNPINNED), and
+ * back: L plane [h][w] + ab planes [2][h][w] -> lab2rgb -> clip -> trunc(x * 255) u8 RGB.  Host or device pointers. */
+int havc_colormnet_rgb_to_lab(havc_ctx* ctx, const uint8_t* rgb, float* lab, int width, int height);
+int havc_colormnet_lab_to_rgb(havc_ctx* ctx, const float* l_plane, const float* ab, uint8_t* rgb, int width, int height);
 
 /* timing of the dominant kernel for bench.py's roofline object: average duration (ms) and launch count
  * of HAVC_OP_CONV ops with the given tag over the launches since havc_reset_stats (HIP events on the

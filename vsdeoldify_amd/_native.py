@@ -19,6 +19,8 @@ OP_CONV, OP_MAXPOOL, OP_BLUR_RESIZE, OP_AFFINE, OP_ATTENTION, OP_PREP_RGB8, OP_C
 OP_SUBSAMPLE2, OP_PROJ2, OP_BILINEAR2, OP_PREP_LAB_L = 8, 9, 10, 11
 OP_DWCONV7, OP_LAYERNORM, OP_MHA, OP_PIXSHUF4_BLUR, OP_PREP_DDCOLOR, OP_DWCONV7_LN = 12, 13, 14, 15, 16, 17
 OP_FOLD_QUERIES, OP_SHUF4_BLUR_AB = 18, 19
+OP_EW, OP_DWCONV, OP_CHAN_ATTN, OP_MHA64, OP_CBAM, OP_GRU, OP_PLANAR_IN, OP_PLANAR_OUT = 20, 21, 22, 23, 24, 25, 26, 27
+EW_SRC_BCAST, EW_RES, EW_RES_BCAST, EW_RELU, EW_DUAL = 1, 2, 4, 8, 16
 F_RELU_PRE, F_AFFINE, F_RESIDUAL, F_RELU_POST = 0x1, 0x2, 0x4, 0x8
 F_OUT_PIXSHUF, F_OUT_TRANSPOSED, F_OUT_RGB8, F_LEAKY, F_FUSE_RGB8, F_PS_BLUR = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 F_GELU, F_W_FROM_BUF = 0x400, 0x800
@@ -78,6 +80,11 @@ SYMBOLS = [
     ("havc_net_upload", _I, [_P, _I, _P, _SZ]),
     ("havc_net_download", _I, [_P, _I, _P, _SZ]),
     ("havc_net_run_ops", _I, [_P, _I, _I, _I]),
+    ("havc_net_enqueue_ops", _I, [_P, _I, _I, _I]),
+    ("havc_net_bind", _I, [_P, _I, _P]),
+    ("havc_get_stream", _P, [_P]),
+    ("havc_colormnet_rgb_to_lab", _I, [_P, _P, _P, _I, _I]),
+    ("havc_colormnet_lab_to_rgb", _I, [_P, _P, _P, _P, _I, _I]),
     ("havc_net_profile", _I, [_P, _I, _P, _I]),
     ("havc_net_autotune", _I, [_P, _I, C.POINTER(_I)]),
     ("havc_device_name", _I, [_P, C.c_char_p, _I]),
@@ -203,6 +210,10 @@ class Context:
     def synchronize(self):
         check(self.lib.havc_synchronize(self.h), self.h)
 
+    def stream_ptr(self):
+        """the ctx's hipStream_t as an integer (torch.cuda.ExternalStream(ptr) puts torch's work on the same stream)"""
+        return int(self.lib.havc_get_stream(self.h) or 0)
+
     def device_name(self):
         buf = C.create_string_buffer(256)
         check(self.lib.havc_device_name(self.h, buf, 256), self.h)
@@ -298,6 +309,14 @@ class Net:
 
     def run_ops(self, first, count, batch=1):
         check(self.ctx.lib.havc_net_run_ops(self.h, first, count, batch), self.ctx.h)
+
+    def enqueue_ops(self, first, count, batch=1):
+        """run_ops without the blocking timer: only enqueues on the ctx stream"""
+        check(self.ctx.lib.havc_net_enqueue_ops(self.h, first, count, batch), self.ctx.h)
+
+    def bind(self, buf, ptr):
+        """point buffer `buf` at caller-owned device memory (int / c_void_p; None restores the net's own allocation)"""
+        check(self.ctx.lib.havc_net_bind(self.h, int(buf), C.c_void_p(ptr) if isinstance(ptr, int) else ptr), self.ctx.h)
 
     def run_rgb8_dev(self, d_in, d_out, batch):
         check(self.ctx.lib.havc_net_run_rgb8(self.h, d_in, d_out, batch), self.ctx.h)

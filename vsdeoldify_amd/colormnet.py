@@ -47,9 +47,33 @@ def _out_like(ref, shape):
     return a, nat.as_ptr(a)
 
 
-def _sync_if_device(ctx, ref):
-    if ref.torch is not None and ref.torch.is_cuda:
-        ctx.synchronize()                                       # device outputs are only enqueued; torch reads them on another stream
+class ordered:
+    """Orders a libhavc call on device tensors against torch's work.  libhavc enqueues on the ctx stream (non-blocking), torch on its
+    current stream: when the two differ, torch's stream is drained BEFORE the call (its producers — cat, float(), contiguous(), the convs
+    that made q / k / v — are asynchronous) and the ctx stream AFTER it (torch reads the outputs on its own stream).  When torch already
+    runs on the ctx stream (torch.cuda.ExternalStream(ctx.stream_ptr()), as colormnet_net.ColorMNetNetwork does) nothing is needed.
+    Tensors of another GPU than the ctx's are refused."""
+
+    def __init__(self, ctx, *tensors):
+        self.ctx, self.sync = ctx, False
+        dev = [t for t in tensors if t is not None and hasattr(t, "is_cuda") and t.is_cuda]
+        if dev:
+            import torch
+            for t in dev:
+                if t.device.index != ctx.device_id:
+                    raise ValueError(f"tensor on cuda:{t.device.index} handed to the libhavc context of GPU {ctx.device_id}")
+            cur = torch.cuda.current_stream(dev[0].device)
+            if cur.cuda_stream != ctx.stream_ptr():
+                cur.synchronize()
+                self.sync = True
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        if self.sync:
+            self.ctx.synchronize()
+        return False
 
 
 def get_similarity(mk, ms, qk, qe, device_index=0):
@@ -60,8 +84,8 @@ def get_similarity(mk, ms, qk, qe, device_index=0):
     N, HW = int(np.prod(m.shape[2:])), int(np.prod(q.shape[2:]))
     s, e = _Op(ms), _Op(qe)
     out, optr = _out_like(m, (B, N, HW))
-    nat.check(ctx.lib.havc_memory_similarity(ctx.h, m.ptr, s.ptr, q.ptr, e.ptr, optr, B, CK, N, HW), ctx.h)
-    _sync_if_device(ctx, m)
+    with ordered(ctx, m.torch, s.torch, q.torch, e.torch):
+        nat.check(ctx.lib.havc_memory_similarity(ctx.h, m.ptr, s.ptr, q.ptr, e.ptr, optr, B, CK, N, HW), ctx.h)
     return out
 
 
@@ -75,8 +99,8 @@ def match_memory_readout(mk, ms, qk, qe, mv, top_k=30, device_index=0):
         raise ValueError("memory values and memory keys disagree on the number of memory elements")
     s, e = _Op(ms), _Op(qe)
     out, optr = _out_like(m, (B, CV, HW))
-    nat.check(ctx.lib.havc_memory_read_topk(ctx.h, m.ptr, s.ptr, q.ptr, e.ptr, v.ptr, optr, B, CK, CV, N, HW, int(top_k)), ctx.h)
-    _sync_if_device(ctx, m)
+    with ordered(ctx, m.torch, s.torch, q.torch, e.torch, v.torch):
+        nat.check(ctx.lib.havc_memory_read_topk(ctx.h, m.ptr, s.ptr, q.ptr, e.ptr, v.ptr, optr, B, CK, CV, N, HW, int(top_k)), ctx.h)
     return out
 
 
@@ -87,8 +111,8 @@ def local_correlation(q, k, max_dis=7, dilation=1, q_scale=1.0, device_index=0):
     n, c, h, w = a.shape
     ws = 2 * max_dis + 1
     out, optr = _out_like(a, (n, 1, ws * ws, h * w))
-    nat.check(ctx.lib.havc_local_correlation(ctx.h, a.ptr, b.ptr, optr, n, c, h, w, int(max_dis), int(dilation), float(q_scale)), ctx.h)
-    _sync_if_device(ctx, a)
+    with ordered(ctx, a.torch, b.torch):
+        nat.check(ctx.lib.havc_local_correlation(ctx.h, a.ptr, b.ptr, optr, n, c, h, w, int(max_dis), int(dilation), float(q_scale)), ctx.h)
     return out
 
 
@@ -101,6 +125,6 @@ def local_attention(q, k, v, rel_w, rel_b, max_dis=7, dilation=1, device_index=0
     ws = 2 * max_dis + 1
     agg, aptr = _out_like(a, (h * w, n, cv))
     attn, tptr = _out_like(a, (n, 1, ws * ws, h * w))
-    nat.check(ctx.lib.havc_local_attention(ctx.h, a.ptr, b.ptr, vv.ptr, rw.ptr, rb.ptr, aptr, tptr, n, c, cv, h, w, int(max_dis), int(dilation)), ctx.h)
-    _sync_if_device(ctx, a)
+    with ordered(ctx, a.torch, b.torch, vv.torch, rw.torch, rb.torch):
+        nat.check(ctx.lib.havc_local_attention(ctx.h, a.ptr, b.ptr, vv.ptr, rw.ptr, rb.ptr, aptr, tptr, n, c, cv, h, w, int(max_dis), int(dilation)), ctx.h)
     return agg, attn

@@ -40,10 +40,10 @@ class _HipBackend:
         CK, N, HW, R = mk.shape[1], mk.shape[2], qk.shape[2], mv.shape[0]
         out = torch.empty((R, HW), dtype=torch.float32, device=mk.device)
         usage = torch.empty((1, N), dtype=torch.float32, device=mk.device) if want_usage else None
-        nat.check(ctx.lib.havc_memory_read_topk_usage(ctx.h, self._p(mk), self._p(ms), self._p(qk), self._p(qe), self._p(mv), self._p(out),
-                                                      self._p(usage), 1, CK, R, N, HW, int(top_k)), ctx.h)
-        if mk.is_cuda:
-            ctx.synchronize()
+        from .colormnet import ordered
+        with ordered(ctx, mk, ms, qk, qe, mv):                  # the operands were produced asynchronously on torch's stream (cat, float, contiguous)
+            nat.check(ctx.lib.havc_memory_read_topk_usage(ctx.h, self._p(mk), self._p(ms), self._p(qk), self._p(qe), self._p(mv), self._p(out),
+                                                          self._p(usage), 1, CK, R, N, HW, int(top_k)), ctx.h)
         return out, usage
 
     def dense_readout(self, mk, ms, qk, qe, mv):
@@ -55,10 +55,10 @@ class _HipBackend:
         qe = None if qe is None else qe.float().contiguous()
         CK, N, P, R = mk.shape[1], mk.shape[2], qk.shape[2], mv.shape[0]
         out = torch.empty((R, P), dtype=torch.float32, device=mk.device)
-        nat.check(ctx.lib.havc_memory_dense_readout(ctx.h, self._p(mk), self._p(ms), self._p(qk), self._p(qe), self._p(mv), self._p(out), 1, CK, R, N, P),
-                  ctx.h)
-        if mk.is_cuda:
-            ctx.synchronize()
+        from .colormnet import ordered
+        with ordered(ctx, mk, ms, qk, qe, mv):
+            nat.check(ctx.lib.havc_memory_dense_readout(ctx.h, self._p(mk), self._p(ms), self._p(qk), self._p(qe), self._p(mv), self._p(out), 1, CK, R, N, P),
+                      ctx.h)
         return out
 
 

@@ -1,0 +1,155 @@
+"""ColorMNetRender — drop-in for the reference's per-frame exemplar colorizer (BASELINE configs[4]):
+
+  /root/reference/vsdeoldify/colormnet/colormnet_render.py:47-321   class ColorMNetRender (constructor, set_config, set_ref_frame,
+                                                                    colorize_batch_frames, colorize_frame, get_image, the reset rule)
+  called from colormnet/__init__.py:42-128 (vs_colormnet_local) and through the XML-RPC pair colormnet_server.py / colormnet_client.py
+  (vs_colormnet_remote): here the call is in-process, no server thread, no PIL-bytes-over-HTTP hop.
+
+Same constructor arguments, same methods, same state machine (frame / reference counters, the memory reset on a new reference image or when
+max_memory_frames is reached, `FirstFrameIsNotExemplar`, the "no reference yet -> return the frame unchanged" rule).  The arithmetic is on the
+MI355X: RGB -> normalised Lab and Lab -> RGB (csrc/zhang.hip device functions), the network (colormnet_net.ColorMNetNetwork: HIP plan over
+the conv / attention / ColorMNet kernels), the memory (colormnet_memory.MemoryManager).  torch is used for device memory and tensor
+bookkeeping only.  No CPU fallback: without libhavc_mi355.so or a gfx950 device the constructor raises.
+Sequential in time by nature (every frame reads what the previous ones wrote) => one clip per GPU, replicas only.
+
+image_size: the reference's HAVC entry points always pass -1 (vsdeoldify/__init__.py:1700,1712; the clip is resized beforehand by
+SmartResizeColorizer, vsslib/vsresize.py:271-316); image_size >= 0 (torchvision Resize inside the transform) is refused.
+"""
+import os
+
+import numpy as np
+
+from .colormnet_core import InferenceCore
+
+DEF_MAX_MEMORY_FRAMES = 10000              # vsslib/constants.py:64
+WEIGHTS = "weights/DINOv2FeatureV6_LocalAtten_s2_154000.pth"      # colormnet_render.py:107-108
+
+
+def default_config(vid_length, max_memory_frames, propagate=False):
+    """the config dict of _colorize_config_init / _colorize_model_init (colormnet_render.py:95-160) for image_size = -1"""
+    cfg = {"FirstFrameIsNotExemplar": not propagate, "dataset": "D16_batch"}
+    cfg["max_mid_term_frames"] = min(10, vid_length)
+    cfg["min_mid_term_frames"] = min(5, int(cfg["max_mid_term_frames"] / 2))
+    cfg["max_long_term_elements"] = max_memory_frames
+    cfg["num_prototypes"] = 128
+    cfg["top_k"] = 30
+    cfg["mem_every"] = min(5, cfg["max_mid_term_frames"])
+    cfg["deep_update_every"] = -1
+    cfg["save_scores"] = False
+    cfg["size"] = -1
+    cfg["disable_long_term"] = False
+    cfg["enable_long_term"] = True
+    span = cfg["max_mid_term_frames"] - cfg["min_mid_term_frames"]
+    cfg["enable_long_term_count_usage"] = bool(span > 0 and (vid_length / span * cfg["num_prototypes"]) >= cfg["max_long_term_elements"])
+    return cfg
+
+
+_NETWORKS = {}
+
+
+def _load_network(project_dir, state_dict, device_index):
+    """one packed network per (weights, device), like the reference's singleton (`_initialized`, colormnet_render.py:68-71,92-94)"""
+    from .colormnet_net import ColorMNetNetwork
+    key = (id(state_dict) if state_dict is not None else os.path.join(project_dir, WEIGHTS), device_index)
+    if key not in _NETWORKS:
+        if state_dict is None:
+            import torch
+            path = key[0]
+            if not os.path.isfile(path):
+                raise FileNotFoundError(f"ColorMNet weights not found: {path}")
+            state_dict = torch.load(path, map_location="cpu")
+        _NETWORKS[key] = ColorMNetNetwork(state_dict, device_index=device_index)
+    return _NETWORKS[key]
+
+
+class ColorMNetRender:
+    """renders one frame at a time (colormnet_render.py:47)"""
+
+    def __init__(self, image_size=-1, vid_length=None, enable_resize=False, encode_mode=None, propagate=False, max_memory_frames=None,
+                 reset_on_ref_update=True, project_dir=None, state_dict=None, device_index=0, network=None):
+        if image_size is not None and image_size >= 0:
+            raise NotImplementedError("image_size >= 0 (resize inside the transform) is never used by HAVC (vsdeoldify/__init__.py:1700)")
+        if vid_length is None:
+            raise TypeError("vid_length is required (the reference computes min(DEF_MAX_MEMORY_FRAMES, vid_length) with it)")
+        self.reset_on_ref_update, self.enable_resize = reset_on_ref_update, enable_resize
+        self.project_dir = project_dir if project_dir is not None else os.path.dirname(os.path.realpath(__file__))
+        self.encode_mode = 0 if encode_mode is None else encode_mode
+        if max_memory_frames is None or max_memory_frames == 0:
+            self.max_memory_frames = min(DEF_MAX_MEMORY_FRAMES, vid_length)
+        else:
+            self.max_memory_frames = min(DEF_MAX_MEMORY_FRAMES, max_memory_frames)
+        self.vid_length, self.size = vid_length, -1
+        self.total_colored_frames = self.frame_count = self.ref_count = self.ref_count_prv = 0
+        self.ref_img = self.ref_img_valid = self.img = None
+        self.first_mask_loaded = False
+        self.device_index = device_index
+        self.network = network if network is not None else _load_network(self.project_dir, state_dict, device_index)
+        self.config = default_config(vid_length, self.max_memory_frames, propagate)
+        self.config.update(key_dim=self.network.key_dim, value_dim=self.network.value_dim, hidden_dim=self.network.hidden_dim)
+        self.processor = InferenceCore(self.network, self.config, device_index=device_index)
+
+    # ---- colormnet_render.py:162-193 ----
+    def set_config(self, param_name=None, param_value=None):
+        self.config[param_name] = param_value
+        self.processor.update_config(self.config)
+
+    def set_ref_frame(self, frame_ref=None, frame_propagate=False):
+        self.ref_img = frame_ref
+        self.config["FirstFrameIsNotExemplar"] = not frame_propagate
+        if frame_ref is not None:
+            self.ref_img_valid = frame_ref
+            self.ref_count_prv = self.ref_count if self.frame_count > 0 else 0
+            self.ref_count = self.frame_count
+
+    def colorize_batch_frames(self, frame_list=None, ref_list=None, frame_propagate=False):
+        out = []
+        for i, (frame_i, ref_i) in enumerate(zip(frame_list, ref_list)):
+            self.set_ref_frame(ref_i, frame_propagate)
+            out.append(self.colorize_frame(i, frame_i))
+        return out
+
+    def get_frame_count(self):
+        return self.frame_count
+
+    # ---- colormnet_render.py:197-283 ----
+    def colorize_frame(self, ti=None, frame_i=None):
+        with self.network.on_stream():            # the step's tensor bookkeeping and the library share one HIP stream: no host sync inside a frame
+            return self._colorize_frame(ti, frame_i)
+
+    def _colorize_frame(self, ti, frame_i):
+        from PIL import Image
+        self.total_colored_frames += 1
+        reset_1 = self.frame_count >= self.max_memory_frames          # (the reference's other trigger is < 100 MB of free device memory)
+        reset_2 = self.reset_on_ref_update and self.ref_img is not None and (self.ref_count - self.ref_count_prv >= 1)
+        if reset_1 or reset_2:
+            self.frame_count = 0
+            self.config["FirstFrameIsNotExemplar"] = True              # the reference image is the previous coloured frame
+            self.processor = InferenceCore(self.network, self.config, device_index=self.device_index)
+            ref = self.ref_img_valid
+        else:
+            ref = self.ref_img
+            self.frame_count += 1
+        lab = self.network.image_to_lab(np.asarray(frame_i))           # [3,H,W] normalised Lab on the device (get_image :285-301)
+        rgb = lab[:1].repeat(3, 1, 1)
+        msk = self.network.image_to_lab(np.asarray(ref)) if ref is not None else None
+        if msk is not None and not self.config["FirstFrameIsNotExemplar"]:
+            msk = msk[1:3]
+        if not self.first_mask_loaded:
+            if msk is None:
+                return frame_i                                          # nothing to propagate from yet
+            self.first_mask_loaded = True
+        labels = None
+        if msk is not None:
+            self.processor.set_all_labels(list(range(1, 3)))
+            labels = range(1, 3)
+        is_last = self.vid_length == self.total_colored_frames - 1
+        if self.config["FirstFrameIsNotExemplar"]:
+            if msk is None:
+                prob = self.processor.step_AnyExemplar(rgb, None, None, labels, end=is_last)
+            else:
+                prob = self.processor.step_AnyExemplar(rgb, msk[:1].repeat(3, 1, 1), msk[1:3], labels, end=is_last)
+        else:
+            prob = self.processor.step(rgb, msk, labels, end=is_last)
+        out = Image.fromarray(self.network.lab_to_image(lab[:1], prob))
+        self.img = self.ref_img_valid = out                             # save_last_image (:303-305)
+        return out

@@ -1,0 +1,546 @@
+// ColorMNet network kernels: everything of colormnet/model/{modules,resnet,cbam,group_modules,basic}.py that is not a
+// dense convolution (those run on conv_pipe_kernel / conv_igemm_kernel) and not the memory (colormnet.hip).  Activations are the
+// plan executor's NHWC fp16 views; the arithmetic is fp32.  Sizes here are small (a 384 x 216 clip is a 14 x 28 key grid): these kernels
+// are latency / HBM bound, written for coalesced 16-byte channel vectors; the MFMA work of a ColorMNet frame is in the convs and in mha64.
+//
+//   ew_kernel             F.interpolate(bilinear, align_corners=False) / mode='area' / copies, with the broadcast-over-objects adds of
+//                         MainToGroupDistributor (group_modules.py:62-93), upsample_groups / downsample_groups (:24-29) and the ReLU that
+//                         GroupResBlock applies to its INPUT (:50-58) as an optional second, rectified output
+//   dwconv_kernel<K>      depthwise K x K (+ bias): CrossChannelAttention to_{q,k,v}_dw (resnet.py:296-303), DWConv2d (basic.py:75-94)
+//   chan_gram / chan_softmax   CrossChannelAttention (resnet.py:310-331): L2-normalised q k^T over the pixels, x temperature, softmax ->
+//                         a block-diagonal fp16 weight matrix that a 1 x 1 conv with HAVC_F_W_FROM_BUF applies to v
+//   mha64_kernel          multi-head self-attention, head dim 64, flash form on MFMA (DINOv2 ViT-S/14 blocks; oracle/dinov2.py)
+//   cbam_*                CBAM channel gate + spatial gate (cbam.py:27-77), fused with the `g + r` of FeatureFusionBlock (modules.py:35-39)
+//   gru_kernel            HiddenReinforcer / HiddenUpdater gates (modules.py:66-76, 93-101)
+//   planar_in / planar_out   fp32 planar (the reference's NCHW tensors: keys, values, hidden state, masks) <-> NHWC fp16 views, with the
+//                         activations of KeyProjection (d^2 + 1, sigmoid; modules.py:226-229) and of segment (tanh; network.py:141)
+#include "kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+static inline int grid_for(int64_t work, int per_block = 256) {
+    int64_t b = (work + per_block - 1) / per_block;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bilin_src(int dst, float scale, int in, int& i0, int& i1, float& l) {
+    float src = ((float)dst + 0.5f) * scale - 0.5f;              // aten upsample_bilinear2d, align_corners = False
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i0 = i0 > in - 1 ? in - 1 : i0;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l = src - (float)i0;
+}
+
+__global__ void ew_kernel(EwArgs a) {
+    const int64_t total = (int64_t)a.B * a.Ho * a.Wo * a.C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % a.C8);
+        int64_t r = i / a.C8;
+        const int wo = (int)(r % a.Wo);
+        r /= a.Wo;
+        const int ho = (int)(r % a.Ho), b = (int)(r / a.Ho);
+        const half_t* xb = a.x + (int64_t)b * a.x_fs + a.x_co + c8 * 8;
+        float v[8];
+        if (a.mode == 1) {
+            int y0, y1, x0, x1;
+            float ly, lx;
+            bilin_src(ho, a.rh, a.Hi, y0, y1, ly);
+            bilin_src(wo, a.rw, a.Wi, x0, x1, lx);
+            const half8 p00 = *reinterpret_cast<const half8*>(xb + ((int64_t)y0 * a.Wi + x0) * a.x_cp);
+            const half8 p01 = *reinterpret_cast<const half8*>(xb + ((int64_t)y0 * a.Wi + x1) * a.x_cp);
+            const half8 p10 = *reinterpret_cast<const half8*>(xb + ((int64_t)y1 * a.Wi + x0) * a.x_cp);
+            const half8 p11 = *reinterpret_cast<const half8*>(xb + ((int64_t)y1 * a.Wi + x1) * a.x_cp);
+            const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = w00 * (float)p00[e] + w01 * (float)p01[e] + w10 * (float)p10[e] + w11 * (float)p11[e];
+        } else if (a.mode == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            for (int dy = 0; dy < a.factor; ++dy)
+                for (int dx = 0; dx < a.factor; ++dx) {
+                    const half8 p = *reinterpret_cast<const half8*>(xb + ((int64_t)(ho * a.factor + dy) * a.Wi + wo * a.factor + dx) * a.x_cp);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)p[e];
+                }
+            const float inv = 1.f / (float)(a.factor * a.factor);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= inv;
+        } else {
+            const half8 p = *reinterpret_cast<const half8*>(xb + ((int64_t)ho * a.Wi + wo) * a.x_cp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)p[e];
+        }
+        const int64_t po = (int64_t)ho * a.Wo + wo;
+        if (a.res) {
+            const half8 q = *reinterpret_cast<const half8*>(a.res + (int64_t)b * a.r_fs + po * a.r_cp + a.r_co + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)q[e];
+        }
+        half8 o, o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float t = (a.flags & HAVC_EW_RELU) ? fmaxf(v[e], 0.f) : v[e];
+            o[e] = (half_t)t;
+            o2[e] = (half_t)fmaxf(v[e], 0.f);
+        }
+        *reinterpret_cast<half8*>(a.y + (int64_t)b * a.y_fs + po * a.y_cp + a.y_co + c8 * 8) = o;
+        if (a.y2) *reinterpret_cast<half8*>(a.y2 + (int64_t)b * a.y2_fs + po * a.y2_cp + a.y2_co + c8 * 8) = o2;
+    }
+}
+
+int launch_ew(const EwArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(ew_kernel, dim3(grid_for((int64_t)a.B * a.Ho * a.Wo * a.C8)), dim3(256), 0, s, a);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// depthwise K x K, zero padding K / 2, stride 1.  Weights fp16 [K*K][w_pitch] (tap-major, channels contiguous), bias fp32 or null.
+template <int K>
+__global__ void dwconv_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w, const float* __restrict__ bias, half_t* __restrict__ y,
+                              int B, int H, int W, int C8, int x_cp, int x_co, int64_t x_fs, int y_cp, int y_co, int64_t y_fs, int w_pitch) {
+    const int64_t total = (int64_t)B * H * W * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        int64_t r = i / C8;
+        const int xw = (int)(r % W);
+        r /= W;
+        const int yh = (int)(r % H), b = (int)(r / H);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bias ? bias[c8 * 8 + e] : 0.f;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int yy = yh + ky - K / 2;
+            if (yy < 0 || yy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int xx = xw + kx - K / 2;
+                if (xx < 0 || xx >= W) continue;
+                const half8 p = *reinterpret_cast<const half8*>(x + (int64_t)b * x_fs + ((int64_t)yy * W + xx) * x_cp + x_co + c8 * 8);
+                const half8 q = *reinterpret_cast<const half8*>(w + (ky * K + kx) * w_pitch + c8 * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)p[e] * (float)q[e];
+            }
+        }
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)acc[e];
+        *reinterpret_cast<half8*>(y + (int64_t)b * y_fs + ((int64_t)yh * W + xw) * y_cp + y_co + c8 * 8) = o;
+    }
+}
+
+int launch_dwconv(const half_t* x, const half_t* w, const float* bias, half_t* y, int B, int H, int W, int C, int K, int x_cp, int x_co, int64_t x_fs,
+                  int y_cp, int y_co, int64_t y_fs, int w_pitch, hipStream_t s) {
+    const int g = grid_for((int64_t)B * H * W * (C / 8));
+    if (K == 3) hipLaunchKernelGGL(dwconv_kernel<3>, dim3(g), dim3(256), 0, s, x, w, bias, y, B, H, W, C / 8, x_cp, x_co, x_fs, y_cp, y_co, y_fs, w_pitch);
+    else if (K == 5) hipLaunchKernelGGL(dwconv_kernel<5>, dim3(g), dim3(256), 0, s, x, w, bias, y, B, H, W, C / 8, x_cp, x_co, x_fs, y_cp, y_co, y_fs, w_pitch);
+    else return (int)hipErrorInvalidValue;
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// CrossChannelAttention, step 1: per (frame, head, 64 x 64 tile of the c x c map, pixel split): partial Gram q^T k over the split's pixels
+// and the partial squared norms of the tile's q / k channels.  part_g: [B][heads][S][c][c], part_n: [B][S][2][heads * c].
+constexpr int CG_T = 64, CG_P = 32;
+__global__ void __launch_bounds__(256) chan_gram_kernel(const half_t* __restrict__ q, int q_cp, int q_co, int64_t q_fs, const half_t* __restrict__ k,
+                                                        int k_cp, int k_co, int64_t k_fs, float* __restrict__ part_g, float* __restrict__ part_n, int P,
+                                                        int heads, int c, int S) {
+    __shared__ float qs[CG_P][CG_T + 1], ks[CG_P][CG_T + 1];
+    const int tiles = (c + CG_T - 1) / CG_T;
+    int bid = blockIdx.x;
+    const int sp = bid % S; bid /= S;
+    const int tj = bid % tiles; bid /= tiles;
+    const int ti = bid % tiles; bid /= tiles;
+    const int h = bid % heads, b = bid / heads;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int per = (P + S - 1) / S, p_lo = sp * per, p_hi = min(P, p_lo + per);
+    float acc[4][4] = {};
+    float nq[4] = {}, nk[4] = {};
+    const half_t* qb = q + (int64_t)b * q_fs + q_co + h * c + ti * CG_T;
+    const half_t* kb = k + (int64_t)b * k_fs + k_co + h * c + tj * CG_T;
+    for (int p0 = p_lo; p0 < p_hi; p0 += CG_P) {
+        // stage CG_P pixels x 64 channels of q and k (8 channels per thread: 32 x 8 = 256 threads)
+        {
+            const int pp = tid >> 3, ch = (tid & 7) * 8;
+            const int p = p0 + pp;
+            half8 vq, vk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { vq[e] = (half_t)0.f; vk[e] = (half_t)0.f; }
+            if (p < p_hi) {
+                if (ti * CG_T + ch < c) vq = *reinterpret_cast<const half8*>(qb + (int64_t)p * q_cp + ch);
+                if (tj * CG_T + ch < c) vk = *reinterpret_cast<const half8*>(kb + (int64_t)p * k_cp + ch);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { qs[pp][ch + e] = (float)vq[e]; ks[pp][ch + e] = (float)vk[e]; }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int pp = 0; pp < CG_P; ++pp) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { av[r] = qs[pp][ty * 4 + r]; bv[r] = ks[pp][tx * 4 + r]; }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                nq[r] += av[r] * av[r];
+                nk[r] += bv[r] * bv[r];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[r][t] += av[r] * bv[t];
+            }
+        }
+        __syncthreads();
+    }
+    float* g = part_g + ((((int64_t)b * heads + h) * S + sp) * c) * c;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = ti * CG_T + ty * 4 + r;
+        if (i >= c) continue;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = tj * CG_T + tx * 4 + t;
+            if (j < c) g[(int64_t)i * c + j] = acc[r][t];
+        }
+    }
+    float* nn = part_n + ((int64_t)b * S + sp) * 2 * heads * c;
+    if (tj == 0 && tx == 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (ti * CG_T + ty * 4 + r < c) nn[h * c + ti * CG_T + ty * 4 + r] = nq[r];
+    if (ti == 0 && ty == 0)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (tj * CG_T + tx * 4 + r < c) nn[heads * c + h * c + tj * CG_T + tx * 4 + r] = nk[r];
+}
+
+// step 2: one block per (frame, head, row i): sum the splits in a fixed order, cosine = G / (max(|q_i|, eps) max(|k_j|, eps)), x temperature,
+// softmax over j, fp16 row of the block-diagonal matrix W[h c + i][h c + j] (row pitch w_pitch; off-diagonal blocks stay zero).
+__global__ void __launch_bounds__(256) chan_softmax_kernel(const float* __restrict__ part_g, const float* __restrict__ part_n, const float* __restrict__ temp,
+                                                           half_t* __restrict__ wout, int64_t w_fs, int w_pitch, int heads, int c, int S) {
+    __shared__ float red[256];
+    int bid = blockIdx.x;
+    const int i = bid % c; bid /= c;
+    const int h = bid % heads, b = bid / heads;
+    const int j = threadIdx.x;
+    float v = -INFINITY;
+    if (j < c) {
+        float g = 0.f, a = 0.f, bb = 0.f;
+        for (int sp = 0; sp < S; ++sp) {
+            g += part_g[((((int64_t)b * heads + h) * S + sp) * c + i) * c + j];
+            const float* nn = part_n + ((int64_t)b * S + sp) * 2 * heads * c;
+            a += nn[h * c + i];
+            bb += nn[heads * c + h * c + j];
+        }
+        v = g / (fmaxf(sqrtf(a), 1e-12f) * fmaxf(sqrtf(bb), 1e-12f)) * temp[h];
+    }
+    red[j] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (j < o) red[j] = fmaxf(red[j], red[j + o]); __syncthreads(); }
+    const float mx = red[0];
+    __syncthreads();
+    const float ex = j < c ? __expf(v - mx) : 0.f;
+    red[j] = ex;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if (j < o) red[j] += red[j + o]; __syncthreads(); }
+    if (j < c) wout[(int64_t)b * w_fs + (int64_t)(h * c + i) * w_pitch + h * c + j] = (half_t)(ex / red[0]);
+}
+
+int chan_attn_splits(int P, int heads, int c) {
+    const int tiles = ((c + CG_T - 1) / CG_T) * ((c + CG_T - 1) / CG_T) * heads;
+    int S = (512 + tiles - 1) / tiles;
+    const int maxS = (P + 127) / 128;
+    S = S > maxS ? maxS : S;
+    return S < 1 ? 1 : S;
+}
+
+int launch_chan_attn(const half_t* q, int q_cp, int q_co, int64_t q_fs, const half_t* k, int k_cp, int k_co, int64_t k_fs, const float* temp,
+                     float* part_g, float* part_n, half_t* wout, int64_t w_fs, int w_pitch, int B, int P, int heads, int c, hipStream_t s) {
+    if (c > 256 || (c & 7)) return (int)hipErrorInvalidValue;
+    const int S = chan_attn_splits(P, heads, c), tiles = (c + CG_T - 1) / CG_T;
+    hipLaunchKernelGGL(chan_gram_kernel, dim3(B * heads * tiles * tiles * S), dim3(256), 0, s, q, q_cp, q_co, q_fs, k, k_cp, k_co, k_fs, part_g, part_n, P,
+                       heads, c, S);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(chan_softmax_kernel, dim3(B * heads * c), dim3(256), 0, s, part_g, part_n, temp, wout, w_fs, w_pitch, heads, c, S);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Multi-head self-attention, head dim 64 (DINOv2 ViT-S/14: 6 heads), flash form.  A block = 64 queries of one head of one frame, 4 waves,
+// a wave owns one 16-query fragment; keys / values stream through LDS in tiles of 64 (K rows, V transposed while staging).
+//   S^T[key][query] = K[key][:] . Q[query][:]        two K-steps of v_mfma_f32_16x16x32_f16 (A = K rows from LDS, B = Q from registers)
+//   O^T[dv][query]  = V^T[dv][key] . P^T[key][query]  A = V^T rows from LDS, B = P straight from the S accumulators: S fragment f covers keys
+//       32 (f >> 1) + (i >> 2) 8 + (f & 1) 4 + (i & 3) (i = MFMA row), so a lane's eight P values of fragments 2s, 2s+1 are keys lg*8 .. +7 of
+//       the 32-key step s in natural order.  Row max / sum: in-lane over the lane's keys + __shfl_xor 16 / 32 over the 4 lanes of a query.
+constexpr int M64_KT = 64, M64_KP = 64 + 8, M64_VP = 64 + 8;
+__global__ void __launch_bounds__(256) mha64_kernel(const half_t* __restrict__ qkv, int cp, int q_co, int k_co, int v_co, int tok, half_t* __restrict__ o,
+                                                    int o_cp, int o_co, int o_tok, int heads, int L, float scale) {
+    __shared__ __attribute__((aligned(16))) half_t Ks[M64_KT * M64_KP];
+    __shared__ __attribute__((aligned(16))) half_t VsT[64 * M64_VP];
+    const int qt = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+    const half_t* base = qkv + (int64_t)b * tok * cp;
+    const int iq = qt * 64 + wave * 16 + lr;
+    half8 qf[2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st) qf[st] = *reinterpret_cast<const half8*>(base + (int64_t)min(iq, L - 1) * cp + q_co + h * 64 + st * 32 + lg * 8);
+    float m = -INFINITY, l = 0.f;
+    float4v oacc[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) oacc[f] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < L; k0 += M64_KT) {
+        const int nk = min(M64_KT, L - k0);
+        __syncthreads();                                           // the previous tile is fully consumed
+        for (int i = tid; i < M64_KT * 8; i += 256) {
+            const int key = i >> 3, ch = i & 7;
+            half8 tk, tv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { tk[e] = (half_t)0.f; tv[e] = (half_t)0.f; }
+            if (key < nk) {
+                const half_t* row = base + (int64_t)(k0 + key) * cp + h * 64 + ch * 8;
+                tk = *reinterpret_cast<const half8*>(row + k_co);
+                tv = *reinterpret_cast<const half8*>(row + v_co);
+            }
+            *reinterpret_cast<half8*>(&Ks[key * M64_KP + ch * 8]) = tk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) VsT[(ch * 8 + e) * M64_VP + key] = tv[e];
+        }
+        __syncthreads();
+        float4v sacc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int krow = 32 * (f >> 1) + (lr >> 2) * 8 + (f & 1) * 4 + (lr & 3);
+            sacc[f] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                const half8 kf = *reinterpret_cast<const half8*>(&Ks[krow * M64_KP + st * 32 + lg * 8]);
+                sacc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[st], sacc[f], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = 32 * (f >> 1) + lg * 8 + (f & 1) * 4 + r;
+                sacc[f][r] = key < nk ? sacc[f][r] * scale : -INFINITY;
+                mx = fmaxf(mx, sacc[f][r]);
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m, mx);
+        const float corr = __expf(m - mn);                         // first tile: exp(-inf) = 0
+        m = mn;
+        l *= corr;
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[f][r] *= corr;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            half8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float pv = __expf(sacc[2 * s2 + (j >> 2)][j & 3] - m);
+                l += pv;
+                pf[j] = (half_t)pv;
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const half8 vf = *reinterpret_cast<const half8*>(&VsT[(f * 16 + lr) * M64_VP + s2 * 32 + lg * 8]);
+                oacc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[f], 0, 0, 0);
+            }
+        }
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    if (iq < L) {
+        const float inv = 1.f / l;
+        half_t* op = o + ((int64_t)b * o_tok + iq) * o_cp + o_co + h * 64;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            half4v t;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = (half_t)(oacc[f][r] * inv);
+            *reinterpret_cast<half4v*>(op + f * 16 + lg * 4) = t;
+        }
+    }
+}
+
+int launch_mha64(const half_t* qkv, int cp, int q_co, int k_co, int v_co, int tok, half_t* o, int o_cp, int o_co, int o_tok, int B, int heads, int L,
+                 float scale, hipStream_t s) {
+    hipLaunchKernelGGL(mha64_kernel, dim3((L + 63) / 64, heads, B), dim3(256), 0, s, qkv, cp, q_co, k_co, v_co, tok, o, o_cp, o_co, o_tok, heads, L, scale);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// CBAM channel gate: one block per frame.  avg / max over the pixels per channel, the shared MLP on both, sigmoid -> scale[C] (fp32).
+__global__ void __launch_bounds__(512) cbam_channel_kernel(const half_t* __restrict__ x, int cp, int co, int64_t fs, int P, int C, int Ch,
+                                                           const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                           const float* __restrict__ b2, float* __restrict__ scale) {
+    extern __shared__ float sm[];                                 // avg[C], mx[C], hid[2 * Ch]
+    float* avg = sm; float* mxs = sm + C; float* hid = sm + 2 * C;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const half_t* xb = x + (int64_t)b * fs + co;
+    for (int c = tid; c < C; c += blockDim.x) {
+        float s0 = 0.f, s1 = 0.f, m0 = -INFINITY, m1 = -INFINITY;
+        int p = 0;
+        for (; p + 1 < P; p += 2) {
+            const float a0 = (float)xb[(int64_t)p * cp + c], a1 = (float)xb[(int64_t)(p + 1) * cp + c];
+            s0 += a0; s1 += a1; m0 = fmaxf(m0, a0); m1 = fmaxf(m1, a1);
+        }
+        if (p < P) { const float a0 = (float)xb[(int64_t)p * cp + c]; s0 += a0; m0 = fmaxf(m0, a0); }
+        avg[c] = (s0 + s1) / (float)P;
+        mxs[c] = fmaxf(m0, m1);
+    }
+    __syncthreads();
+    for (int t = tid; t < 2 * Ch; t += blockDim.x) {
+        const int kk = t % Ch;
+        const float* v = t < Ch ? avg : mxs;
+        float acc = b1[kk];
+        for (int c = 0; c < C; ++c) acc += w1[kk * C + c] * v[c];
+        hid[t] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += blockDim.x) {
+        float acc = 2.f * b2[c];
+        for (int kk = 0; kk < Ch; ++kk) acc += w2[c * Ch + kk] * (hid[kk] + hid[Ch + kk]);
+        scale[(int64_t)b * C + c] = 1.f / (1.f + __expf(-acc));
+    }
+}
+
+// spatial pool: one wave per pixel: max_c and mean_c of x * scale -> comp[B][P][2]
+__global__ void cbam_spatial_pool_kernel(const half_t* __restrict__ x, int cp, int co, int64_t fs, int B, int P, int C, const float* __restrict__ scale,
+                                         float* __restrict__ comp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave0; i < (int64_t)B * P; i += nw) {
+        const int b = (int)(i / P), p = (int)(i % P);
+        float mx = -INFINITY, sum = 0.f;
+        for (int c8 = lane; c8 < C / 8; c8 += 64) {
+            const half8 v = *reinterpret_cast<const half8*>(x + (int64_t)b * fs + (int64_t)p * cp + co + c8 * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float t = (float)v[e] * scale[(int64_t)b * C + c8 * 8 + e]; mx = fmaxf(mx, t); sum += t; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); sum += __shfl_xor(sum, o); }
+        if (lane == 0) { comp[i * 2] = mx; comp[i * 2 + 1] = sum / (float)C; }
+    }
+}
+
+// apply: one wave per pixel: sg = sigmoid(conv7x7(comp) + bias); y = x (1 + scale[c] sg)  (= g + CBAM(g)); y2 (optional) = relu(y)
+__global__ void cbam_apply_kernel(const half_t* __restrict__ x, int cp, int co, int64_t fs, int B, int H, int W, int C, const float* __restrict__ scale,
+                                  const float* __restrict__ comp, const float* __restrict__ w7, const float* __restrict__ b7, half_t* __restrict__ y,
+                                  int y_cp, int y_co, int64_t y_fs, half_t* __restrict__ y2, int y2_cp, int y2_co, int64_t y2_fs) {
+    const int lane = threadIdx.x & 63, P = H * W;
+    const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave0; i < (int64_t)B * P; i += nw) {
+        const int b = (int)(i / P), p = (int)(i % P), py = p / W, px = p % W;
+        float acc = 0.f;
+        for (int t = lane; t < 98; t += 64) {
+            const int ch = t / 49, k = t % 49, yy = py + k / 7 - 3, xx = px + k % 7 - 3;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc += w7[ch * 49 + k] * comp[((int64_t)b * P + yy * W + xx) * 2 + ch];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        const float sg = 1.f / (1.f + __expf(-(acc + b7[0])));
+        for (int c8 = lane; c8 < C / 8; c8 += 64) {
+            const half8 v = *reinterpret_cast<const half8*>(x + (int64_t)b * fs + (int64_t)p * cp + co + c8 * 8);
+            half8 o, o2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = (float)v[e] * (1.f + scale[(int64_t)b * C + c8 * 8 + e] * sg);
+                o[e] = (half_t)t;
+                o2[e] = (half_t)fmaxf(t, 0.f);
+            }
+            *reinterpret_cast<half8*>(y + (int64_t)b * y_fs + (int64_t)p * y_cp + y_co + c8 * 8) = o;
+            if (y2) *reinterpret_cast<half8*>(y2 + (int64_t)b * y2_fs + (int64_t)p * y2_cp + y2_co + c8 * 8) = o2;
+        }
+    }
+}
+
+int launch_cbam(const half_t* x, int cp, int co, int64_t fs, int B, int H, int W, int C, const float* w1, const float* b1, const float* w2, const float* b2,
+                const float* w7, const float* b7, float* scale, float* comp, half_t* y, int y_cp, int y_co, int64_t y_fs, half_t* y2, int y2_cp, int y2_co,
+                int64_t y2_fs, hipStream_t s) {
+    const int Ch = C / 16, P = H * W;
+    if ((C & 15) || C > 4096) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(cbam_channel_kernel, dim3(B), dim3(512), (2 * C + 2 * Ch) * sizeof(float), s, x, cp, co, fs, P, C, Ch, w1, b1, w2, b2, scale);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(cbam_spatial_pool_kernel, dim3(grid_for((int64_t)B * P, 4)), dim3(256), 0, s, x, cp, co, fs, B, P, C, scale, comp);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(cbam_apply_kernel, dim3(grid_for((int64_t)B * P, 4)), dim3(256), 0, s, x, cp, co, fs, B, H, W, C, scale, comp, w7, b7, y, y_cp, y_co,
+                       y_fs, y2, y2_cp, y2_co, y2_fs);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// GRU-like hidden update (modules.py:66-76): values = conv3x3(cat[g, h]) as an NHWC fp16 view of 3 hd channels (forget | update | new),
+// h and the result fp32 planar [B][hd][P] (the reference's hidden-state tensor): new_h = f h (1 - u) + u n
+__global__ void gru_kernel(const half_t* __restrict__ v, int cp, int co, int64_t fs, const float* __restrict__ h, float* __restrict__ out, int B, int P,
+                           int hd) {
+    const int64_t total = (int64_t)B * hd * P;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % P);
+        const int c = (int)((i / P) % hd), b = (int)(i / ((int64_t)P * hd));
+        const half_t* vp = v + (int64_t)b * fs + (int64_t)p * cp + co;
+        const float f = 1.f / (1.f + __expf(-(float)vp[c])), u = 1.f / (1.f + __expf(-(float)vp[hd + c])), n = tanhf((float)vp[2 * hd + c]);
+        out[i] = f * h[i] * (1.f - u) + u * n;
+    }
+}
+
+int launch_gru(const half_t* v, int cp, int co, int64_t fs, const float* h, float* out, int B, int P, int hd, hipStream_t s) {
+    hipLaunchKernelGGL(gru_kernel, dim3(grid_for((int64_t)B * hd * P)), dim3(256), 0, s, v, cp, co, fs, h, out, B, P, hd);
+    return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// fp32 planar [B][C][P] (pixel_major = 0) or [B][P][C] (pixel_major = 1) -> NHWC fp16 view of C8 * 8 channels (channels >= C written as 0)
+__global__ void planar_in_kernel(const float* __restrict__ x, int64_t x_fs, half_t* __restrict__ y, int cp, int co, int64_t fs, int B, int P, int C, int C8,
+                                 int pixel_major, int bcast) {
+    const int64_t total = (int64_t)B * C8 * P;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % P);
+        const int c8 = (int)((i / P) % C8), b = (int)(i / ((int64_t)P * C8));
+        const float* xb = x + (bcast ? 0 : (int64_t)b * x_fs);
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c8 * 8 + e;
+            o[e] = c < C ? (half_t)(pixel_major ? xb[(int64_t)p * C + c] : xb[(int64_t)c * P + p]) : (half_t)0.f;
+        }
+        *reinterpret_cast<half8*>(y + (int64_t)b * fs + (int64_t)p * cp + co + c8 * 8) = o;
+    }
+}
+
+int launch_planar_in(const float* x, int64_t x_fs, half_t* y, int cp, int co, int64_t fs, int B, int P, int C, int span, int pixel_major, int bcast,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(planar_in_kernel, dim3(grid_for((int64_t)B * (span / 8) * P)), dim3(256), 0, s, x, x_fs, y, cp, co, fs, B, P, C, span / 8, pixel_major,
+                       bcast);
+    return (int)hipGetLastError();
+}
+
+// NHWC fp16 view (C channels at co) -> fp32 planar [B][C][P]; act 0 none, 1 x^2 + 1 (shrinkage), 2 sigmoid (selection), 3 tanh (ab planes)
+__global__ void planar_out_kernel(const half_t* __restrict__ x, int cp, int co, int64_t fs, float* __restrict__ y, int64_t y_fs, int B, int P, int C, int act) {
+    const int C8 = (C + 7) / 8;
+    const int64_t total = (int64_t)B * C8 * P;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % P);
+        const int c8 = (int)((i / P) % C8), b = (int)(i / ((int64_t)P * C8));
+        const half_t* xp = x + (int64_t)b * fs + (int64_t)p * cp + co + c8 * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c8 * 8 + e;
+            if (c >= C) break;
+            float t = (float)xp[e];
+            if (act == 1) t = t * t + 1.f;
+            else if (act == 2) t = 1.f / (1.f + __expf(-t));
+            else if (act == 3) t = tanhf(t);
+            y[(int64_t)b * y_fs + (int64_t)c * P + p] = t;
+        }
+    }
+}
+
+int launch_planar_out(const half_t* x, int cp, int co, int64_t fs, float* y, int64_t y_fs, int B, int P, int C, int act, hipStream_t s) {
+    hipLaunchKernelGGL(planar_out_kernel, dim3(grid_for((int64_t)B * ((C + 7) / 8) * P)), dim3(256), 0, s, x, cp, co, fs, y, y_fs, B, P, C, act);
+    return (int)hipGetLastError();
+}

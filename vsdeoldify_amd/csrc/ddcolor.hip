@@ -59,7 +59,7 @@ int launch_dwconv7(const half_t* x, const half_t* w, const float* bias, half_t* 
 template <int LP>
 __global__ void layernorm_c_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, int64_t npix, int C, int x_cpitch, int x_coff, int y_cpitch,
-                                   int y_coff) {
+                                   int y_coff, int relu) {
     constexpr int PPW = 64 / LP;                               // pixels per wave
     const int lane = threadIdx.x & 63, l = lane % LP, sub = lane / LP;
     const int C8 = (C + 7) / 8;
@@ -100,7 +100,9 @@ __global__ void layernorm_c_kernel(const half_t* __restrict__ x, half_t* __restr
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = c8 * 8 + e;
-                    o[e] = c < C ? (half_t)((v[k][e] - mean) * rstd * gamma[c] + beta[c]) : (half_t)0.f;
+                    float t = c < C ? (v[k][e] - mean) * rstd * gamma[c] + beta[c] : 0.f;
+                    if (relu) t = fmaxf(t, 0.f);                       // ColorMNet Fuse: relu(norm3(x)) (colormnet/model/resnet.py:395-396)
+                    o[e] = (half_t)t;
                 }
                 *reinterpret_cast<half8*>(y + p * y_cpitch + y_coff + c8 * 8) = o;
             }
@@ -108,12 +110,12 @@ __global__ void layernorm_c_kernel(const half_t* __restrict__ x, half_t* __restr
     }
 }
 int launch_layernorm_c(const half_t* x, half_t* y, const float* gamma, const float* beta, float eps, int64_t npix, int C, int x_cpitch,
-                       int x_coff, int y_cpitch, int y_coff, hipStream_t s) {
+                       int x_coff, int y_cpitch, int y_coff, hipStream_t s, int relu) {
     if (C > 2048) return (int)hipErrorInvalidValue;
     const int need = ((C + 7) / 8 + 3) / 4;                    // lanes per pixel at 4 chunks per lane
 #define LN_LAUNCH(LP)                                                                                                                          \
     hipLaunchKernelGGL(layernorm_c_kernel<LP>, dim3(grid_for_dd((npix + 64 / LP - 1) / (64 / LP), 4)), dim3(256), 0, s, x, y, gamma, beta, eps, npix, \
-                       C, x_cpitch, x_coff, y_cpitch, y_coff)
+                       C, x_cpitch, x_coff, y_cpitch, y_coff, relu)
     if (need <= 8) LN_LAUNCH(8);
     else if (need <= 16) LN_LAUNCH(16);
     else if (need <= 32) LN_LAUNCH(32);

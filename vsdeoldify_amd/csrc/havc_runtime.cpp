@@ -74,6 +74,7 @@ struct havc_net {
     std::vector<int64_t> ktab_off;        // per op: element offset into d_ktab, -1 for non-conv ops
     const void* in_override = nullptr;
     void* out_override = nullptr;
+    std::vector<void*> bound;             // havc_net_bind: caller-owned device memory standing in for a buffer (nullptr = own allocation)
     double flops_per_frame = 0;
 };
 
@@ -239,6 +240,7 @@ int pil_resize_dev(havc_ctx* c, const uint8_t* d_src, int sw, int sh, uint8_t* d
 inline void* bufptr(havc_net* n, int id) {
     if (id == n->in_buf && n->in_override) return const_cast<void*>(n->in_override);
     if (id == n->out_buf && n->out_override) return n->out_override;
+    if (!n->bound.empty() && n->bound[id]) return n->bound[id];
     return n->bufs[id];
 }
 
@@ -465,7 +467,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             if (op.scale_off < 0 || op.shift_off < 0) return fail(c, HAVC_E_INVALID, "layernorm op: gamma / beta");
             e = launch_layernorm_c((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), wptr<float>(n, op.scale_off),
                                    wptr<float>(n, op.shift_off), op.f0, (int64_t)batch * op.Hi * op.Wi, op.Ci, op.src_cpitch, op.src_coff,
-                                   op.dst_cpitch, op.dst_coff, s);
+                                   op.dst_cpitch, op.dst_coff, s, (op.flags & HAVC_F_RELU_POST) ? 1 : 0);
             break;
         case HAVC_OP_MHA:
             if (op.src2 < 0 || op.Ci != op.kh * 32) return fail(c, HAVC_E_INVALID, "mha op: K/V buffer, head dim 32");
@@ -491,6 +493,84 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             e = launch_prep_ddcolor((const uint8_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
                                     op.src2 >= 0 ? (half_t*)bufptr(n, op.src2) : nullptr, op.res_cpitch, op.res_coff,
                                     (int64_t)batch * op.Hi * op.Wi, s);
+            break;
+        case HAVC_OP_EW: {
+            EwArgs a{};
+            const bool dual = op.flags & HAVC_EW_DUAL, res = op.flags & HAVC_EW_RES;
+            if ((op.Ci & 7) || op.kh < 0 || op.kh > 2 || (res && op.src2 < 0) || (dual && (op.aux0 < 0 || op.aux0 >= (int)n->bufs.size())) ||
+                (op.kh == 0 && (op.Hi != op.Ho || op.Wi != op.Wo)) || (op.kh == 2 && (op.kw < 1 || op.Ho * op.kw != op.Hi || op.Wo * op.kw != op.Wi)))
+                return fail(c, HAVC_E_INVALID, "ew op: channels / mode / sizes / buffers");
+            a.x = (const half_t*)bufptr(n, op.src); a.y = (half_t*)bufptr(n, op.dst);
+            a.res = res ? (const half_t*)bufptr(n, op.src2) : nullptr;
+            a.y2 = dual ? (half_t*)bufptr(n, op.aux0) : nullptr;
+            a.B = batch; a.Hi = op.Hi; a.Wi = op.Wi; a.Ho = op.Ho; a.Wo = op.Wo; a.C8 = op.Ci / 8;
+            a.x_cp = op.src_cpitch; a.x_co = op.src_coff; a.y_cp = op.dst_cpitch; a.y_co = op.dst_coff;
+            a.r_cp = op.res_cpitch; a.r_co = op.res_coff; a.y2_cp = op.Kc; a.y2_co = op.aux1;
+            a.x_fs = (op.flags & HAVC_EW_SRC_BCAST) ? 0 : n->bufdesc[op.src].elems_per_frame;
+            a.y_fs = n->bufdesc[op.dst].elems_per_frame;
+            a.r_fs = (!res || (op.flags & HAVC_EW_RES_BCAST)) ? 0 : n->bufdesc[op.src2].elems_per_frame;
+            a.y2_fs = dual ? n->bufdesc[op.aux0].elems_per_frame : 0;
+            a.mode = op.kh; a.factor = op.kw; a.flags = op.flags; a.rh = op.f0; a.rw = op.f1;
+            e = launch_ew(a, s);
+            break;
+        }
+        case HAVC_OP_DWCONV:
+            if (op.w_off < 0 || (op.Ci & 7) || (op.kh != 3 && op.kh != 5)) return fail(c, HAVC_E_INVALID, "dwconv op: weights / channels / kernel size");
+            e = launch_dwconv((const half_t*)bufptr(n, op.src), wptr<half_t>(n, op.w_off), wptr<float>(n, op.bias_off), (half_t*)bufptr(n, op.dst), batch,
+                              op.Hi, op.Wi, op.Ci, op.kh, op.src_cpitch, op.src_coff, n->bufdesc[op.src].elems_per_frame, op.dst_cpitch, op.dst_coff,
+                              n->bufdesc[op.dst].elems_per_frame, op.Kc, s);
+            break;
+        case HAVC_OP_CHAN_ATTN: {
+            const int heads = op.kh, cc = heads > 0 ? op.Ci / heads : 0, P = op.Hi * op.Wi;
+            if (heads < 1 || cc * heads != op.Ci || cc > 256 || (cc & 7) || op.src2 < 0 || op.scale_off < 0 || op.aux0 < 0 || op.aux1 < 0 ||
+                op.aux0 >= (int)n->bufs.size() || op.aux1 >= (int)n->bufs.size())
+                return fail(c, HAVC_E_INVALID, "channel-attention op: heads / channels per head (<= 256) / buffers");
+            const int S = chan_attn_splits(P, heads, cc);
+            if ((uint64_t)n->bufdesc[op.aux0].elems_per_frame < (uint64_t)heads * S * cc * cc || (uint64_t)n->bufdesc[op.aux1].elems_per_frame < (uint64_t)S * 2 * op.Ci ||
+                (uint64_t)n->bufdesc[op.dst].elems_per_frame < (uint64_t)op.Ci * op.Kc * 8)
+                return fail(c, HAVC_E_INVALID, "channel-attention op: scratch / matrix buffers too small");
+            e = launch_chan_attn((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, n->bufdesc[op.src].elems_per_frame,
+                                 (const half_t*)bufptr(n, op.src2), op.res_cpitch, op.res_coff, n->bufdesc[op.src2].elems_per_frame, wptr<float>(n, op.scale_off),
+                                 (float*)bufptr(n, op.aux0), (float*)bufptr(n, op.aux1), (half_t*)bufptr(n, op.dst), n->bufdesc[op.dst].elems_per_frame,
+                                 op.Kc * 8, batch, P, heads, cc, s);
+            c->stats.launches += 1;
+            break;
+        }
+        case HAVC_OP_MHA64:
+            if (op.Ci != op.kh * 64 || op.Ho < 1 || op.Ho > op.Wi) return fail(c, HAVC_E_INVALID, "mha64 op: head dim 64, live tokens <= tokens per frame");
+            e = launch_mha64((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, op.res_coff, op.aux0, op.Wi, (half_t*)bufptr(n, op.dst),
+                             op.dst_cpitch, op.dst_coff, op.Wi, batch, op.kh, op.Ho, op.f0, s);
+            break;
+        case HAVC_OP_CBAM: {
+            const int C = op.Ci, Ch = C / 16;
+            const bool dual = op.flags & HAVC_EW_DUAL;
+            if (op.w_off < 0 || (C & 15) || op.aux0 < 0 || op.aux1 < 0 || (dual && op.src2 < 0) || (uint64_t)n->bufdesc[op.aux0].elems_per_frame < (uint64_t)C ||
+                (uint64_t)n->bufdesc[op.aux1].elems_per_frame < (uint64_t)op.Hi * op.Wi * 2)
+                return fail(c, HAVC_E_INVALID, "cbam op: weights / channels / scratch buffers");
+            const float* w1 = wptr<float>(n, op.w_off);
+            const float *b1 = w1 + (size_t)Ch * C, *w2 = b1 + Ch, *b2 = w2 + (size_t)C * Ch, *w7 = b2 + C, *b7 = w7 + 98;
+            e = launch_cbam((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, n->bufdesc[op.src].elems_per_frame, batch, op.Hi, op.Wi, C, w1, b1,
+                            w2, b2, w7, b7, (float*)bufptr(n, op.aux0), (float*)bufptr(n, op.aux1), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
+                            n->bufdesc[op.dst].elems_per_frame, dual ? (half_t*)bufptr(n, op.src2) : nullptr, op.res_cpitch, op.res_coff,
+                            dual ? n->bufdesc[op.src2].elems_per_frame : 0, s);
+            c->stats.launches += 2;
+            break;
+        }
+        case HAVC_OP_GRU:
+            if (op.src2 < 0 || n->bufdesc[op.src2].elem_bytes != 4 || n->bufdesc[op.dst].elem_bytes != 4 || op.Co < 1)
+                return fail(c, HAVC_E_INVALID, "gru op: fp32 planar hidden buffers");
+            e = launch_gru((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, n->bufdesc[op.src].elems_per_frame, (const float*)bufptr(n, op.src2),
+                           (float*)bufptr(n, op.dst), batch, op.Hi * op.Wi, op.Co, s);
+            break;
+        case HAVC_OP_PLANAR_IN:
+            if (n->bufdesc[op.src].elem_bytes != 4 || (op.Co & 7) || op.Ci > op.Co) return fail(c, HAVC_E_INVALID, "planar-in op: fp32 source, Ci <= Co, Co % 8 == 0");
+            e = launch_planar_in((const float*)bufptr(n, op.src), n->bufdesc[op.src].elems_per_frame, (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
+                                 n->bufdesc[op.dst].elems_per_frame, batch, op.Hi * op.Wi, op.Ci, op.Co, op.flags & 1, (op.flags & 2) ? 1 : 0, s);
+            break;
+        case HAVC_OP_PLANAR_OUT:
+            if (n->bufdesc[op.dst].elem_bytes != 4 || op.kh < 0 || op.kh > 3) return fail(c, HAVC_E_INVALID, "planar-out op: fp32 destination, activation 0..3");
+            e = launch_planar_out((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, n->bufdesc[op.src].elems_per_frame, (float*)bufptr(n, op.dst),
+                                  n->bufdesc[op.dst].elems_per_frame, batch, op.Hi * op.Wi, op.Ci, op.kh, s);
             break;
         default:
             return fail(c, HAVC_E_INVALID, "unknown op type");
@@ -883,6 +963,24 @@ int havc_net_download(havc_net* n, int buf, void* host, size_t nbytes) {
     HIP_TRY(c, hipMemcpy(host, n->bufs[buf], nbytes, hipMemcpyDeviceToHost));
     return HAVC_OK;
 }
+
+int havc_net_bind(havc_net* n, int buf, void* device_ptr) {
+    if (!n || buf < 0 || buf >= (int)n->bufs.size()) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(n->ctx->mu);
+    if (n->bound.empty()) n->bound.assign(n->bufs.size(), nullptr);
+    n->bound[buf] = device_ptr;
+    return HAVC_OK;
+}
+
+int havc_net_enqueue_ops(havc_net* n, int first_op, int n_ops, int batch) {
+    if (!n) return HAVC_E_INVALID;
+    havc_ctx* c = n->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    return run_ops_locked(n, first_op, n_ops, batch);
+}
+
+void* havc_get_stream(havc_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 int havc_net_run_ops(havc_net* n, int first_op, int n_ops, int batch) {
     if (!n) return HAVC_E_INVALID;
@@ -1882,6 +1980,40 @@ int havc_local_attention(havc_ctx* c, const float* q, const float* k, const floa
         if (!host_agg) HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
     return stage_out(c, agg, d_agg, fo, host_agg);
+}
+
+// ---- ColorMNetRender's frame transforms (colormnet_render.py:285-301, 276-279) ----
+int havc_colormnet_rgb_to_lab(havc_ctx* c, const uint8_t* rgb, float* lab, int width, int height) {
+    if (!c || !rgb || !lab || width < 1 || height < 1) return fail(c, HAVC_E_INVALID, "colormnet_rgb_to_lab: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t npix = (size_t)width * height;
+    const uint8_t* d_in;
+    uint8_t* d_out;
+    bool host;
+    int rc;
+    if ((rc = stage_in(c, 0, rgb, npix * 3, &d_in)) || (rc = stage_out_ptr(c, 2, lab, npix * 12, &d_out, &host))) return rc;
+    int e = launch_cmn_rgb_to_lab(d_in, (float*)d_out, (int64_t)npix, c->stream);
+    c->stats.launches++;
+    if (e) return hip_fail(c, (hipError_t)e, "colormnet_rgb_to_lab");
+    return stage_out(c, lab, d_out, npix * 12, host);
+}
+
+int havc_colormnet_lab_to_rgb(havc_ctx* c, const float* l_plane, const float* ab, uint8_t* rgb, int width, int height) {
+    if (!c || !l_plane || !ab || !rgb || width < 1 || height < 1) return fail(c, HAVC_E_INVALID, "colormnet_lab_to_rgb: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t npix = (size_t)width * height;
+    const float *d_l, *d_ab;
+    uint8_t* d_out;
+    bool host;
+    int rc;
+    if ((rc = stage_in_f(c, 0, l_plane, npix * 4, &d_l)) || (rc = stage_in_f(c, 1, ab, npix * 8, &d_ab)) || (rc = stage_out_ptr(c, 2, rgb, npix * 3, &d_out, &host)))
+        return rc;
+    int e = launch_cmn_lab_to_rgb(d_l, d_ab, d_out, (int64_t)npix, c->stream);
+    c->stats.launches++;
+    if (e) return hip_fail(c, (hipError_t)e, "colormnet_lab_to_rgb");
+    return stage_out(c, rgb, d_out, npix * 3, host);
 }
 
 int havc_dev_copy(havc_ctx* c, void* d_dst, const void* d_src, size_t nbytes) {

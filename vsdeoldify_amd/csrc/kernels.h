@@ -105,7 +105,7 @@ int launch_fold_queries(const half_t* e, int e_cpitch, int e_coff, int tok, cons
 int launch_shuf4_blur_ab(const float* proj, const half_t* img, int img_cpitch, int img_coff, const float* rimg, const float* bias, half_t* y,
                          int y_cpitch, int y_coff, int B, int Hi, int Wi, hipStream_t s);
 int launch_layernorm_c(const half_t* x, half_t* y, const float* gamma, const float* beta, float eps, int64_t npix, int C, int x_cpitch,
-                       int x_coff, int y_cpitch, int y_coff, hipStream_t s);
+                       int x_coff, int y_cpitch, int y_coff, hipStream_t s, int relu = 0);
 int launch_mha32(const half_t* q, int q_cpitch, int q_coff, int q_tok, const half_t* kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,
                  half_t* o, int o_cpitch, int o_coff, int o_tok, int B, int heads, int Lq, int Lk, float scale, hipStream_t s);
 int mha32_nsplit(int Lk);
@@ -150,3 +150,38 @@ int launch_mem_topk_readout(const float* sim, const float* mv, int* idx, float* 
 int launch_local_correlation(const float* q, const float* k, float* out, int n, int C, int H, int W, int R, int dil, float qscale, hipStream_t s);
 int launch_local_softmax(float* qk, const float* q, const float* rel_w, const float* rel_b, int n, int C, int H, int W, int R, int dil, hipStream_t s);
 int launch_local_agg(const float* attn, const float* v, float* agg, int n, int CV, int H, int W, int R, int dil, hipStream_t s);
+
+// ---- ColorMNet network kernels (colormnet_net.hip) ----
+#ifndef HAVC_EW_SRC_BCAST          // (public values: include/havc_mi355.h)
+#define HAVC_EW_SRC_BCAST 1
+#define HAVC_EW_RES 2
+#define HAVC_EW_RES_BCAST 4
+#define HAVC_EW_RELU 8
+#define HAVC_EW_DUAL 16
+#endif
+struct EwArgs {
+    const half_t* x; half_t* y; const half_t* res; half_t* y2;
+    int B, Hi, Wi, Ho, Wo, C8;
+    int x_cp, x_co, y_cp, y_co, r_cp, r_co, y2_cp, y2_co;
+    int64_t x_fs, y_fs, r_fs, y2_fs;          // frame strides in elements (0 = the same frame for every batch entry)
+    int mode, factor, flags;                  // mode 0 copy, 1 bilinear (align_corners = False), 2 area (factor x factor mean)
+    float rh, rw;                             // bilinear source / destination ratios
+};
+int launch_ew(const EwArgs& a, hipStream_t s);
+int launch_dwconv(const half_t* x, const half_t* w, const float* bias, half_t* y, int B, int H, int W, int C, int K, int x_cp, int x_co, int64_t x_fs,
+                  int y_cp, int y_co, int64_t y_fs, int w_pitch, hipStream_t s);
+int chan_attn_splits(int P, int heads, int c);
+int launch_chan_attn(const half_t* q, int q_cp, int q_co, int64_t q_fs, const half_t* k, int k_cp, int k_co, int64_t k_fs, const float* temp,
+                     float* part_g, float* part_n, half_t* wout, int64_t w_fs, int w_pitch, int B, int P, int heads, int c, hipStream_t s);
+int launch_mha64(const half_t* qkv, int cp, int q_co, int k_co, int v_co, int tok, half_t* o, int o_cp, int o_co, int o_tok, int B, int heads, int L,
+                 float scale, hipStream_t s);
+int launch_cbam(const half_t* x, int cp, int co, int64_t fs, int B, int H, int W, int C, const float* w1, const float* b1, const float* w2, const float* b2,
+                const float* w7, const float* b7, float* scale, float* comp, half_t* y, int y_cp, int y_co, int64_t y_fs, half_t* y2, int y2_cp, int y2_co,
+                int64_t y2_fs, hipStream_t s);
+int launch_gru(const half_t* v, int cp, int co, int64_t fs, const float* h, float* out, int B, int P, int hd, hipStream_t s);
+int launch_planar_in(const float* x, int64_t x_fs, half_t* y, int cp, int co, int64_t fs, int B, int P, int C, int span, int pixel_major, int bcast,
+                     hipStream_t s);
+int launch_planar_out(const half_t* x, int cp, int co, int64_t fs, float* y, int64_t y_fs, int B, int P, int C, int act, hipStream_t s);
+// the frame wrapper of ColorMNetRender (zhang.hip: skimage Lab formulas in fp64)
+int launch_cmn_rgb_to_lab(const uint8_t* rgb, float* lab, int64_t npix, hipStream_t s);
+int launch_cmn_lab_to_rgb(const float* l_plane, const float* ab, uint8_t* rgb, int64_t npix, hipStream_t s);

@@ -271,3 +271,39 @@ int launch_pil_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* tmp, u
     }
     return (int)hipGetLastError();
 }
+
+
+// ---- ColorMNet frame wrapper (colormnet/colormnet_render.py:285-301 get_image, :276-279; dataset/range_transform.py:24-47): ----
+// RGB2Lab = float32(skimage.color.rgb2lab(u8 image)) -> Normalize(mean [50,0,0], std [50,110,110]) as three fp32 planes, and back:
+// inv_lll2rgb_trans ((x - [-1,0,0]) / [1/50, 1/110, 1/110] in fp32), skimage lab2rgb, clip(0, 1), * 255, truncate to u8.
+__global__ void cmn_rgb_to_lab_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ lab, int64_t npix) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const double R = srgb_to_linear(rgb[i * 3] / 255.0), G = srgb_to_linear(rgb[i * 3 + 1] / 255.0), B = srgb_to_linear(rgb[i * 3 + 2] / 255.0);
+        const double fx = lab_f((0.412453 * R + 0.357580 * G + 0.180423 * B) / 0.95047);
+        const double fy = lab_f(0.212671 * R + 0.715160 * G + 0.072169 * B);
+        const double fz = lab_f((0.019334 * R + 0.119193 * G + 0.950227 * B) / 1.08883);
+        const float L = (float)(116.0 * fy - 16.0), a = (float)(500.0 * (fx - fy)), b = (float)(200.0 * (fy - fz));
+        lab[i] = (L - 50.f) / 50.f;
+        lab[npix + i] = a / 110.f;
+        lab[2 * npix + i] = b / 110.f;
+    }
+}
+int launch_cmn_rgb_to_lab(const uint8_t* rgb, float* lab, int64_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(cmn_rgb_to_lab_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, lab, npix);
+    return (int)hipGetLastError();
+}
+__global__ void cmn_lab_to_rgb_kernel(const float* __restrict__ lp, const float* __restrict__ ab, uint8_t* __restrict__ rgb, int64_t npix) {
+    const float s50 = (float)(1 / 50.), s110 = (float)(1 / 110.);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const float L = (lp[i] - (-1.f)) / s50, a = ab[i] / s110, b = ab[npix + i] / s110;
+        double r, g, bl;
+        lab_to_rgb01((double)L, (double)a, (double)b, r, g, bl);
+        rgb[i * 3] = (uint8_t)(r * 255.0);
+        rgb[i * 3 + 1] = (uint8_t)(g * 255.0);
+        rgb[i * 3 + 2] = (uint8_t)(bl * 255.0);
+    }
+}
+int launch_cmn_lab_to_rgb(const float* l_plane, const float* ab, uint8_t* rgb, int64_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(cmn_lab_to_rgb_kernel, dim3(grid_for(npix)), dim3(256), 0, s, l_plane, ab, rgb, npix);
+    return (int)hipGetLastError();
+}

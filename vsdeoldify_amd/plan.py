@@ -328,9 +328,9 @@ class PlanBuilder:
         return self._op(name, type=nat.OP_SHUF4_BLUR_AB, src=proj_buf, src2=img.buf, res_coff=img.coff, res_cpitch=img.cpitch, dst=y.buf,
                         dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=Hi, Wi=Wi, Ci=2, Ho=y.H, Wo=y.W, Co=2, w_off=rimg_off, bias_off=bias_off, flops=flops)
 
-    def layernorm(self, name, x, y, gamma_off, beta_off, eps):
+    def layernorm(self, name, x, y, gamma_off, beta_off, eps, relu=False):
         assert x.C == y.C and x.H * x.W == y.H * y.W
-        return self._op(name, type=nat.OP_LAYERNORM, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf, dst_coff=y.coff,
+        return self._op(name, type=nat.OP_LAYERNORM, flags=(nat.F_RELU_POST if relu else 0), src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf, dst_coff=y.coff,
                         dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.C, Ho=y.H, Wo=y.W, Co=y.C, scale_off=gamma_off, shift_off=beta_off, f0=eps)
 
     def mha(self, name, q, kv, k_coff, v_coff, y, heads, n_q, n_k, scale):
@@ -362,6 +362,60 @@ class PlanBuilder:
         return self._op(name, type=nat.OP_CONV, flags=nat.F_W_FROM_BUF, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, src2=wview.buf,
                         dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.span, Ho=x.H, Wo=x.W, Co=y.span, kh=1, kw=1,
                         stride=1, pad=0, dil=1, Kc=Kc, Npad=Npad, aux1=Kc, out_step=1, flops=2 * x.H * x.W * n_rows * x.C)
+
+    # ---- ColorMNet ops (csrc/colormnet_net.hip) ----
+    def ew(self, name, x, y, mode=0, ratio=(1.0, 1.0), factor=1, res=None, src_bcast=False, res_bcast=False, relu=False, dual=None):
+        """copy / bilinear (align_corners False; ratio = source / destination as aten computes it) / area resample of view x into view y,
+        optional + res, optional ReLU, optional second rectified output `dual` (a View)."""
+        assert x.span == y.span and (res is None or res.span == x.span) and (dual is None or dual.span == x.span), name
+        flags = (nat.EW_SRC_BCAST if src_bcast else 0) | (nat.EW_RES if res is not None else 0) | (nat.EW_RES_BCAST if res_bcast else 0) | \
+                (nat.EW_RELU if relu else 0) | (nat.EW_DUAL if dual is not None else 0)
+        kw = dict(type=nat.OP_EW, flags=flags, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch,
+                  Hi=x.H, Wi=x.W, Ci=x.span, Ho=y.H, Wo=y.W, Co=y.span, kh=mode, kw=factor, f0=ratio[0], f1=ratio[1])
+        if res is not None:
+            kw.update(src2=res.buf, res_coff=res.coff, res_cpitch=res.cpitch)
+        if dual is not None:
+            kw.update(aux0=dual.buf, aux1=dual.coff, Kc=dual.cpitch)
+        return self._op(name, **kw)
+
+    def dwconv(self, name, x, y, w_off, bias_off, w_pitch, k):
+        assert x.span == y.span and x.H == y.H and x.W == y.W
+        return self._op(name, type=nat.OP_DWCONV, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch,
+                        Hi=x.H, Wi=x.W, Ci=x.span, Ho=y.H, Wo=y.W, Co=y.span, w_off=w_off, bias_off=bias_off, Kc=w_pitch, kh=k, kw=k,
+                        flops=2 * x.H * x.W * x.C * k * k)
+
+    def chan_attn(self, name, q, k, heads, temp_off, w_buf, w_kc, part_g, part_n):
+        assert q.span == k.span == q.C and q.H == k.H and q.W == k.W and q.C % heads == 0
+        c = q.C // heads
+        return self._op(name, type=nat.OP_CHAN_ATTN, src=q.buf, src_coff=q.coff, src_cpitch=q.cpitch, src2=k.buf, res_coff=k.coff, res_cpitch=k.cpitch,
+                        dst=w_buf, Hi=q.H, Wi=q.W, Ci=q.C, Ho=q.H, Wo=q.W, Co=q.C, kh=heads, Kc=w_kc, scale_off=temp_off, aux0=part_g, aux1=part_n,
+                        flops=2 * q.H * q.W * heads * c * c)
+
+    def mha64(self, name, qkv, q_coff, k_coff, v_coff, y, heads, live, scale):
+        assert qkv.H == 1 and y.H == 1 and y.W == qkv.W and y.C == heads * 64
+        return self._op(name, type=nat.OP_MHA64, src=qkv.buf, src_coff=qkv.coff + q_coff, src_cpitch=qkv.cpitch, res_coff=qkv.coff + k_coff,
+                        aux0=qkv.coff + v_coff, dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=1, Wi=qkv.W, Ci=heads * 64, Ho=live, Wo=qkv.W,
+                        Co=heads * 64, kh=heads, f0=scale, flops=4 * live * live * heads * 64)
+
+    def cbam(self, name, x, y, w_off, scale_buf, comp_buf, dual=None):
+        assert x.span == y.span == x.C and x.H == y.H
+        kw = dict(type=nat.OP_CBAM, flags=(nat.EW_DUAL if dual is not None else 0), src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf,
+                  dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.C, Ho=y.H, Wo=y.W, Co=y.C, w_off=w_off, aux0=scale_buf, aux1=comp_buf)
+        if dual is not None:
+            kw.update(src2=dual.buf, res_coff=dual.coff, res_cpitch=dual.cpitch)
+        return self._op(name, **kw)
+
+    def gru(self, name, values, h_buf, out_buf, hd):
+        return self._op(name, type=nat.OP_GRU, src=values.buf, src_coff=values.coff, src_cpitch=values.cpitch, src2=h_buf, dst=out_buf, Hi=values.H,
+                        Wi=values.W, Ci=3 * hd, Ho=values.H, Wo=values.W, Co=hd)
+
+    def planar_in(self, name, src_buf, C, y, pixel_major=False, bcast=False):
+        return self._op(name, type=nat.OP_PLANAR_IN, flags=(1 if pixel_major else 0) | (2 if bcast else 0), src=src_buf, dst=y.buf, dst_coff=y.coff,
+                        dst_cpitch=y.cpitch, Hi=y.H, Wi=y.W, Ci=C, Ho=y.H, Wo=y.W, Co=y.span)
+
+    def planar_out(self, name, x, coff, C, dst_buf, act=0):
+        return self._op(name, type=nat.OP_PLANAR_OUT, src=x.buf, src_coff=x.coff + coff, src_cpitch=x.cpitch, dst=dst_buf, Hi=x.H, Wi=x.W, Ci=C,
+                        Ho=x.H, Wo=x.W, Co=C, kh=act)
 
     def finish(self):
         ops = np.array(self.ops, dtype=nat.OP_DTYPE)
