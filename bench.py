@@ -44,24 +44,53 @@ TAG_TAIL_RES = 1
 PMC_FILE = os.path.join("profiles", "r2_tail_conv_pmc.json")
 
 
-def cpu_baseline_and_parity(sds, frame, gpu_out, threads):
-    """Time the CPU oracle (fp32 PyTorch restatement + numpy tail) on ONE frame of the same workload and use
-    its output as the parity reference for the GPU result of that frame."""
+PARITY_SEEDS = ((1, 2), (11, 12), (21, 22))     # (video, stable) weight seeds: the bench weights first
+PARITY_FRAMES = (4, 2, 2)                       # frames of the clip checked per seed pair: 8 frames over 3 weight sets
+
+
+def _stats(de, d):
+    return {"ciede2000_mean": round(float(de.mean()), 4), "ciede2000_p99": round(float(np.percentile(de, 99)), 4),
+            "ciede2000_max": round(float(de.max()), 4), "pixels_with_dE_below_1": round(float((de < 1.0).mean()), 5),
+            "bytes_within_1lsb": round(float((d <= 1).mean()), 5), "bytes_within_2lsb": round(float((d <= 2).mean()), 5)}
+
+
+def cpu_baseline_and_parity(cc_main, frames, threads, device_index):
+    """Time the CPU oracle (fp32 PyTorch restatement + numpy tail) on frames of the same workload and use its outputs as the parity
+    reference for the GPU results of those frames: 8 frames of the clip over 3 seeded weight sets (the bench weights + two more),
+    per-frame statistics pooled, the worst frame named."""
+    import gc
     import torch
     from oracle import imaging, pipeline
+    from vsdeoldify_amd.clip import ClipColorizer
+    from vsdeoldify_amd.synth import synth_state_dict
     torch.set_num_threads(threads)
-    t0 = time.time()
-    ref = pipeline.colorize_frame_fullsize(sds, "stable", frame, RENDER_FACTOR, 0.5)
-    dt = time.time() - t0
-    de = imaging.delta_e00_images(gpu_out, ref)
-    d = np.abs(gpu_out.astype(np.int32) - ref.astype(np.int32))
-    parity = {"ciede2000_mean": round(float(de.mean()), 4), "ciede2000_p99": round(float(np.percentile(de, 99)), 4),
-              "ciede2000_max": round(float(de.max()), 4), "pixels_with_dE_below_1": round(float((de < 1.0).mean()), 5),
-              "bytes_within_1lsb": round(float((d <= 1).mean()), 5), "bytes_within_2lsb": round(float((d <= 2).mean()), 5),
-              "frames_checked": 1, "against": "oracle (CPU fp32 port)",
-              "note": "fp16 MFMA operands; floor / decomposition in profiles/r2_precision_study.txt"}
-    base = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"1 frame of the 1080p clip (2 U-Net passes at 560x560 fp32 + Spline64/YUV tail), {dt:.1f} s"}
+    per, des, ds, cpu_s, cpu_n = [], [], [], 0.0, 0
+    for (sv, ss), nfr in zip(PARITY_SEEDS, PARITY_FRAMES):
+        sds = {"video": synth_state_dict("wide", sv), "stable": synth_state_dict("wide", ss)}
+        cc = cc_main if (sv, ss) == PARITY_SEEDS[0] else ClipColorizer("stable", RENDER_FACTOR, 0.5, device_index=device_index, state_dicts=sds, max_batch=2)
+        idx = [(i * 7) % len(frames) for i in range(nfr)]
+        got = np.concatenate([cc.colorize(frames[i:i + 1]) for i in idx])
+        for k, i in enumerate(idx):
+            t0 = time.time()
+            ref = pipeline.colorize_frame_fullsize(sds, "stable", frames[i], RENDER_FACTOR, 0.5)
+            cpu_s += time.time() - t0
+            cpu_n += 1
+            de = imaging.delta_e00_images(got[k], ref)
+            d = np.abs(got[k].astype(np.int32) - ref.astype(np.int32))
+            des.append(de.reshape(-1)); ds.append(d.reshape(-1))
+            per.append({"weights_seed": [sv, ss], "frame": int(i), "mean": round(float(de.mean()), 4), "p99": round(float(np.percentile(de, 99)), 4),
+                        "max": round(float(de.max()), 3)})
+        if cc is not cc_main:
+            for r in (cc.render._video, cc.render._second):
+                r.close()
+            del cc
+            gc.collect()
+    parity = _stats(np.concatenate(des), np.concatenate(ds))
+    worst = max(per, key=lambda r: r["p99"])
+    parity.update({"frames_checked": len(per), "weight_sets": len(PARITY_SEEDS), "worst_frame": worst, "per_frame": per, "against": "oracle (CPU fp32 port)",
+                   "note": "fp16 MFMA operands; floor / decomposition in profiles/r2_precision_study.txt"})
+    base = {"value": round(cpu_n / cpu_s, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{cpu_n} frames of the 1080p clip (2 U-Net passes at 560x560 fp32 + Spline64/YUV tail each), {cpu_s:.1f} s"}
     return base, parity
 
 
@@ -76,8 +105,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
     ap.add_argument("--clip-frames", type=int, default=32, help="distinct synthetic frames resident per GPU")
-    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4"],
-                    help="c2 = BASELINE configs[1] (headline), c3 = configs[2] (DDColor large, input 512), c4 = configs[3] (DeOldify+DDColor merge)")
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
+                    help="c2 = BASELINE configs[1] (headline), c3 = configs[2] (DDColor large, input 512), c4 = configs[3] (DeOldify+DDColor merge), "
+                         "c5 = configs[4] (ColorMNet exemplar path, 1 reference frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sustained / PCIe-inclusive / batch-1 legs")
     ap.add_argument("--sustain-seconds", type=float, default=30.0)
@@ -105,6 +135,8 @@ def main():
 
     if args.config in ("c3", "c4"):
         return bench_c4(args, rank, local_rank, world, dist, ddcolor_only=args.config == "c3")
+    if args.config == "c5":
+        return bench_c5(args, rank, local_rank, world, dist)
 
     from vsdeoldify_amd import _native as nat
     from vsdeoldify_amd.clip import ClipColorizer, synthetic_gray_frame
@@ -149,10 +181,16 @@ def main():
     nat.check(ctx.lib.havc_tag_timing_enable(ctx.h, TAG_TAIL_RES, 0), ctx.h)
     st = ctx.stats()
 
+    multi = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)                               # RCCL: one element per rank, proves every rank took part
+        t = mine.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        multi = {"rccl_ranks": int(dist.get_world_size()), "backend": dist.get_backend(), "cuda_device_count": torch.cuda.device_count(),
+                 "per_rank_frames_per_s": [round(args.steps * args.batch / float(e.item()), 2) for e in every]}
 
     total_frames = args.steps * args.batch * world
     S = RENDER_FACTOR * 16
@@ -191,13 +229,12 @@ def main():
                      "flops_per_launch": conv_flops},
         "gpu_ms_per_frame": round(st.total_ms / max(st.frames, 1), 4),
     }
+    if multi is not None:
+        out["multi_gpu"] = multi
     if rank == 0 and world == 1 and not args.no_extras:
         out.update(extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        got = np.empty((1, HEIGHT, WIDTH, 3), np.uint8)
-        step(0)
-        ctx.dev_download(got, d_dst)
-        base, parity = cpu_baseline_and_parity(sds, frames[0], got[0], min(os.cpu_count() or 1, args.cpu_threads))
+        base, parity = cpu_baseline_and_parity(cc, frames, min(os.cpu_count() or 1, args.cpu_threads), local_rank)
         out["cpu_baseline"] = base
         out["parity"] = parity
     if dist is not None:
@@ -340,13 +377,15 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
     from vsdeoldify_amd.device import DeviceImage
     from vsdeoldify_amd.havc import HAVCFrameColorizer
     from vsdeoldify_amd.synth import synth_ddcolor_state_dict, synth_state_dict
+    from vsdeoldify_amd.havc import DEF_TWEAK_p
+    dd_defaults = dict(ddtweak=(False, False, False), ddtweak_p=(DEF_TWEAK_p, HUE_ADJUST))      # HAVC_colorizer's defaults (__init__.py:2292-2293)
     if ddcolor_only:
         col = HAVCFrameColorizer(method=1, ddcolor_p=(1, 32, 1.0, 0.0, True), device_index=local_rank,
-                                 ddcolor_state_dict=synth_ddcolor_state_dict(1), max_batch=args.batch)
+                                 ddcolor_state_dict=synth_ddcolor_state_dict(1), max_batch=args.batch, **dd_defaults)
     else:
         col = HAVCFrameColorizer(method=2, mweight=0.4, deoldify_p=(0, 24, 1.0, 0.0), ddcolor_p=(1, 24, 1.0, 0.0, True), device_index=local_rank,
                                  state_dicts={"video": synth_state_dict("wide", 1)}, ddcolor_state_dict=synth_ddcolor_state_dict(1),
-                                 max_batch=args.batch)
+                                 max_batch=args.batch, **dd_defaults)
     ctx = col.ctx
     frames = np.stack([synthetic_gray_frame(rank * args.batch + i, WIDTH, HEIGHT) for i in range(args.batch)])
     clip = DeviceImage.from_numpy(ctx, frames)
@@ -361,21 +400,37 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
             dist.barrier()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+    from vsdeoldify_amd import _native as nat
+    from vsdeoldify_amd.ddcolor_net import TAG_STAGE2_PW1
+    tag = TAG_STAGE2_PW1 if ddcolor_only else TAG_TAIL_RES      # the launches each config spends most time in
     for i in range(max(args.warmup, 1)):
         step(i)
     ctx.reset_stats()
+    nat.check(ctx.lib.havc_tag_timing_enable(ctx.h, tag, 1), ctx.h)
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     sync_all()
     elapsed = time.perf_counter() - t0
+    avg_ms, launches = ctypes.c_double(), ctypes.c_int64()
+    nat.check(ctx.lib.havc_tag_timing_read(ctx.h, ctypes.byref(avg_ms), ctypes.byref(launches)), ctx.h)
+    nat.check(ctx.lib.havc_tag_timing_enable(ctx.h, tag, 0), ctx.h)
     st = ctx.stats()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total = args.steps * args.batch * world
+    if ddcolor_only:            # 27 tagged GEMMs per pass: tokens x 768 -> 3072 at 32 x 32 tokens per frame
+        per_pass, flops_frame, kname = 27, 2.0 * 32 * 32 * 768 * 3072, "conv_pipe_kernel (ConvNeXt-L stage 2 pwconv1 + GELU, 768 -> 3072 at 32x32 tokens per frame, 27 launches per pass)"
+    else:                       # 2 tagged convs per pass: 3x3 259 -> 259 at 384 x 384
+        per_pass, flops_frame, kname = 2, 2.0 * 384 * 384 * 259 * 259 * 9, "conv_pipe_kernel<2,4,8,1> (DeOldify video layers.10 res-block 3x3 259->259 @384x384, 2 launches per pass)"
+    fpl = args.steps * args.batch * per_pass / max(int(launches.value), 1)
+    achieved = flops_frame * fpl / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4),
+                "traffic": None, "kernel": kname, "launches_timed": int(launches.value), "frames_per_launch": round(fpl, 2),
+                "avg_launch_ms": round(avg_ms.value, 4), "flops_per_launch": flops_frame * fpl}
     gflop_frame = st.total_flops / max(st.frames / (1 if ddcolor_only else 2), 1) / 1e9 if st.frames else 0.0        # every model counts `frames`
     out = {"metric": "colorized frames/sec/GPU @1080p (DDColor large, input 512)" if ddcolor_only else
                      "colorized frames/sec/GPU @1080p (HAVC DeOldify+DDColor merge, combine_method=2)", "value": round(total / elapsed, 3),
@@ -388,7 +443,172 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
                       "ddcolor": "artistic, input %d (parity UNPINNED)" % (512 if ddcolor_only else 384),
                       "mweight": None if ddcolor_only else 0.4, "algorithmic_gflop_per_frame": round(gflop_frame, 2), "device_resident": True,
                       "parallelism": f"frame-sharded x{world}, weight replica per GPU, no collective"},
-           "whole_path_tflops": round(total * gflop_frame * 1e9 / elapsed / 1e12 / world, 2)}
+           "whole_path_tflops": round(total * gflop_frame * 1e9 / elapsed / 1e12 / world, 2), "roofline": roofline}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the same graph assembled from the oracle pieces on ONE 1080p frame of the clip: timed as the CPU baseline, compared with the GPU frame
+        from oracle import ddcolor as D, imaging, pipeline, resample
+        threads = min(os.cpu_count() or 1, args.cpu_threads)
+        torch.set_num_threads(threads)
+        got = keep[0].frame(0).numpy()
+        fr = frames[0]
+        t0 = time.time()
+        fs = 512 if ddcolor_only else 384
+        sq = resample.resize_rgb8(fr, fs, fs)
+        from oracle import tweaks
+        b_ = tweaks.adjust_hue_range(D.colorize_frame(synth_ddcolor_state_dict(1), sq, input_size=fs), HUE_ADJUST)    # vsmodels.py:365-366
+        c_ = b_ if ddcolor_only else pipeline.combine_models(pipeline.model_image_render({"video": synth_state_dict("wide", 1)}, "video", sq, 24, 0, True), b_, 2, 0.4)
+        ref = pipeline.post_process(resample.resize_rgb8(c_, WIDTH, HEIGHT), fr)
+        dt = time.time() - t0
+        de = imaging.delta_e00_images(got, ref)
+        d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+        out["cpu_baseline"] = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+                               "sample": f"1 frame of the 1080p clip through the oracle graph (fp32 torch models + numpy tail), {dt:.1f} s"}
+        out["parity"] = {"ciede2000_mean": round(float(de.mean()), 4), "ciede2000_p99": round(float(np.percentile(de, 99)), 4),
+                         "ciede2000_max": round(float(de.max()), 4), "pixels_with_dE_below_1": round(float((de < 1.0).mean()), 5),
+                         "bytes_within_2lsb": round(float((d <= 2).mean()), 5), "frames_checked": 1,
+                         "against": "oracle graph (CPU fp32); DDColor itself is parity-UNPINNED (external wheel, oracle/ddcolor.py)"}
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+HUE_ADJUST = "300:360|0.8,0.1"  # HAVC_colorizer's default ddtweak_p[1]: adjust_hue_range on every DDColor frame (vsslib/vsmodels.py:365-366)
+C5_H, C5_W = 216, 384          # HAVC_deepex render_speed 'medium' (deepex/__init__.py:58-62); a 16:9 clip needs no borders (vsresize.py:295-316)
+
+
+def c5_reference_image(gray_small):
+    """a colour exemplar for frame 0 (what HAVC_deepex gets from a colorizer or from the user): smooth hue fields over the frame's own luma"""
+    h, w, _ = gray_small.shape
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    l = gray_small[..., 0].astype(np.float32)
+    col = np.stack([l * 1.05 + 25 * np.sin(yy / 23.0), l * 0.92 + 18 * np.cos(xx / 31.0), l * 0.75 + 20 * np.sin((xx + yy) / 41.0) + 10], -1)
+    return np.clip(col, 0, 255).astype(np.uint8)
+
+
+def bench_c5(args, rank, local_rank, world, dist):
+    """BASELINE configs[4]: ColorMNet exemplar path, 1 reference frame, 1080p clip (HAVC_deepex(ex_model=0), __init__.py:1421-1735):
+    Spline64 1080p -> 384 x 216 (SmartResizeColorizer) -> ColorMNetRender.colorize_frame, frame after frame (the memory carries state:
+    strictly sequential) -> Spline64 back to 1080p + luma of the source (vs_recover_clip_luma).  The clip stays in HBM; the reference
+    image arrives with frame 0 (in the warm-up), the timed steps are steady-state frames incl. memory frames every 5th frame and the
+    long-term consolidation.  One step = --batch consecutive frames.  Sequential in time => replicas only across GPUs (one clip per GPU)."""
+    import torch
+    from vsdeoldify_amd import _native as nat
+    from vsdeoldify_amd.clip import synthetic_gray_frame
+    from vsdeoldify_amd.colormnet_net import ColorMNetNetwork
+    from vsdeoldify_amd.colormnet_render import ColorMNetRender
+    from vsdeoldify_amd.device import DeviceImage
+    from vsdeoldify_amd.synth import synth_colormnet_state_dict
+    sd = synth_colormnet_state_dict(1)
+    torch.cuda.set_device(local_rank)
+    net = ColorMNetNetwork(sd, device_index=local_rank)
+    ctx = net.ctx
+    n_clip = max(args.clip_frames, 8)
+    frames = np.stack([synthetic_gray_frame(rank * n_clip + i, WIDTH, HEIGHT) for i in range(n_clip)])
+    clip, dst = DeviceImage.from_numpy(ctx, frames), DeviceImage(ctx, frames.shape)
+    rnd = ColorMNetRender(image_size=-1, vid_length=10000, enable_resize=False, encode_mode=1, max_memory_frames=0, reset_on_ref_update=False, network=net)
+
+    def resize(src, sw, sh, out, dw, dh, luma=None):
+        nat.check(ctx.lib.havc_spline64_resize(ctx.h, src.ptr, sw, sh, out.ptr, dw, dh, luma.ptr if luma is not None else None), ctx.h)
+    small0 = DeviceImage(ctx, (C5_H, C5_W, 3))
+    resize(clip.frame(0), WIDTH, HEIGHT, small0, C5_W, C5_H)
+    ref_img = c5_reference_image(small0.numpy())
+    state = {"t": 0}
+
+    def one_frame():
+        t = state["t"]
+        src = clip.frame(t % n_clip)
+        small = DeviceImage(ctx, (C5_H, C5_W, 3))
+        resize(src, WIDTH, HEIGHT, small, C5_W, C5_H)
+        rnd.set_ref_frame(ref_img if t == 0 else None, False)
+        col = rnd.colorize_frame(t, small)
+        resize(col, C5_W, C5_H, dst.frame(t % n_clip), WIDTH, HEIGHT, luma=src)
+        state["t"] = t + 1
+
+    def step(_):
+        for _k in range(args.batch):
+            one_frame()
+
+    def sync_all():
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    for i in range(max(args.warmup, 1)):
+        step(i)
+    # the launch a frame spends most time in: the 3x3 conv 1536 -> 512 that maps the DINOv2 branch into the 1/8 Fuse block
+    plan_net = list(net.nets.values())[0]
+    tag_name = "key_encoder.fuse2.encode_enc"
+    op = plan_net.plan_ops[plan_net.names.index(tag_name)]
+    ctx.reset_stats()
+    nat.check(ctx.lib.havc_tag_timing_enable(ctx.h, int(op["tag"]), 1), ctx.h)
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    avg_ms, launches = ctypes.c_double(), ctypes.c_int64()
+    nat.check(ctx.lib.havc_tag_timing_read(ctx.h, ctypes.byref(avg_ms), ctypes.byref(launches)), ctx.h)
+    nat.check(ctx.lib.havc_tag_timing_enable(ctx.h, int(op["tag"]), 0), ctx.h)
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total = args.steps * args.batch * world
+    sl = plan_net.slices
+    gf = {k: sum(int(o["flops"]) for o in plan_net.plan_ops[v[0]:v[0] + v[1]]) * v[2] / 1e9 for k, v in sl.items()}
+    # per steady-state frame: key + skip + segment + hidden update + short-term tail every frame, value encoder (+ its hidden update) every 5th
+    gflop_frame = gf["key"] + gf["skip"] + gf["segment"] + gf["segment_hidden"] + gf["short"] + (gf["value"] + gf["value_hidden"]) / 5.0
+    flops_launch = float(op["flops"])
+    achieved = flops_launch / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
+    mem = rnd.processor.memory
+    out = {"metric": "colorized frames/sec/GPU @1080p (ColorMNet exemplar path, 1 reference frame)", "value": round(total / elapsed, 3),
+           "unit": "frames/s (sum over n_gpus)", "n_gpus": world, "value_per_gpu": round(total / elapsed / world, 3), "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f16", "data": "synthetic",
+           "config": {"workload": "ColorMNet exemplar path, 1 reference frame, 1080p clip (BASELINE.json configs[4])", "frames_per_step_per_gpu": args.batch,
+                      "network_input": f"{C5_W}x{C5_H} (HAVC_deepex render_speed 'medium'), padded to 448x224 inside the step",
+                      "weights": "seeded synthetic (ResNet50 + DINOv2 ViT-S/14 key encoder, ResNet18 value encoder, decoder; DINOv2 branch parity-UNPINNED)",
+                      "algorithmic_gflop_per_frame": round(gflop_frame, 2), "mem_every": 5, "device_resident": True,
+                      "working_memory_elements": int(mem.work_mem.size), "long_term_elements": int(mem.long_mem.size) if mem.long_mem.engaged() else 0,
+                      "parallelism": f"sequential in time: replicas only, one clip per GPU x{world}"},
+           "whole_path_tflops": round(total * gflop_frame * 1e9 / elapsed / 1e12 / world, 2),
+           "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4),
+                        "traffic": None, "kernel": f"conv_pipe_kernel ({tag_name}: 3x3 1536 -> 512 at 28x56, M = 1568 pixels, one frame per launch: "
+                        "the step is sequential in time, nothing to batch)", "launches_timed": int(launches.value), "frames_per_launch": 1,
+                        "avg_launch_ms": round(avg_ms.value, 4), "flops_per_launch": flops_launch}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU oracle over the first frames of the same clip (the exemplar arrives with frame 0): timed, and compared with the GPU's frames
+        from oracle import colormnet_clip, imaging, pipeline, resample
+        threads = min(os.cpu_count() or 1, args.cpu_threads)
+        torch.set_num_threads(threads)
+        K = 4
+        rnd2 = ColorMNetRender(image_size=-1, vid_length=10000, max_memory_frames=0, reset_on_ref_update=False, network=net)
+        gpu = []
+        for t in range(K):
+            small = DeviceImage(ctx, (C5_H, C5_W, 3))
+            resize(clip.frame(t), WIDTH, HEIGHT, small, C5_W, C5_H)
+            rnd2.set_ref_frame(ref_img if t == 0 else None, False)
+            col = rnd2.colorize_frame(t, small)
+            o = DeviceImage(ctx, (HEIGHT, WIDTH, 3))
+            resize(col, C5_W, C5_H, o, WIDTH, HEIGHT, luma=clip.frame(t))
+            gpu.append(o.numpy())
+        t0 = time.time()
+        smalls = [resample.resize_rgb8(frames[t], C5_W, C5_H) for t in range(K)]
+        cols = colormnet_clip.colorize_clip({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, smalls, {0: ref_img}, vid_length=10000)
+        refs = [pipeline.post_process(resample.resize_rgb8(c_, WIDTH, HEIGHT), frames[t]) for t, c_ in enumerate(cols)]
+        dt = time.time() - t0
+        des = [imaging.delta_e00_images(g_, r_) for g_, r_ in zip(gpu, refs)]
+        worst = int(np.argmax([float(np.percentile(d_, 99)) for d_ in des]))
+        de = np.concatenate([d_.reshape(-1) for d_ in des])
+        out["cpu_baseline"] = {"value": round(K / dt, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+                               "sample": f"the first {K} frames of the clip (exemplar with frame 0) through the oracle loop (fp32 torch network + numpy tail), {dt:.1f} s"}
+        out["parity"] = {"ciede2000_mean": round(float(de.mean()), 4), "ciede2000_p99": round(float(np.percentile(de, 99)), 4),
+                         "ciede2000_max": round(float(de.max()), 4), "pixels_with_dE_below_1": round(float((de < 1.0).mean()), 5),
+                         "frames_checked": K, "worst_frame": worst, "worst_frame_p99": round(float(np.percentile(des[worst], 99)), 4),
+                         "against": "oracle loop (CPU fp32), pinned to the reference's own ColorMNetRender; DINOv2 branch and skimage Lab parity-UNPINNED"}
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

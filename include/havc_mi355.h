@@ -37,6 +37,8 @@ extern "C" {
                               /*   (deoldify/filters.py:55-63 semantics)                                       */
 #define HAVC_E_HIP (-3)       /* any other HIP runtime failure            -> Python raises RuntimeError        */
 #define HAVC_E_NODEVICE (-4)  /* no gfx950 device visible                 -> Python raises RuntimeError        */
+#define HAVC_E_RANGE (-5)     /* range check on: an activation left the fp16 range (inf / NaN in a buffer)       */
+                              /*                                          -> Python raises HavcRangeError      */
 
 typedef struct havc_ctx havc_ctx;
 typedef struct havc_weights havc_weights;
@@ -218,6 +220,15 @@ void havc_net_free(havc_net* net);
  *                     d_out = device u8 RGB interleaved [batch][S][S][3] (raw colour, trunc(x*255),
  *                     i.e. BaseFilter._model_process output, deoldify/filters.py:45-68). */
 int havc_net_run_rgb8(havc_net* net, const uint8_t* d_in, uint8_t* d_out, int batch);
+/* The fp16 contract's debug switch.  The reference computes in fp32 end to end (deoldify/filters.py:45-68, fastai/basic_train.py:352-363);
+ * this library stores every activation in fp16 (fp32 accumulation).  With the range check ON (havc_range_check_enable, or HAVC_RANGE_CHECK=1
+ * in the environment when the ctx is created) the destination buffer of EVERY op is scanned after the op: the largest finite magnitude and
+ * the number of inf / NaN values are recorded per op, and a run that produced a non-finite value fails with HAVC_E_RANGE naming the first
+ * offending op instead of colouring a frame from garbage.  Enable it BEFORE creating the nets (their buffers are then zero-filled so that
+ * never-written padding cannot trip the scan).  Costs one small kernel + a synchronisation per op: a debug / validation mode for new
+ * checkpoints, not a production setting.  havc_net_range_stats returns the figures of the net's last run (n_ops entries each). */
+int havc_range_check_enable(havc_ctx* ctx, int enable);
+int havc_net_range_stats(havc_net* net, float* abs_max, int64_t* non_finite, int n_ops);
 /* Point activation buffer `buf` of the net at caller-owned device memory (>= batch * elems_per_frame * elem_bytes bytes; NULL restores the
  * net's own allocation).  The ColorMNet step hands its per-frame tensors (keys, values, hidden state, multi-scale features: the reference's
  * torch tensors, colormnet/inference/inference_core.py) to the plan and receives results this way, without a copy. */
@@ -340,7 +351,10 @@ int havc_image_tweak(havc_ctx* ctx, const uint8_t* img, uint8_t* out, int width,
  * [0,180]), S *= clamp(sat,0,10), V *= clamp(1+bright,0,10), back to RGB.  With has_adjust != 0 the parsed "hue_adjust" stage
  * follows: pixels whose tweaked hue lies strictly inside one of the n_ranges degree ranges take the colour re-tweaked by
  * (adj_sat, adj_hue), all others the ORIGINAL pixel; adj_weight > 0 merges towards the re-tweaked colour (adj_hue == 0) or the
- * original (adj_hue != 0), < 0 towards the original. */
+ * original (adj_hue != 0), < 0 towards the original.
+ * has_adjust == 2: the adjust stage ALONE, computed from the image itself = adjust_hue_range / adjust_chroma (vsslib/restcolor.py:221-286),
+ * what vs_sc_ddcolor applies to every DDColor frame through vs_sc_adjust_clip_hue (vsslib/vsmodels.py:365-366, vsfilters.py:435-455) with
+ * HAVC_colorizer's default ddtweak_p[1] = "300:360|0.8,0.1"; sat / bright / hue are ignored. */
 int havc_image_chroma_tweak(havc_ctx* ctx, const uint8_t* img, uint8_t* out, int width, int height, double sat, double bright, int hue,
                             int has_adjust, const double* hue_ranges, int n_ranges, double adj_sat, int adj_hue, double adj_weight);
 /* the per-pixel half of luma_adjusted_levels (vsslib/imfilters.py:335-372): cv2 RGB->YUV, Y' = lut[Y], YUV->RGB.  The caller

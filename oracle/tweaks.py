@@ -305,6 +305,35 @@ def np_image_chroma_tweak(img, sat=1, bright=0, hue=0, hue_adjust="none"):
     return restored
 
 
+def adjust_hue_range(img, hue_adjust="none"):
+    """restcolor.py:221-286 (adjust_hue_range -> adjust_chroma): like the adjust stage of np_image_chroma_tweak, but computed from the
+    image itself (no identity HSV round trip in front).  vs_sc_ddcolor applies it to EVERY DDColor frame when scene detection is off
+    (vsslib/vsmodels.py:365-366 with HAVC_colorizer's default ddtweak_p[1] = "300:360|0.8,0.1", vsfilters.py:435-455)."""
+    img = np.asarray(img)
+    if hue_adjust in ("none", ""):
+        return img
+    param = parse_hue_adjust(hue_adjust)
+    if param is None:
+        return img
+    hue_range, sat, hue, weight = param
+    if hue_range in ("none", ""):
+        return img
+    hsv = cvcolor.rgb2hsv_u8(img)
+    g = hsv.copy()
+    if hue != 0:
+        g[:, :, 0] = np_hue_add(g[:, :, 0], hue)
+    if sat != 1:
+        g[:, :, 1] = g[:, :, 1] * min(max(sat, 0), 10)
+    gray_rgb = cvcolor.hsv2rgb_u8(g)
+    cond = hue_conditions(hsv[:, :, 0], hue_range)
+    restored = np.where(cond[..., None], gray_rgb, img).astype(np.uint8)
+    if weight > 0:
+        restored = _wmerge(restored, gray_rgb if hue == 0 else img, weight)
+    if weight < 0:
+        restored = _wmerge(restored, img, -weight)
+    return restored
+
+
 def _luma_merge(img2, img1, lo, hi):
     from .pipeline import image_luma_merge
     return image_luma_merge(img2, img1, lo) if lo == hi else w_image_luma_merge(img2, img1, lo, hi)

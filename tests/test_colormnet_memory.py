@@ -75,3 +75,24 @@ def test_gpu_memory_manager_matches_the_executed_reference(long_term, device):
     if device == "cuda" and not torch.cuda.is_available():
         pytest.skip("torch sees no GPU")
     replay(long_term, backend=None, device=device, tol=1e-4)
+
+
+def test_a_failing_long_term_cleanup_is_swallowed_like_the_reference():
+    """memory_manager.py:183-193 wraps remove_obsolete_features + compress_features in try / except: pass.  Two ways to get there:
+    num_prototypes larger than the candidate range (torch.topk raises), and a long-term memory of EXACTLY max_size elements
+    (kv_memory_store.py:153-154: topk(k=0) then values[-1] -> IndexError): the frame's consolidation is skipped, the clip goes on."""
+    cfg = dict(CFG, enable_long_term=True, enable_long_term_count_usage=True, num_prototypes=10 ** 6)
+    m = MemoryManager(cfg, backend=OracleBackend())
+    for t in range(FRAMES):
+        f = {k: torch.from_numpy(GOLD[f"in_{k}_{t}"]) for k in ("key", "shrinkage", "selection", "value")}
+        if t > 0:
+            m.match_memory(f["key"], f["selection"])
+        m.add_memory(f["key"], f["shrinkage"], f["value"], [1, 2], selection=f["selection"])       # never raises
+    assert not m.long_mem.engaged() and m.work_mem.size == FRAMES * H * W                          # nothing was ever consolidated
+    from vsdeoldify_amd.colormnet_memory import KeyValueMemoryStore
+    s = KeyValueMemoryStore(count_usage=True)
+    s.add(torch.zeros(1, CK, 5), [torch.zeros(OBJ, CV, 5)], torch.ones(1, 1, 5), None, None)
+    with pytest.raises(IndexError):
+        s.remove_obsolete_features(5)
+    s.remove_obsolete_features(6)                                                                   # below max_size: nothing to do
+    assert s.size == 5

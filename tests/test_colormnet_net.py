@@ -130,37 +130,12 @@ def test_oracle_network_matches_the_executed_reference():
         check("short", short, stride_of("short"), 2e-4)
 
 
-def oracle_clip(sd, frames, refs, mem_every, backend, network=None, device="cpu"):
-    """the all-oracle frame loop: oracle network + the drop-in InferenceCore / MemoryManager on the oracle's memory functions"""
-    from vsdeoldify_amd.colormnet_render import default_config
-    from vsdeoldify_amd.colormnet_core import InferenceCore
-    net = network or O.Network(sd)
-    cfg = default_config(len(frames), 0)
-    cfg.update(mem_every=mem_every, key_dim=64, value_dim=512, hidden_dim=64)
-    proc = InferenceCore(net, cfg, memory_backend=backend)
-    outs = []
-    for t, fr in enumerate(frames):
-        rgb = np.stack([fr] * 3, -1)
-        lab = O.frame_to_lab_tensor(rgb)
-        lll = lab[:1].repeat(3, 1, 1).to(device)
-        ref = refs.get(t)
-        with torch.no_grad():
-            if ref is not None:
-                m = O.frame_to_lab_tensor(ref).to(device)
-                proc.set_all_labels([1, 2])
-                ab = proc.step_AnyExemplar(lll, m[:1].repeat(3, 1, 1), m[1:3], [1, 2], end=False)
-            else:
-                ab = proc.step_AnyExemplar(lll, None, None, None, end=False)
-        outs.append(O.lab_tensor_to_rgb(lll[:1].cpu(), ab.cpu()))
-    return np.stack(outs)
-
-
 def test_oracle_frame_loop_matches_the_reference_render_class():
     """the reference's own ColorMNetRender.colorize_frame over 9 frames (exemplars with frames 0 and 4) vs oracle network + drop-in
     InferenceCore / MemoryManager: u8 frames, identical up to float noise at the rounding boundary"""
-    from tests.test_colormnet_memory import OracleBackend
+    from oracle import colormnet_clip
     frames, refs, want = REN["frames"], REN["refs"], REN["outs"]
-    got = oracle_clip(tsd(), list(frames), {0: refs[0], 4: refs[1]}, int(REN["mem_every"]), OracleBackend())
+    got = np.stack(colormnet_clip.colorize_clip(tsd(), [np.stack([f] * 3, -1) for f in frames], {0: refs[0], 4: refs[1]}, {"mem_every": int(REN["mem_every"])}))
     d = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert got.shape == want.shape and d.max() <= 1 and (d > 0).mean() < 2e-3, (int(d.max()), float((d > 0).mean()))
 

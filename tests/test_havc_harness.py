@@ -28,7 +28,13 @@ def test_parameter_rules_follow_the_reference():
 def test_vapoursynth_only_features_are_refused_not_approximated():
     f = np.zeros((8, 8, 3), np.uint8)
     with pytest.raises(NotImplementedError):
-        havc.HAVC_colorizer(f, ddtweak=[True, False, False])
+        havc.HAVC_colorizer(f, ddtweak=[False, True, False])                       # rgb_denoise
+    with pytest.raises(NotImplementedError):
+        havc.HAVC_colorizer(f, ddtweak=[True, False, True])                        # vs_auto_levels (retinex)
+    with pytest.raises(NotImplementedError):
+        havc.HAVC_colorizer(f, ddtweak=[True, False, False], ddtweak_p=([10.0, 1.0, 2.5, True, 0.3, 0.6, 1.5, 0.5], "none"))   # bright through vs_tweak
+    with pytest.raises(NotImplementedError):
+        havc.HAVC_colorizer(f, ddtweak=[True, False, False], ddtweak_p=([0.0, 1.0, 2.5, False, 0.3, 0.6, 1.5, 0.5], "none"))   # gamma through vs_tweak
     with pytest.raises(NotImplementedError):
         havc.HAVC_colorizer(f, sc_threshold=0.1)
     with pytest.raises(havc.HAVCError):
@@ -73,6 +79,9 @@ def _frame(seed, h=120, w=200):
     return np.clip(r.normal(120, 55, (h, w, 1)), 0, 255).astype(np.uint8).repeat(3, -1)
 
 
+HUE_ADJ = "300:360|0.8,0.1"                     # HAVC_colorizer's default ddtweak_p[1] (__init__.py:2293)
+
+
 def _weights():
     from vsdeoldify_amd.synth import synth_ddcolor_state_dict, synth_state_dict
     return {"video": synth_state_dict("wide", 1)}, synth_ddcolor_state_dict(1, **SMALL_DD)
@@ -88,7 +97,7 @@ def test_gpu_frame_matches_oracle_graph(ctx, method):
     rf, w_merge = 10, 0.4
     frame = _frame(3)
     col = havc.HAVCFrameColorizer(method=method, mweight=w_merge, deoldify_p=(0, rf, 1.0, 0.0), ddcolor_p=(1, rf, 1.0, 0.0, True),
-                                  state_dicts=sds, ddcolor_state_dict=dsd, ddcolor_kwargs=SMALL_DD)
+                                  state_dicts=sds, ddcolor_state_dict=dsd, ddcolor_kwargs=SMALL_DD, ddtweak_p=(havc.DEF_TWEAK_p, HUE_ADJ))
     got = col.colorize(frame)
     assert got.shape == frame.shape and got.dtype == np.uint8
     fs = min(rf * 16, frame.shape[1])
@@ -98,15 +107,39 @@ def test_gpu_frame_matches_oracle_graph(ctx, method):
         c = pipeline.combine_models(a, b, method, w_merge)
         return pipeline.post_process(resample.resize_rgb8(c, frame.shape[1], frame.shape[0]), frame)
     # (2) integer stages, given the GPU's model outputs
+    from oracle import tweaks
     a_gpu = col._deoldify_render().render_square_batch(sq[None])[0] if method != 1 else None
-    b_gpu = col._ddcolor_clip(sq[None], (rf // 2) * 32)[0] if method != 0 else None
+    b_gpu = tweaks.adjust_hue_range(col._ddcolor_clip(sq[None], (rf // 2) * 32)[0], HUE_ADJ) if method != 0 else None
     d = np.abs(got.astype(int) - graph(a_gpu, b_gpu).astype(int))
     assert d.max() <= 1 and (d > 0).mean() < 2e-4, (method, int(d.max()), float((d > 0).mean()))      # Spline64 .5-boundary ties only
     # (1) all-oracle graph
     a = pipeline.model_image_render(sds, "video", sq, rf, 0, True) if method != 1 else None
-    b = D.colorize_frame(dsd, sq, input_size=(rf // 2) * 32, **SMALL_DD) if method != 0 else None
+    b = tweaks.adjust_hue_range(D.colorize_frame(dsd, sq, input_size=(rf // 2) * 32, **SMALL_DD), HUE_ADJ) if method != 0 else None
     de = imaging.delta_e00_images(got, graph(a, b))
     assert de.mean() < 0.6, (method, float(de.mean()))
+
+
+@pytest.mark.gpu
+def test_gpu_ddcolor_pre_tweak_matches_the_reference_flow(ctx):
+    """ddtweak = [True, False, False] with DEF_TWEAK_p and no scene detection (vsslib/vsmodels.py:333-344,373-374): luma_adjusted_levels on
+    every frame in front of DDColor, adjust_hue_range behind it, then the clip's luma back (vs_recover_clip_luma).  Integer stages
+    bit-exact given the GPU's own DDColor output of the tweaked frame."""
+    from oracle import pipeline, resample, tweaks
+    sds, dsd = _weights()
+    frame = (_frame(11).astype(np.float32) * 0.35).astype(np.uint8)                # dark: mean luma below luma_min = 0.3 -> the levels change
+    rf = 10
+    col = havc.HAVCFrameColorizer(method=1, ddcolor_p=(1, rf, 1.0, 0.0, True), ddcolor_state_dict=dsd, ddcolor_kwargs=SMALL_DD,
+                                  ddtweak=(True, False, False), ddtweak_p=(havc.DEF_TWEAK_p, HUE_ADJ))
+    got = col.colorize(frame)
+    fs = min(rf * 16, frame.shape[1])
+    sq = resample.resize_rgb8(frame, fs, fs)
+    pre = tweaks.luma_adjusted_levels(sq, 0.3, 2.5, 0.6, 1.5, 0.5)
+    assert np.abs(pre.astype(int) - sq.astype(int)).max() > 0
+    b = col._ddcolor_clip(pre[None], (rf // 2) * 32)[0]
+    b = pipeline.post_process(tweaks.adjust_hue_range(b, HUE_ADJ), sq)
+    want = pipeline.post_process(resample.resize_rgb8(b, frame.shape[1], frame.shape[0]), frame)
+    d = np.abs(got.astype(int) - want.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-4, (int(d.max()), float((d > 0).mean()))
 
 
 @pytest.mark.gpu
@@ -177,4 +210,4 @@ def test_legacy_entry_points_forward_like_the_reference(ctx):
     with pytest.warns(DeprecationWarning):
         assert np.array_equal(havc.ddeoldify(frame, cmc_tresh=0.2, **kw), want)
     with pytest.raises(NotImplementedError):
-        havc.HAVC_ddeoldify(frame, ddtweak=True, **kw)
+        havc.HAVC_ddeoldify(frame, ddtweak=True, ddtweak_p=([5.0, 1.0, 2.5, True, 0.3, 0.6, 1.5, 0.5], "none"), **kw)

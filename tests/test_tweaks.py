@@ -152,3 +152,28 @@ def test_gpu_chroma_tweak_and_stabilizer_frames(ctx):
     assert np.array_equal(stabilizer.dark_tweak_frame(G["base"], 0.3, 0.8, "none"), G["dark_tweak_0"])
     assert np.array_equal(stabilizer.dark_tweak_frame(G["base"], 0.45, 0.5, "280:360,0:30"), G["dark_tweak_1"])
     assert np.array_equal(stabilizer.colormap_frame(base, "blue|+40,0.2"), tweaks.colormap_frame(base, "blue|+40,0.2"))
+
+
+def test_oracle_adjust_hue_range_matches_the_executed_reference():
+    """oracle.tweaks.adjust_hue_range vs tests/golden/hue_adjust.npz (restcolor.adjust_hue_range executed by tools/gen_golden_hue_adjust.py)"""
+    import os
+    from oracle import tweaks
+    from tests.conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "hue_adjust.npz"))
+    for i, c in enumerate(g["cases"].tolist()):
+        assert np.array_equal(tweaks.adjust_hue_range(g["img"], c), g[f"out_{i}"]), c
+
+
+@pytest.mark.gpu
+def test_gpu_adjust_hue_range_is_bit_exact(ctx):
+    """havc_image_chroma_tweak(has_adjust = 2) = adjust_hue_range, frame and DeviceImage clip"""
+    import os
+    from tests.conftest import GOLDEN
+    from vsdeoldify_amd import imfilters as F
+    from vsdeoldify_amd.device import DeviceImage
+    g = np.load(os.path.join(GOLDEN, "hue_adjust.npz"))
+    for i, c in enumerate(g["cases"].tolist()):
+        assert np.array_equal(F.adjust_hue_range_np(ctx, g["img"], c), g[f"out_{i}"]), c
+    clip = DeviceImage.from_numpy(ctx, np.stack([g["img"], g["img"][::-1]]))
+    out = F.adjust_hue_range_np(ctx, clip, "300:360|0.8,0.1").numpy()
+    assert np.array_equal(out[0], g["out_0"]) and np.array_equal(out[1], g["out_0"][::-1])

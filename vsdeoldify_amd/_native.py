@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HAVC_MI355_LIB") or os.path.join(_HERE, "lib", "libhavc_mi355.so")   # override: A/B builds in tools/
 
-HAVC_OK, HAVC_E_INVALID, HAVC_E_OOM, HAVC_E_HIP, HAVC_E_NODEVICE = 0, -1, -2, -3, -4
+HAVC_OK, HAVC_E_INVALID, HAVC_E_OOM, HAVC_E_HIP, HAVC_E_NODEVICE, HAVC_E_RANGE = 0, -1, -2, -3, -4, -5
 
 # op types / flags (mirror include/havc_mi355.h)
 OP_CONV, OP_MAXPOOL, OP_BLUR_RESIZE, OP_AFFINE, OP_ATTENTION, OP_PREP_RGB8, OP_COPY_CH = 1, 2, 3, 4, 5, 6, 7
@@ -59,6 +59,10 @@ class HavcOutOfMemory(RuntimeError):
     """HAVC_E_OOM: the caller reproduces deoldify/filters.py:55-63 (return the input, warn)."""
 
 
+class HavcRangeError(RuntimeError):
+    """HAVC_E_RANGE: with the range check on, an activation left the fp16 range (inf / NaN in an activation buffer)."""
+
+
 _lib = None
 
 # every symbol include/havc_mi355.h declares: (name, restype, argtypes)
@@ -82,6 +86,8 @@ SYMBOLS = [
     ("havc_net_run_ops", _I, [_P, _I, _I, _I]),
     ("havc_net_enqueue_ops", _I, [_P, _I, _I, _I]),
     ("havc_net_bind", _I, [_P, _I, _P]),
+    ("havc_range_check_enable", _I, [_P, _I]),
+    ("havc_net_range_stats", _I, [_P, _P, _P, _I]),
     ("havc_get_stream", _P, [_P]),
     ("havc_colormnet_rgb_to_lab", _I, [_P, _P, _P, _I, _I]),
     ("havc_colormnet_lab_to_rgb", _I, [_P, _P, _P, _P, _I, _I]),
@@ -137,11 +143,30 @@ SYMBOLS = [
 ]
 
 
+def _preload_torch_hip_runtime():
+    """PyTorch-ROCm ships its own libamdhip64.so (same soname as /opt/rocm's).  Whichever is loaded first serves BOTH torch and this
+    library; torch does not find its GPU on the system runtime, so when torch is installed its copy is loaded first — without importing
+    torch.  The two then share one HIP runtime (what lets libhavc use torch tensors through their device pointers) whatever the import
+    order.  HAVC_NO_TORCH_HIP_PRELOAD=1 skips this."""
+    if os.environ.get("HAVC_NO_TORCH_HIP_PRELOAD"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(p):
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def load():
     """dlopen the HIP library (idempotent).  Raises NativeLibraryError when it is not built."""
     global _lib
     if _lib is not None:
         return _lib
+    _preload_torch_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise NativeLibraryError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -172,6 +197,8 @@ def check(rc, ctx=None):
         raise ValueError(f"havc: invalid argument: {msg}")
     if rc == HAVC_E_NODEVICE:
         raise NativeLibraryError(f"havc: {msg}")
+    if rc == HAVC_E_RANGE:
+        raise HavcRangeError(f"havc: {msg}")
     raise RuntimeError(f"havc: HIP failure ({rc}): {msg}")
 
 
@@ -190,6 +217,10 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            for lst in self.__dict__.get("_pool", {}).values():          # DeviceImage free list (device.py): raw hipMallocs, freed with the ctx
+                while lst:
+                    self.lib.havc_dev_free(self.h, lst.pop())
+            self.__dict__["_pool_bytes"] = 0
             self.lib.havc_destroy(self.h)
             self.h = None
 
@@ -209,6 +240,10 @@ class Context:
 
     def synchronize(self):
         check(self.lib.havc_synchronize(self.h), self.h)
+
+    def range_check(self, enable=True):
+        """the fp16 contract's debug switch (include/havc_mi355.h): enable BEFORE creating nets"""
+        check(self.lib.havc_range_check_enable(self.h, 1 if enable else 0), self.h)
 
     def stream_ptr(self):
         """the ctx's hipStream_t as an integer (torch.cuda.ExternalStream(ptr) puts torch's work on the same stream)"""
@@ -368,6 +403,12 @@ class Net:
         h = hashlib.sha1(ops.tobytes() + self.bufs.tobytes())
         h.update(f"{batch}|{self.ctx.device_name()}|{st.st_size}|{st.st_mtime_ns}".encode())
         return os.path.join(root, h.hexdigest() + ".i32")
+
+    def range_stats(self):
+        """(abs_max [n_ops], non_finite [n_ops]) of the destination buffers after the last range-checked run"""
+        a, b = np.zeros(len(self.ops), np.float32), np.zeros(len(self.ops), np.int64)
+        check(self.ctx.lib.havc_net_range_stats(self.h, as_ptr(a), as_ptr(b), len(self.ops)), self.ctx.h)
+        return a, b
 
     def cfgs(self):
         return [self.ctx.lib.havc_net_get_cfg(self.h, i) for i in range(len(self.ops))]

@@ -72,11 +72,14 @@ class ModelColorization:
         type(self)._initialized = False
 
     def colorize_frames(self, frames):
-        """uint8 [n,H,W,3] -> uint8 [n,H,W,3]."""
-        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        """uint8 [n,H,W,3] -> uint8 [n,H,W,3] (ndarray, or a device.DeviceImage: then nothing leaves HBM and the call only enqueues)."""
+        from .device import is_device, operand_ptr
+        dev = is_device(frames)
+        if not dev:
+            frames = np.ascontiguousarray(frames, dtype=np.uint8)
         n, h, w, _ = frames.shape
-        out = np.empty_like(frames)
-        nat.check(self.ctx.lib.havc_zhang_frames(self.ctx.h, self.net.h, nat.as_ptr(frames), nat.as_ptr(out), n, w, h), self.ctx.h)
+        out = frames.empty_like() if dev else np.empty_like(frames)
+        nat.check(self.ctx.lib.havc_zhang_frames(self.ctx.h, self.net.h, operand_ptr(frames), operand_ptr(out), n, w, h), self.ctx.h)
         return out
 
     def colorize_frame(self, frame_i=None):

@@ -124,8 +124,12 @@ class KeyValueMemoryStore:
 
     def remove_obsolete_features(self, max_size):
         import torch
-        if not self.count_usage or self.size < max_size or self.size == max_size:
+        if not self.count_usage or self.size < max_size:
             return
+        if self.size == max_size:
+            # kv_memory_store.py:153-154: torch.topk(usage, k=0) is empty and `values[-1]` raises IndexError; MemoryManager.add_memory swallows
+            # it (memory_manager.py:183-193) and with it THIS frame's consolidation.  Same observable behaviour here.
+            raise IndexError("index -1 is out of bounds for dimension 0 with size 0")
         usage = self.get_usage().flatten()
         lowest, _ = torch.topk(usage, k=self.size - max_size, largest=False, sorted=True)
         survived = usage > lowest[-1]
@@ -237,10 +241,14 @@ class MemoryManager:
         if selection is not None:
             selection = selection.flatten(start_dim=2)
         self.work_mem.add(key, value, shrinkage, selection, objects)
-        if self.enable_long_term and self.work_mem.size >= self.max_work_elements:
-            if self.long_mem.size >= (self.max_long_elements - self.num_prototypes):
-                self.long_mem.remove_obsolete_features(self.max_long_elements - self.num_prototypes)
-            self.compress_features()
+        if self.enable_long_term:
+            try:                                                   # memory_manager.py:183-193: a failing clean-up is swallowed, the clip goes on
+                if self.work_mem.size >= self.max_work_elements:
+                    if self.long_mem.size >= (self.max_long_elements - self.num_prototypes):
+                        self.long_mem.remove_obsolete_features(self.max_long_elements - self.num_prototypes)
+                    self.compress_features()
+            except Exception:
+                pass
 
     def create_hidden_state(self, n, sample_key):
         import torch

@@ -601,26 +601,34 @@ class ColorMNetNetwork:
 
     # ---- ColorMNetRender's frame transforms (colormnet_render.py:285-301, 276-279) ----
     def image_to_lab(self, rgb_u8):
-        """u8 [H, W, 3] (host) -> normalised Lab [3, H, W] fp32 on the device"""
+        """u8 [H, W, 3] (host array / PIL image, or a device.DeviceImage) -> normalised Lab [3, H, W] fp32 on the device"""
         import ctypes as C
-        import torch
-        a = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
-        if a.ndim != 3 or a.shape[2] != 3:
+        from .device import is_device
+        if is_device(rgb_u8):
+            shape, ptr, keep = rgb_u8.shape, rgb_u8.ptr, rgb_u8
+        else:
+            keep = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
+            shape, ptr = keep.shape, nat.as_ptr(keep)
+        if len(shape) != 3 or shape[2] != 3:
             raise ValueError("RGB image expected")
         with self.on_stream():
-            lab = self._new(3, a.shape[0], a.shape[1])
-            nat.check(self.ctx.lib.havc_colormnet_rgb_to_lab(self.ctx.h, nat.as_ptr(a), C.c_void_p(lab.data_ptr()), a.shape[1], a.shape[0]), self.ctx.h)
+            lab = self._new(3, shape[0], shape[1])
+            nat.check(self.ctx.lib.havc_colormnet_rgb_to_lab(self.ctx.h, ptr, C.c_void_p(lab.data_ptr()), shape[1], shape[0]), self.ctx.h)
         return lab
 
-    def lab_to_image(self, l_plane, ab):
-        """L [1, H, W] + ab [2, H, W] (device, normalised) -> u8 [H, W, 3] on the host (blocks until it is there)"""
+    def lab_to_image(self, l_plane, ab, out=None):
+        """L [1, H, W] + ab [2, H, W] (device, normalised) -> u8 [H, W, 3]: a host array (blocks until it is there), or `out` (a DeviceImage:
+        only enqueued)"""
         import ctypes as C
         import torch
         H, W = l_plane.shape[-2:]
-        out = np.empty((H, W, 3), np.uint8)
+        host = out is None
+        if host:
+            out = np.empty((H, W, 3), np.uint8)
         with self.on_stream():
             lp, abp = l_plane.to(self.device, torch.float32).contiguous(), ab.to(self.device, torch.float32).contiguous()
-            nat.check(self.ctx.lib.havc_colormnet_lab_to_rgb(self.ctx.h, C.c_void_p(lp.data_ptr()), C.c_void_p(abp.data_ptr()), nat.as_ptr(out), W, H), self.ctx.h)
+            nat.check(self.ctx.lib.havc_colormnet_lab_to_rgb(self.ctx.h, C.c_void_p(lp.data_ptr()), C.c_void_p(abp.data_ptr()),
+                                                             nat.as_ptr(out) if host else out.ptr, W, H), self.ctx.h)
         return out
 
     def close(self):

@@ -118,6 +118,7 @@ class ColorMNetRender:
 
     def _colorize_frame(self, ti, frame_i):
         from PIL import Image
+        from .device import DeviceImage, is_device
         self.total_colored_frames += 1
         reset_1 = self.frame_count >= self.max_memory_frames          # (the reference's other trigger is < 100 MB of free device memory)
         reset_2 = self.reset_on_ref_update and self.ref_img is not None and (self.ref_count - self.ref_count_prv >= 1)
@@ -129,9 +130,10 @@ class ColorMNetRender:
         else:
             ref = self.ref_img
             self.frame_count += 1
-        lab = self.network.image_to_lab(np.asarray(frame_i))           # [3,H,W] normalised Lab on the device (get_image :285-301)
+        as_lab = lambda im: self.network.image_to_lab(im if is_device(im) else np.asarray(im))
+        lab = as_lab(frame_i)                                           # [3,H,W] normalised Lab on the device (get_image :285-301)
         rgb = lab[:1].repeat(3, 1, 1)
-        msk = self.network.image_to_lab(np.asarray(ref)) if ref is not None else None
+        msk = as_lab(ref) if ref is not None else None
         if msk is not None and not self.config["FirstFrameIsNotExemplar"]:
             msk = msk[1:3]
         if not self.first_mask_loaded:
@@ -150,6 +152,9 @@ class ColorMNetRender:
                 prob = self.processor.step_AnyExemplar(rgb, msk[:1].repeat(3, 1, 1), msk[1:3], labels, end=is_last)
         else:
             prob = self.processor.step(rgb, msk, labels, end=is_last)
-        out = Image.fromarray(self.network.lab_to_image(lab[:1], prob))
+        if is_device(frame_i):                                          # a frame that lives in HBM stays there: nothing blocks
+            out = self.network.lab_to_image(lab[:1], prob, out=DeviceImage(frame_i.ctx, frame_i.shape))
+        else:
+            out = Image.fromarray(self.network.lab_to_image(lab[:1], prob))
         self.img = self.ref_img_valid = out                             # save_last_image (:303-305)
         return out

@@ -311,3 +311,33 @@ int launch_bilinear2(const float* x, float* y, int B, int Hi, int Wi, int Ho, in
                        Ho, Wo, (float)Hi / (float)Ho, (float)Wi / (float)Wo, mul);
     return (int)hipGetLastError();
 }
+
+
+// ---- HAVC_RANGE_CHECK: abs-max and non-finite count of an activation buffer (fp16 or fp32), debug switch of the fp16 contract ----
+// The reference computes in fp32 end to end (deoldify/filters.py:45-68); this path stores every activation in fp16.  An activation beyond
+// 65504 becomes inf in the conv epilogue and would colour a frame silently: with the switch on, every op's destination buffer is scanned
+// after the op and the call fails loudly, naming the op.  stats: [0] = bits of the largest finite |x| (as fp32), [2..3] = 64-bit count.
+template <typename T>
+__global__ void range_stats_kernel(const T* __restrict__ p, int64_t n, unsigned* __restrict__ stats) {
+    float mx = 0.f;
+    unsigned long long bad = 0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = fabsf((float)p[i]);
+        if (v <= 3.0e38f) mx = fmaxf(mx, v); else ++bad;           // NaN fails the comparison too
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); bad += __shfl_xor(bad, o); }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(stats, __float_as_uint(mx));
+        if (bad) atomicAdd(reinterpret_cast<unsigned long long*>(stats + 2), bad);
+    }
+}
+
+int launch_range_stats(const void* p, int elem_bytes, int64_t n, unsigned* stats, hipStream_t s) {
+    int64_t b = (n + 2047) / 2048;
+    const int g = (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
+    if (elem_bytes == 2) hipLaunchKernelGGL(range_stats_kernel<half_t>, dim3(g), dim3(256), 0, s, (const half_t*)p, n, stats);
+    else if (elem_bytes == 4) hipLaunchKernelGGL(range_stats_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)p, n, stats);
+    else return 0;
+    return (int)hipGetLastError();
+}

@@ -35,6 +35,7 @@ struct havc_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_main_done = nullptr;
     hipStream_t cur = nullptr;            // stream the plan executor launches on (stream or stream2)
     bool two_streams = true;              // HAVC_TWO_STREAMS=0 serialises the two generators (A/B measurements)
+    bool range_check = false;             // HAVC_RANGE_CHECK / havc_range_check_enable: scan every op's destination for inf / NaN / abs-max
     uint64_t nt_store_bytes = 0;          // conv outputs at least this large are written with non-temporal stores (0 = never); HAVC_NT_STORE_MB
     uint64_t desc_limit = 0xE0000000ull;  // bytes one conv launch may address per operand (32-bit buffer descriptors);
                                           // HAVC_DESC_LIMIT_BYTES lowers it so tests reach the frame-chunking path at small sizes
@@ -74,6 +75,10 @@ struct havc_net {
     std::vector<int64_t> ktab_off;        // per op: element offset into d_ktab, -1 for non-conv ops
     const void* in_override = nullptr;
     void* out_override = nullptr;
+    unsigned* d_range = nullptr;          // range check: per op {abs-max bits, -, non-finite count (64 bit)}
+    bool range_ready = false;             // buffers were zero-filled at creation (never-written padding cannot trip the scan)
+    std::vector<float> range_absmax;
+    std::vector<int64_t> range_bad;
     std::vector<void*> bound;             // havc_net_bind: caller-owned device memory standing in for a buffer (nullptr = own allocation)
     double flops_per_frame = 0;
 };
@@ -584,9 +589,44 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
 int run_ops_locked(havc_net* n, int first, int count, int batch) {
     if (batch < 1 || batch > n->max_batch) return fail(n->ctx, HAVC_E_INVALID, "batch out of range");
     if (first < 0 || count < 0 || first + count > (int)n->ops.size()) return fail(n->ctx, HAVC_E_INVALID, "op range");
+    havc_ctx* c = n->ctx;
+    const bool check = c->range_check;
+    if (check && !n->range_ready) return fail(c, HAVC_E_INVALID, "range check: enable it before the net is created (its buffers must start zero-filled)");
+    hipStream_t s = c->cur ? c->cur : c->stream;
     for (int i = first; i < first + count; ++i) {
         int rc = run_op(n, n->ops[i], batch);
         if (rc) return rc;
+        if (check) {
+            const havc_op& op = n->ops[i];
+            const havc_buf& bd = n->bufdesc[op.dst];
+            int e = launch_range_stats(bufptr(n, op.dst), bd.elem_bytes, (int64_t)batch * bd.elems_per_frame, n->d_range + 4 * (size_t)i, s);
+            if (e) return hip_fail(c, (hipError_t)e, "range-check kernel");
+        }
+    }
+    if (check) {
+        std::vector<unsigned> host((size_t)n->ops.size() * 4);
+        HIP_TRY(c, hipStreamSynchronize(s));
+        HIP_TRY(c, hipMemcpy(host.data(), n->d_range, host.size() * 4, hipMemcpyDeviceToHost));
+        HIP_TRY(c, hipMemset(n->d_range, 0, host.size() * 4));
+        n->range_absmax.assign(n->ops.size(), 0.f);
+        n->range_bad.assign(n->ops.size(), 0);
+        int first_bad = -1;
+        for (size_t i = 0; i < n->ops.size(); ++i) {
+            float f;
+            memcpy(&f, &host[4 * i], 4);
+            unsigned long long b;
+            memcpy(&b, &host[4 * i + 2], 8);
+            n->range_absmax[i] = f;
+            n->range_bad[i] = (int64_t)b;
+            if (b && first_bad < 0) first_bad = (int)i;
+        }
+        if (first_bad >= 0) {
+            char msg[256];
+            snprintf(msg, sizeof msg, "range check: op %d (type %d, tag %d) left %lld non-finite values in buffer %d -- an activation exceeded the fp16 range "
+                     "(65504); largest finite magnitude there %.4g", first_bad, n->ops[first_bad].type, n->ops[first_bad].tag, (long long)n->range_bad[first_bad],
+                     n->ops[first_bad].dst, (double)n->range_absmax[first_bad]);
+            return fail(c, HAVC_E_RANGE, msg);
+        }
     }
     return HAVC_OK;
 }
@@ -717,6 +757,7 @@ int havc_create(havc_ctx** out, int device_id) {
     c->dev = device_id;
     if (const char* e = getenv("HAVC_TWO_STREAMS")) c->two_streams = atoi(e) != 0;
     if (const char* e = getenv("HAVC_NT_STORE_MB")) c->nt_store_bytes = strtoull(e, nullptr, 0) << 20;
+    if (const char* e = getenv("HAVC_RANGE_CHECK")) c->range_check = atoi(e) != 0;
     if (const char* e = getenv("HAVC_DESC_LIMIT_BYTES")) {
         const unsigned long long v = strtoull(e, nullptr, 0);
         if (v >= 4096 && v <= 0xE0000000ull) c->desc_limit = v;
@@ -893,7 +934,7 @@ int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops,
         // +256 B tail so a predicated-off 16-byte vector address is never formed past the allocation
         size_t nb = (size_t)bufs[i].elems_per_frame * bufs[i].elem_bytes * max_batch + 256;
         hipError_t e = hipMalloc(&n->bufs[i], nb);
-        if (e == hipSuccess && bufs[i].zero_init) e = hipMemset(n->bufs[i], 0, nb);
+        if (e == hipSuccess && (bufs[i].zero_init || c->range_check)) e = hipMemset(n->bufs[i], 0, nb);
         if (e != hipSuccess) {
             for (int k = 0; k <= i; ++k) {
                 if (!n->bufs[k]) continue;
@@ -909,6 +950,11 @@ int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops,
         }
         c->stats.bytes_resident += (int64_t)nb;
     }
+    if (c->range_check) {
+        if (hipMalloc((void**)&n->d_range, (size_t)n_ops * 16) != hipSuccess || hipMemset(n->d_range, 0, (size_t)n_ops * 16) != hipSuccess)
+            return fail(c, HAVC_E_HIP, "range-check buffer allocation");
+        n->range_ready = true;
+    }
     *out = n;
     return HAVC_OK;
 }
@@ -923,6 +969,7 @@ void havc_net_free(havc_net* n) {
         for (const havc_op& o : n->ops) if (o.type == HAVC_OP_CONV) chunks += (size_t)o.Kc;
         n->ctx->stats.bytes_resident -= (int64_t)(chunks * sizeof(int2));
     }
+    if (n->d_range) (void)hipFree(n->d_range);
     for (size_t i = 0; i < n->bufs.size(); ++i) {
         if (n->bufs[i]) (void)hipFree(n->bufs[i]);
         n->ctx->stats.bytes_resident -= (int64_t)((size_t)n->bufdesc[i].elems_per_frame * n->bufdesc[i].elem_bytes * n->max_batch + 256);
@@ -961,6 +1008,21 @@ int havc_net_download(havc_net* n, int buf, void* host, size_t nbytes) {
     HIP_TRY(c, hipSetDevice(c->dev));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(host, n->bufs[buf], nbytes, hipMemcpyDeviceToHost));
+    return HAVC_OK;
+}
+
+int havc_range_check_enable(havc_ctx* c, int enable) {
+    if (!c) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->range_check = enable != 0;
+    return HAVC_OK;
+}
+
+int havc_net_range_stats(havc_net* n, float* abs_max, int64_t* non_finite, int n_ops) {
+    if (!n || !abs_max || !non_finite || n_ops != (int)n->ops.size()) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(n->ctx->mu);
+    if (n->range_absmax.size() != n->ops.size()) return fail(n->ctx, HAVC_E_INVALID, "range stats: no checked run of this net yet");
+    for (int i = 0; i < n_ops; ++i) { abs_max[i] = n->range_absmax[i]; non_finite[i] = n->range_bad[i]; }
     return HAVC_OK;
 }
 
@@ -1556,7 +1618,8 @@ int havc_image_chroma_tweak(havc_ctx* c, const uint8_t* img, uint8_t* out, int w
     ChromaTweakArgs a{};
     a.has_hue = hue != 0; a.hue_half = 0.5 * (double)std::min(std::max(hue, -360), 360);
     a.satc = clampd(sat, 0.0, 10.0); a.brightc = clampd(1.0 + bright, 0.0, 10.0);
-    a.has_adjust = has_adjust != 0; a.n_ranges = has_adjust ? n_ranges : 0;
+    a.has_adjust = has_adjust == 2 ? 2 : (has_adjust != 0); a.n_ranges = has_adjust ? n_ranges : 0;
+    if (has_adjust == 2) { a.has_hue = 0; a.satc = 1.0; a.brightc = 1.0; }
     for (int k = 0; k < a.n_ranges; ++k) { a.range_lo[k] = hue_ranges[2 * k]; a.range_hi[k] = hue_ranges[2 * k + 1]; }
     a.has_hue2 = adj_hue != 0; a.hue_half2 = 0.5 * (double)std::min(std::max(adj_hue, -360), 360);
     a.has_sat2 = adj_sat != 1.0; a.sat2c = clampd(adj_sat, 0.0, 10.0);

@@ -151,6 +151,8 @@ int launch_local_correlation(const float* q, const float* k, float* out, int n, 
 int launch_local_softmax(float* qk, const float* q, const float* rel_w, const float* rel_b, int n, int C, int H, int W, int R, int dil, hipStream_t s);
 int launch_local_agg(const float* attn, const float* v, float* agg, int n, int CV, int H, int W, int R, int dil, hipStream_t s);
 
+int launch_range_stats(const void* p, int elem_bytes, int64_t n, unsigned* stats, hipStream_t s);
+
 // ---- ColorMNet network kernels (colormnet_net.hip) ----
 #ifndef HAVC_EW_SRC_BCAST          // (public values: include/havc_mi355.h)
 #define HAVC_EW_SRC_BCAST 1

@@ -255,7 +255,8 @@ __global__ void chroma_tweak_kernel(const uint8_t* __restrict__ img, uint8_t* __
         s = (int)(uint8_t)(long long)((double)s * a.satc);
         v = (int)(uint8_t)(long long)((double)v * a.brightc);
         int r, g, b;
-        cv_hsv2rgb(h, s, v, r, g, b);
+        if (a.has_adjust == 2) { r = r0; g = g0; b = b0; }      // adjust_chroma (restcolor.py:243-286): no tweak stage, no HSV round trip in front
+        else cv_hsv2rgb(h, s, v, r, g, b);
         if (a.has_adjust) {
             int hg, sg, vg;
             cv_rgb2hsv(r, g, b, hg, sg, vg);

@@ -22,6 +22,7 @@ from . import _native as nat
 from .plan import PlanBuilder, View, WeightPack, bn_scale_shift, conv_weight, pack_conv, pad_to, pitch_for, to_np
 
 DEPTHS, DIMS = (3, 3, 27, 3), (192, 384, 768, 1536)
+TAG_STAGE2_PW1 = 2             # the 27 pwconv1 GEMMs (768 -> 3072 + GELU) of ConvNeXt stage 2: the launches a DDColor pass spends most time in
 HIDDEN, HEADS, QUERIES, TOK = 256, 8, 100, 112            # TOK: tokens per frame incl. 12 pad rows (= Npad of the einsum conv)
 MEAN = np.array([0.485, 0.456, 0.406], np.float32)
 STD = np.array([0.229, 0.224, 0.225], np.float32)
@@ -118,7 +119,7 @@ class DDColorGenerator:
                     b.dwconv7(p + ".dwconv", x, dbuf, wdw, bdw, x.span)
                     self._ln(b, p + ".norm", p + ".norm", dbuf, nbuf, 1e-6)
                 pc1 = self._lin(p + ".pwconv1", nbuf, sd[p + ".pwconv1.weight"], bias=sd[p + ".pwconv1.bias"])
-                b.conv(p + ".pwconv1", pc1, nbuf, hbuf, flags=nat.F_GELU)
+                b.conv(p + ".pwconv1", pc1, nbuf, hbuf, flags=nat.F_GELU, tag=TAG_STAGE2_PW1 if i == 2 else None)
                 pc2 = self._lin(p + ".pwconv2", hbuf, sd[p + ".pwconv2.weight"], bias=sd[p + ".pwconv2.bias"],
                                 scale=sd[p + ".gamma"].astype(np.float32), shift=np.zeros(c, np.float32))
                 b.conv(p + ".pwconv2", pc2, hbuf, alt, flags=nat.F_AFFINE | nat.F_RESIDUAL, res=x)

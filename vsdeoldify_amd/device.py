@@ -16,22 +16,40 @@ import numpy as np
 
 from . import _native as nat
 
-_pools = {}          # id(ctx) -> {nbytes: [ptr, ...]}
+import os
+
+POOL_MAX_BYTES = int(os.environ.get("HAVC_POOL_MAX_MB", "8192")) << 20     # cached (idle) buffers per context; beyond it a release frees
 
 
 def _pool(ctx):
-    return _pools.setdefault(id(ctx), {})
+    """the free list lives ON the context object: it dies with it (Context.close frees every cached buffer before havc_destroy) and can
+    never be inherited by another context that happens to get the same id()"""
+    p = ctx.__dict__.get("_pool")
+    if p is None:
+        p = ctx.__dict__["_pool"] = {}
+        ctx.__dict__["_pool_bytes"] = 0
+    return p
 
 
 def pool_alloc(ctx, nbytes):
     free = _pool(ctx).get(nbytes)
     if free:
+        ctx._pool_bytes -= nbytes
         return free.pop()
-    return ctx.dev_alloc(nbytes)
+    try:
+        return ctx.dev_alloc(nbytes)
+    except nat.HavcOutOfMemory:
+        pool_trim(ctx)                            # idle buffers of other sizes may be what is in the way: give them back and retry once
+        return ctx.dev_alloc(nbytes)
 
 
 def pool_release(ctx, ptr, nbytes):
-    _pool(ctx).setdefault(nbytes, []).append(ptr)
+    pool = _pool(ctx)
+    if ctx._pool_bytes + nbytes > POOL_MAX_BYTES:
+        ctx.dev_free(ptr)
+        return
+    pool.setdefault(nbytes, []).append(ptr)
+    ctx._pool_bytes += nbytes
 
 
 def pool_trim(ctx):
@@ -39,6 +57,7 @@ def pool_trim(ctx):
     for lst in _pool(ctx).values():
         while lst:
             ctx.dev_free(lst.pop())
+    ctx._pool_bytes = 0
 
 
 class DeviceImage:

@@ -9,8 +9,10 @@ Same names, argument lists, defaults, parameter normalisation, frame-size rule, 
 behind `HAVC_colorizer` (models and nets are built once and reused between calls).
 
 What only VapourSynth can do stays there and is REFUSED here instead of being approximated: `vs_tweak` (deoldify / ddcolor
-sat / hue other than 1 / 0, `luma_mask_sat` < 1), scene detection (`sc_threshold` > 0, `sc_min_freq` > 0), the DDColor
-pre-tweaks (`ddtweak`), non-RGB24 formats.  zimg's Spline64 is replaced by the library's own Spline64 (outside the parity
+sat / hue other than 1 / 0, `luma_mask_sat` < 1), scene detection (`sc_threshold` > 0, `sc_min_freq` > 0), the parts of the DDColor
+pre-tweaks that are VapourSynth filters (`ddtweak`: bright / cont / gamma through vs_tweak, rgb_denoise, retinex), non-RGB24 formats.
+Computed here: the hue adjustment vs_sc_ddcolor applies to every DDColor frame (default "300:360|0.8,0.1") and the luma-constrained
+pre-tweak with its luma recovery (HAVCFrameColorizer._read_ddtweak).  zimg's Spline64 is replaced by the library's own Spline64 (outside the parity
 contract).
 
     out = HAVC_colorizer(clip, method=2, mweight=0.4, torch_dir=..., ...)          # clip: uint8 [n, 1080, 1920, 3]
@@ -30,7 +32,7 @@ DEF_CMC_p = [0.15, True, 20, 24]            # vsslib/constants.py:19-22
 DEF_LMM_p = [0.15, 0.65, 1.0]
 DEF_ALM_p = [0.8, 1.0, 0.15]
 DEF_CRT_p = [0.8, 30, 2, False, 0, 0]
-DEF_TWEAK_p = [0.0, 0.9, 0.7, False, 0.3, 0.6, 1.5, 0.5]
+DEF_TWEAK_p = [0.0, 1.0, 2.5, True, 0.3, 0.6, 1.5, 0.5]     # vsslib/constants.py:23
 DEF_THT_WHITE, DEF_THT_BLACK = 0.88, 0.12
 DEF_STABLE_WEIGHT = DEF_ARTISTIC_WEIGHT = 0.5  # vsslib/constants.py:56-57
 
@@ -57,7 +59,7 @@ class HAVCFrameColorizer:
     def __init__(self, method=2, mweight=0.4, deoldify_p=(0, 24, 1.0, 0.0), ddcolor_p=(1, 24, 1.0, 0.0, True), cmc_p=DEF_CMC_p,
                  lmm_p=DEF_LMM_p, alm_p=DEF_ALM_p, crt_p=DEF_CRT_p, cmb_sw=False, device_index=0, package_dir=None,
                  ddcolor_model_dir=None, state_dicts=None, ddcolor_state_dict=None, zhang_state_dict=None, max_batch=1,
-                 ddcolor_kwargs=None):
+                 ddcolor_kwargs=None, ddtweak=(False, False, False), ddtweak_p=(DEF_TWEAK_p, "none")):
         # ---- __init__.py:2452-2462: method <-> merge weight normalisation ----
         merge_weight = 0.0 if method == 0 else (1.0 if method == 1 else mweight)
         if merge_weight == 0.0:
@@ -67,6 +69,7 @@ class HAVCFrameColorizer:
         if method not in range(0, 8):
             raise HAVCError("HAVC: only dd_method in (0,6) is supported")                        # mcomb.py:192
         self.method, self.merge_weight, self.cmb_sw = method, merge_weight, cmb_sw
+        self._read_ddtweak(ddtweak, ddtweak_p)                   # refuses what only VapourSynth can do before anything touches the GPU
         self.deoldify_model, self.deoldify_rf, d_sat, d_hue = deoldify_p[:4]
         self.ddcolor_model, self.ddcolor_rf, c_sat, c_hue = ddcolor_p[:4]
         if device_index > 7:
@@ -85,6 +88,55 @@ class HAVCFrameColorizer:
         self._dd_kwargs = dict(ddcolor_kwargs or {})
         self._deoldify = self._ddcolor = self._zhang = None
         self._dd_size = None
+
+    def _read_ddtweak(self, flags, tweaks):
+        """vs_sc_ddcolor's tweak handling WITHOUT scene detection (vsslib/vsmodels.py:304-344,365-374; scenechange = False because
+        sc_threshold = sc_min_freq = 0, __init__.py:2496): what can be computed without VapourSynth is computed, the rest is refused.
+          * hue_adjust (ddtweak_p[1], HAVC_colorizer's default "300:360|0.8,0.1"): adjust_hue_range on EVERY DDColor frame — applied;
+          * tweaks_enabled with luma_constrained_tweak and neutral bright / cont (the DEF_TWEAK_p defaults): luma_adjusted_levels on every
+            frame in front of DDColor, the source's luma put back behind it (vs_recover_clip_luma) — applied;
+          * bright / cont / gamma through vs_tweak (std.Expr / std.Levels), rgb_denoise, vs_auto_levels (retinex): VapourSynth filters — refused."""
+        flags = list(flags) if isinstance(flags, (list, tuple)) else [flags, False, False]
+        self.dd_tweaks_enabled, denoise, retinex = (bool(f) for f in (flags + [False, False])[:3])
+        if len(tweaks) == 2:
+            t, hue_adjust = list(tweaks[0]), str(tweaks[1]).lower()
+        else:
+            t, hue_adjust = list(tweaks[:8]), (tweaks[8] if len(tweaks) > 8 else "none")
+        self.dd_hue_adjust = hue_adjust
+        self.dd_levels = None
+        if denoise:
+            raise NotImplementedError("ddtweak[1] (rgb_denoise) is a VapourSynth filter chain: not in this harness")
+        if self.dd_tweaks_enabled:
+            bright, cont, gamma, constrained, luma_min, gamma_luma_min, gamma_alpha, gamma_min = t[:8]
+            if retinex:
+                raise NotImplementedError("ddtweak[2] (vs_auto_levels / retinex) is a VapourSynth filter chain: not in this harness")
+            if not constrained or bright != 0 or cont != 1:
+                raise NotImplementedError("without scene detection vs_sc_tweak is vs_tweak (std.Expr / std.Levels): only the luma-constrained tweak "
+                                          "with neutral bright / cont (the defaults) is computed here")
+            self.dd_levels = (luma_min, gamma, gamma_luma_min, gamma_alpha, gamma_min)
+
+    def _ddcolor_branch(self, sq, input_size):
+        """vs_sc_ddcolor (vsmodels.py:290-375) on the squashed clip: [pre-tweak ->] DDColor / Zhang [-> hue adjust] [-> luma of the clip back]"""
+        src = sq
+        if self.dd_levels is not None:                                # sc_constrained_tweak(scenechange=False): luma_adjusted_levels per frame
+            frames = [F.luma_adjusted_levels_np(self.ctx, sq.frame(i) if is_device(sq) else sq[i], *self.dd_levels) for i in range(sq.shape[0])]
+            if is_device(sq):
+                src = DeviceImage(self.ctx, sq.shape)
+                for i, f in enumerate(frames):
+                    src.frame(i).copy_from(f)
+            else:
+                src = np.stack(frames)
+        b = self._ddcolor_clip(src, input_size)
+        if self.dd_hue_adjust not in ("none", ""):
+            b = F.adjust_hue_range_np(self.ctx, b if is_device(b) else b.reshape((-1,) + b.shape[2:]), self.dd_hue_adjust)
+            if not is_device(b):
+                b = b.reshape(sq.shape)
+        if self.dd_tweaks_enabled:
+            b = F.chroma_post_process_np(self.ctx, b if is_device(b) else b.reshape((-1,) + b.shape[2:]),
+                                         sq if is_device(sq) else sq.reshape((-1,) + sq.shape[2:]))
+            if not is_device(b):
+                b = b.reshape(sq.shape)
+        return b
 
     # ---- model routing: vsslib/vsmodels.py:196-213 (deoldify), :290-350 (ddcolor / zhang) ----
     def _deoldify_render(self):
@@ -107,9 +159,7 @@ class HAVCFrameColorizer:
         from .colorization import ModelColorization                                               # vsmodels.py:346-350
         if self._zhang is None:
             self._zhang = ModelColorization("siggraph17" if self.ddcolor_model == 2 else "eccv16", True, self.device_index, state_dict=self._zh_sd)
-        host = sq.numpy() if is_device(sq) else sq
-        out = np.stack([self._zhang.colorize_frame(f) for f in host])
-        return DeviceImage.from_numpy(self.ctx, out) if is_device(sq) else out
+        return self._zhang.colorize_frames(sq)                                                    # host or device clip: havc_zhang_frames takes both
 
     def _deoldify_clip(self, sq):
         """ModelImageRender over a clip.  Frames at the model's render size (the usual case: frame_size is derived from the larger
@@ -150,7 +200,7 @@ class HAVCFrameColorizer:
         if self.method != 1:
             a = self._deoldify_clip(sq)
         if self.method != 0:
-            b = self._ddcolor_clip(sq, math.trunc(dd_rf / 2) * 32)                               # vsmodels.py:302
+            b = self._ddcolor_branch(sq, math.trunc(dd_rf / 2) * 32)                             # vsmodels.py:302
         col = self._combine(a, b)
         out = self._spline64(col, w, h, luma_from=dclip)
         if host_in:
@@ -240,9 +290,6 @@ _colorizers = {}
 
 
 def _refuse_vs_only(ddtweak, sc_threshold, sc_min_freq):
-    flags = list(ddtweak) if isinstance(ddtweak, (list, tuple)) else [ddtweak]
-    if any(bool(f) for f in flags):
-        raise NotImplementedError("ddtweak (vs_sc_tweak / vs_auto_levels pre-tweaks, denoise) is VapourSynth glue: not in this harness")
     if sc_threshold and sc_threshold > 0 or sc_min_freq and sc_min_freq > 0:
         raise NotImplementedError("scene detection (sc_threshold / sc_min_freq) is VapourSynth glue (SCDetect): not in this harness")
 
@@ -257,12 +304,13 @@ def HAVC_colorizer(clip, method=2, mweight=0.4, deoldify_p=(0, 24, 1.0, 0.0), dd
         raise HAVCError("HAVC_colorizer: this is not a clip")                                     # __init__.py:2437-2438
     _refuse_vs_only(ddtweak, sc_threshold, sc_min_freq)
     cmc = list(cmc_p) if isinstance(cmc_p, (list, tuple)) else [cmc_p]
+    flags = tuple(ddtweak) if isinstance(ddtweak, (list, tuple)) else (ddtweak, False, False)
     key = (method, mweight, tuple(deoldify_p), tuple(ddcolor_p), tuple(cmc), tuple(lmm_p), tuple(alm_p), tuple(crt_p), cmb_sw, device_index,
-           torch_dir, id(harness.get("state_dicts")), id(harness.get("ddcolor_state_dict")), harness.get("max_batch", 1))
+           torch_dir, id(harness.get("state_dicts")), id(harness.get("ddcolor_state_dict")), harness.get("max_batch", 1), flags, repr(ddtweak_p))
     col = _colorizers.get(key)
     if col is None:
         col = HAVCFrameColorizer(method, mweight, deoldify_p, ddcolor_p, cmc, lmm_p, alm_p, crt_p, cmb_sw, device_index, package_dir=torch_dir,
-                                 **harness)
+                                 ddtweak=flags, ddtweak_p=ddtweak_p, **harness)
         _colorizers.clear()                     # one live graph at a time: the nets hold GBs of activations
         _colorizers[key] = col
     return col.colorize_clip(clip)

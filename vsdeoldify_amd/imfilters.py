@@ -316,6 +316,31 @@ def image_chroma_tweak_np(ctx, img, sat=1, bright=0, hue=0, hue_adjust="none"):
     return out
 
 
+def adjust_hue_range_np(ctx, img, hue_adjust="none"):
+    """adjust_hue_range (vsslib/restcolor.py:221-286) on a u8 frame / clip (ndarray or DeviceImage): the per-frame body of
+    vs_sc_adjust_clip_hue (vsfilters.py:435-455)."""
+    import ctypes as C
+    if hue_adjust in ("none", ""):
+        return img
+    param = parse_hue_adjust(hue_adjust)
+    if param is None or param[0] in ("none", ""):
+        return img
+    a, out = _one(ctx, img)
+    rng = parse_hue_ranges(param[0])
+    arr = (C.c_double * max(len(rng), 1))(*rng)
+    nat.check(ctx.lib.havc_image_chroma_tweak(ctx.h, _p(a), _p(out), *_wh(a), 1.0, 0.0, 0, 2, arr, len(rng) // 2, float(param[1]), int(param[2]),
+                                              float(param[3])), ctx.h)
+    return out
+
+
+def adjust_hue_range(img, hue_adjust="none", device_index=0):
+    """restcolor.py:221-233 (PIL in / PIL out)"""
+    from PIL import Image
+    if hue_adjust in ("none", ""):
+        return img
+    return Image.fromarray(adjust_hue_range_np(get_context(device_index), np.asarray(img), hue_adjust))
+
+
 def image_chroma_tweak(img, sat=1, bright=0, hue=0, hue_adjust="none", device_index=0):
     """imfilters.py:540-548."""
     from PIL import Image

@@ -1,8 +1,12 @@
-"""Multi-GPU layer of the hot path: frame sharding + the timing protocol bench.py uses.
+"""Multi-GPU layer of the hot path: frame sharding, the clip runner and the timing protocol bench.py uses.
 
-Frames are independent units: rank r colours frames r, r+G, r+2G, ... on its own GPU with a
-full weight replica.  There is NO data-path collective; torch.distributed (backend "nccl" = RCCL on ROCm,
-"gloo" in the CPU tests) is only used for the barrier and the max-over-ranks reduction of the elapsed time.
+Frames are independent units: rank r colours frames r, r+G, r+2G, ... on its own GPU with a full weight replica;
+nothing is exchanged INSIDE the path.  Two users:
+  * bench.py --gpus N: every rank colours its own resident batches; torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the
+    CPU tests) provides only the barrier and the max-over-ranks reduction of the elapsed time (timed_steps);
+  * colorize_clip_sharded: ONE clip that lives on rank 0 goes through all GPUs and comes back in frame order — exactly one RCCL scatter of
+    the gray frames and one RCCL gather of the coloured ones around the path (device tensors, used in place by libhavc through their
+    pointers: DeviceClipFn orders the library's stream against torch's with events, no host synchronisation).
 """
 import os
 import time
@@ -61,7 +65,7 @@ def timed_steps(step_fn, steps, warmup, sync_fn, dist=None, device=None):
 
 
 # ---- a clip through N GPUs: scatter -> colour -> gather, frame order preserved -----------------------------------------------
-def colorize_clip_sharded(frames, colorize_fn, dist=None, rank=0, world_size=1, device="cpu", n_frames=None, frame_shape=None):
+def colorize_clip_sharded(frames, colorize_fn, dist=None, rank=0, world_size=1, device="cpu", n_frames=None, frame_shape=None, force_collectives=False):
     """Colour a clip on `world_size` ranks and return it, in frame order, on rank 0 (None on the other ranks).
 
     frames      rank 0: uint8 tensor / array [n, h, w, 3] (host or device); other ranks: None (pass n_frames / frame_shape, or
@@ -71,9 +75,10 @@ def colorize_clip_sharded(frames, colorize_fn, dist=None, rank=0, world_size=1, 
                 (every entry point takes device pointers): the shard never leaves HBM between the collectives
     Frames are independent: frame i goes to rank i mod G (shard_frames); the only exchange is ONE scatter of
     the gray frames and ONE gather of the coloured frames (RCCL over xGMI with backend "nccl"; "gloo" in the CPU tests).
-    Shards are padded to ceil(n / G) frames so that the collectives see equal sizes; padding frames are not coloured."""
+    Shards are padded to ceil(n / G) frames so that the collectives see equal sizes; padding frames are not coloured.
+    force_collectives: run the scatter / gather even with ONE rank (a single-GPU box can then exercise the RCCL leg end to end)."""
     import torch
-    if dist is None or world_size == 1:
+    if dist is None or (world_size == 1 and not force_collectives):
         t = torch.as_tensor(frames).to(device)
         return colorize_fn(t)
     meta = torch.zeros(4, dtype=torch.int64, device=device)
@@ -135,7 +140,11 @@ class DeviceClipFn:
         from .device import DeviceImage
         assert t.is_cuda and t.dtype == torch.uint8 and t.is_contiguous()
         ctx = self.colorizer.ctx
-        torch.cuda.current_stream(t.device).synchronize()            # the scatter wrote `t` on torch's stream
+        # the scatter wrote `t` on torch's stream and the gather will read `out` there; libhavc works on its own (non-blocking) stream:
+        # order the two with events in both directions — nothing blocks the host
+        mine = torch.cuda.ExternalStream(ctx.stream_ptr(), device=t.device)
+        theirs = torch.cuda.current_stream(t.device)
+        mine.wait_stream(theirs)
         out = torch.empty_like(t)
         src = DeviceImage(ctx, tuple(t.shape), ctypes.c_void_p(t.data_ptr()))
         if hasattr(self.colorizer, "colorize_device"):               # ClipColorizer: havc_colorize_clip
@@ -144,5 +153,7 @@ class DeviceClipFn:
         else:
             res = self.colorizer.colorize_clip(src)
             DeviceImage(ctx, tuple(out.shape), ctypes.c_void_p(out.data_ptr())).copy_from(res)
-        ctx.synchronize()                                            # the gather reads `out` on torch's stream
+        theirs.wait_stream(mine)
+        t.record_stream(mine)                                        # the caching allocator must not recycle `t` / `out` under the library's work
+        out.record_stream(mine)
         return out
