@@ -142,6 +142,13 @@ enum havc_op_type {
                                      embeddings of DDColor's einsum(bqc,bchw->bqhw)); launched once per frame; no residual  */
 #define HAVC_F_NT_STORE 0x1000    /* the LDS-transposed epilogue stores its rows with non-temporal (streaming) stores: for outputs far
                                      larger than the 256 MiB Infinity Cache that are not re-read soon (set by the runtime, HAVC_NT_STORE_MB) */
+#define HAVC_F_SPLITK(n) ((n) << 16) /* bits 16-19: split-K count n = 2..15 for convs with few output tiles and a long K (one frame of a small
+                                     layer: 4 x 8 tiles on 256 CUs): the K range is cut into n parts (even stage boundaries), one block per
+                                     (tile, part) writes fp32 partial sums to a ctx scratch buffer, a second kernel adds them IN A FIXED
+                                     ORDER and runs the epilogue.  The count is part of the PLAN (chosen by the emitter from the shape), not
+                                     of the tile autotuner: every tile configuration produces the same bytes for a given count.  Plain convs
+                                     only (no PS_BLUR / FUSE_* / W_FROM_BUF / extra-column tile)                                      */
+#define HAVC_F_SPLITK_COUNT(flags) (((flags) >> 16) & 15)
 #define HAVC_F_FUSE_RGB8 0x100    /* the conv output is NOT stored: a following 1x1 conv to 3 channels (fp32 weights at
                                      scale_off [3][Npad], bias at shift_off [3]) + OUT_RGB8 maths run in the epilogue and
                                      write u8 RGB to buffer aux0 (layers.10.1 + layers.11 + layers.12 of the generator);

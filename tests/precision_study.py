@@ -49,6 +49,30 @@ class Q:
         return x
 
 
+# ---- Winograd F(2x2, 3x3) for the two 259 -> 259 tail convs (VERDICT r2 "next" 2-iv: parity-gated experiment) ----
+# Y = A^T [ (G g G^T) (.) (B^T d B) ] A per 4x4 input tile / 2x2 output tile, 16 element-wise products per tile instead of 36 MACs per
+# channel pair (2.25x fewer MFMAs).  On the MFMA path BOTH transformed operands are fp16: the transformed input B^T d B (sums of four
+# activations: up to 4x the dynamic range, new rounding point "wino_in") and the transformed weights G g G^T ("wino_w", packed offline).
+_BT = torch.tensor([[1., 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]])
+_G = torch.tensor([[1., 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]])
+_AT = torch.tensor([[1., 1, 1, 0], [0, 1, -1, -1]])
+
+
+def winograd_conv3x3(x, w, bias, q):
+    """x [1,C,H,W] (H, W even), w [K,C,3,3], pad 1 -> [1,K,H,W]; fp32 accumulation over fp16-rounded transformed operands"""
+    _, C, H, W = x.shape
+    K = w.shape[0]
+    U = q(torch.einsum("ai,kcij,bj->kcab", _G, w, _G), "wino_w")                       # [K,C,4,4]
+    xp = F.pad(x, (1, 1, 1, 1))
+    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)                                              # [1,C,H/2,W/2,4,4]
+    V = q(torch.einsum("ai,nctuij,bj->nctuab", _BT, d, _BT), "wino_in")                 # B^T d B, B = _BT^T
+    ty, tx = V.shape[2], V.shape[3]
+    M = torch.einsum("kcab,ctab->ktab", U, V[0].reshape(C, ty * tx, 4, 4))              # 16 GEMMs, fp32 accumulation
+    Y = torch.einsum("ia,ktab,jb->ktij", _AT, M, _AT).reshape(K, ty, tx, 2, 2)
+    y = Y.permute(0, 1, 3, 2, 4).reshape(1, K, H, W)
+    return y + bias.view(1, -1, 1, 1)
+
+
 def bn_ss(sd, p):
     s = sd[p + ".weight"] / torch.sqrt(sd[p + ".running_var"] + U.EPS)
     return s, sd[p + ".bias"] - sd[p + ".running_mean"] * s
@@ -153,8 +177,12 @@ def forward(sd, x0, q, arch="wide", double_round_res=True):
 
     x = shuffle(x, q(U.conv_w(sd, "layers.8.conv.0"), "l8_w"), sd["layers.8.conv.0.bias"], "l8_act")
     x = torch.cat([x, x0], dim=1)
-    r = q(F.relu(F.conv2d(x, q(U.conv_w(sd, "layers.10.layers.0.0"), "tail_w"), sd["layers.10.layers.0.0.bias"], 1, 1)), "r1")
-    r = F.relu(F.conv2d(r, q(U.conv_w(sd, "layers.10.layers.1.0"), "tail_w"), sd["layers.10.layers.1.0.bias"], 1, 1))
+    if q.p.get("winograd"):
+        r = q(F.relu(winograd_conv3x3(x, U.conv_w(sd, "layers.10.layers.0.0"), sd["layers.10.layers.0.0.bias"], q)), "r1")
+        r = F.relu(winograd_conv3x3(r, U.conv_w(sd, "layers.10.layers.1.0"), sd["layers.10.layers.1.0.bias"], q))
+    else:
+        r = q(F.relu(F.conv2d(x, q(U.conv_w(sd, "layers.10.layers.0.0"), "tail_w"), sd["layers.10.layers.0.0.bias"], 1, 1)), "r1")
+        r = F.relu(F.conv2d(r, q(U.conv_w(sd, "layers.10.layers.1.0"), "tail_w"), sd["layers.10.layers.1.0.bias"], 1, 1))
     x = q(x + r, "r2x")
     y = F.conv2d(x, q(U.conv_w(sd, "layers.11.0"), "final_w"), sd["layers.11.0.bias"])
     return torch.sigmoid(y) * 6.0 - 3.0
@@ -189,6 +217,11 @@ def configs():
     return {
         "all": {g: "f16" for g in GROUPS},
         "all_bf16": {g: "bf16" for g in GROUPS},
+        # Winograd F(2x2,3x3) tail: everything as "all" + transformed inputs / weights in fp16 (the MFMA operands of that scheme)
+        "all_wino": {**{g: "f16" for g in GROUPS}, "winograd": True, "wino_in": "f16", "wino_w": "f16"},
+        "wino_exact": {"winograd": True},                                  # fp32 Winograd alone: the algorithm's own (re-association) error
+        "only_wino_in": {"winograd": True, "wino_in": "f16"},
+        "only_wino_w": {"winograd": True, "wino_w": "f16"},
         "all_single_round": {g: "f16" for g in GROUPS},
         "tail32": {g: "f16" for g in GROUPS if g not in ("r2x", "final_w")},
         "tail32_r1x2": {**{g: "f16" for g in GROUPS if g not in ("r2x", "final_w")}, "r1": "f16x2"},

@@ -101,23 +101,45 @@ def test_gpu_local_attention_matches_oracle(ctx, n, C, Cv, h, w, R, dil):
     assert torch.allclose(M.local_correlation(q, k, R, dil), ref_c, rtol=1e-5, atol=1e-5)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("device", ["cpu", "cuda"])
-def test_gpu_local_gated_propagation_module_matches_the_executed_reference(device):
-    """the torch-module adapter (vsdeoldify_amd/colormnet_torch.py): a reference state_dict loads as is; forward = HIP correlation /
-    softmax / aggregation + the module's own depthwise conv and Linear; output and attention as recorded from the reference module."""
+def _local_fixture():
+    return np.load(os.path.join(os.path.dirname(__file__), "golden", "colormnet_local.npz"))
+
+
+def test_oracle_short_term_tail_matches_the_executed_reference_module():
+    """oracle.colormnet_net.short_term_attn (local attention + DWConv2d + Linear, attention.py:783-860, basic.py:75-94) against the output the
+    reference's own LocalGatedPropagation module produced (tests/golden/colormnet_local.npz)"""
     import torch
-    from vsdeoldify_amd.colormnet_torch import LocalGatedPropagation
-    if device == "cuda" and not torch.cuda.is_available():
-        pytest.skip("torch sees no GPU")
-    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "colormnet_local.npz"))
-    m = LocalGatedPropagation(d_qk=64, d_vu=64, num_head=1, dilation=1, use_linear=False, dropout=0, d_att=64, max_dis=7, expand_ratio=1, enable_corr=False)
-    sd = {"relative_emb_k.weight": torch.from_numpy(g["rel_w"]).reshape(225, 64, 1, 1), "relative_emb_k.bias": torch.from_numpy(g["rel_b"]),
-          "dw_conv.conv.weight": torch.from_numpy(g["dw_w"]), "projection.weight": torch.from_numpy(g["proj_w"]), "projection.bias": torch.from_numpy(g["proj_b"])}
-    m.load_state_dict(sd)
-    m = m.to(device).eval()
-    q, k, v = (torch.from_numpy(g[n]).to(device) for n in ("q", "k", "v"))
-    out, attn = m(q, k, v, None, (q.shape[2], q.shape[3]))
-    assert np.abs(out.cpu().numpy() - g["out"]).max() < 2e-4 and np.abs(attn.cpu().numpy() - g["attn"]).max() < 1e-5
-    with pytest.raises(NotImplementedError):
-        LocalGatedPropagation(d_qk=64, d_vu=64, num_head=2, use_linear=False)
+    from oracle import colormnet_net as ON
+    g = _local_fixture()
+    sd = {"short_term_attn.relative_emb_k.weight": torch.from_numpy(g["rel_w"]).reshape(225, 64, 1, 1), "short_term_attn.relative_emb_k.bias": torch.from_numpy(g["rel_b"]),
+          "short_term_attn.dw_conv.conv.weight": torch.from_numpy(g["dw_w"]), "short_term_attn.projection.weight": torch.from_numpy(g["proj_w"]),
+          "short_term_attn.projection.bias": torch.from_numpy(g["proj_b"])}
+    q, k, v = (torch.from_numpy(g[n]) for n in ("q", "k", "v"))
+    out, attn = ON.short_term_attn(sd, q, k, v, (q.shape[2], q.shape[3]))
+    assert np.abs(out.numpy() - g["out"]).max() < 2e-5 and np.abs(attn.numpy() - g["attn"]).max() < 1e-6
+
+
+@pytest.mark.gpu
+def test_gpu_short_term_tail_ops_match_the_executed_reference_module(ctx):
+    """the plan ops behind the local attention (planar-in of agg_value, depthwise 5x5, Linear as a 1x1 conv, planar-out) on the reference
+    module's recorded agg_value -> its recorded output (fp16 activations: relative tolerance)"""
+    from tests.gpu_util import run_plan
+    from vsdeoldify_amd.plan import PlanBuilder, WeightPack, pack_conv
+    g = _local_fixture()
+    agg, want = g["agg"], g["out"]                                 # [h*w, 1, C]
+    hw, _, C = agg.shape
+    h, w = g["q"].shape[2:]
+    pack, b = WeightPack(), PlanBuilder()
+    src = b.buf(C * hw, 4)
+    a_in, a_dw, a_out = b.tensor(h, w, C), b.tensor(h, w, C), b.tensor(h, w, C)
+    b.planar_in("in", src, C, a_in, pixel_major=True)
+    wp = np.zeros((25, a_in.span), np.float16)
+    wp[:, :C] = g["dw_w"].reshape(C, 25).T
+    b.dwconv("dw", a_in, a_dw, pack.add(wp), -1, a_in.span, 5)
+    pc = pack_conv(pack, g["proj_w"][:, :, None, None].astype(np.float32), a_dw.cmap, a_dw.span, bias=g["proj_b"].astype(np.float32))
+    b.conv("proj", pc, a_dw, a_out)
+    dst = b.buf(C * hw, 4)
+    b.planar_out("out", a_out, 0, C, dst, 0)
+    got = run_plan(ctx, pack, b, {src: agg.reshape(hw, C).astype(np.float32)}, {dst: ((C, hw), np.float32)}, 1)[dst]
+    ref = want[:, 0, :].T
+    assert np.abs(got - ref).max() < 6e-3 * max(1.0, float(np.abs(ref).max())), float(np.abs(got - ref).max())

@@ -325,3 +325,34 @@ def test_conv_fuzz_subset(ctx):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_fuzz.py"), "60", "3"], capture_output=True, text=True, cwd=root, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("60 cases, 0 problems"), out.stdout[-2000:] + out.stderr[-2000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(392, 256, 256, 3), (513, 1536, 384, 1), (784, 1600, 512, 3)])
+def test_conv_split_k_matches_the_unsplit_conv_and_is_tile_independent(ctx, shape):
+    """HAVC_F_SPLITK: a small-M conv (one frame of a ColorMNet layer) with its K range cut into parts == the same conv unsplit up to the
+    fp32 summation order, and the SAME BYTES whatever tile configuration runs it (the count belongs to the plan, the tile to the tuner)."""
+    from tests.gpu_util import conv_op
+    M, Cin, Cout, k = shape
+    H, W = (14, M // 14) if M % 14 == 0 else (1, M)
+    r = np.random.default_rng(M)
+    x = (r.standard_normal((1, Cin, H, W)) * 0.5).astype(np.float32)
+    w = (r.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    bias = r.standard_normal(Cout).astype(np.float32) * 0.1
+    res = (r.standard_normal((1, Cout, H, W)) * 0.5).astype(np.float32)
+    base, _ = conv_op(ctx, x, w, bias=bias, pad=k // 2, flags=nat.F_RELU_PRE, res=res)
+    outs = []
+    for cfg in (0, 70, 72, 71):
+        got, raw = conv_op(ctx, x, w, bias=bias, pad=k // 2, flags=nat.F_RELU_PRE | nat.F_SPLITK(4), res=res, cfg=cfg)
+        outs.append(raw)
+        assert np.abs(got - base).max() < 4e-3 * max(1.0, float(np.abs(base).max())), (cfg, float(np.abs(got - base).max()))
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    t = torch_conv(x, w, bias, k // 2)
+    assert np.abs(base - (np.maximum(t, 0).astype(np.float16).astype(np.float32) + res.astype(np.float16).astype(np.float32))).max() < 2e-2
+
+
+def torch_conv(x, w, bias, pad):
+    import torch
+    import torch.nn.functional as F
+    return F.conv2d(torch.from_numpy(x.astype(np.float16).astype(np.float32)), torch.from_numpy(w.astype(np.float16).astype(np.float32)),
+                    torch.from_numpy(bias), padding=pad).numpy()

@@ -128,13 +128,18 @@ def test_gpu_ddcolor_pre_tweak_matches_the_reference_flow(ctx):
     sds, dsd = _weights()
     frame = (_frame(11).astype(np.float32) * 0.35).astype(np.uint8)                # dark: mean luma below luma_min = 0.3 -> the levels change
     rf = 10
-    col = havc.HAVCFrameColorizer(method=1, ddcolor_p=(1, rf, 1.0, 0.0, True), ddcolor_state_dict=dsd, ddcolor_kwargs=SMALL_DD,
+    col = havc.HAVCFrameColorizer(method=1, deoldify_p=(0, rf, 1.0, 0.0), ddcolor_p=(1, rf, 1.0, 0.0, True), ddcolor_state_dict=dsd, ddcolor_kwargs=SMALL_DD,
                                   ddtweak=(True, False, False), ddtweak_p=(havc.DEF_TWEAK_p, HUE_ADJ))
     got = col.colorize(frame)
+    from vsdeoldify_amd import imfilters as F
+    from vsdeoldify_amd.device import DeviceImage
     fs = min(rf * 16, frame.shape[1])
-    sq = resample.resize_rgb8(frame, fs, fs)
+    # the GPU's own squashed frame: a Spline64 .5-tie that rounds the other way moves the frame's mean luma, hence the level shift of EVERY pixel
+    sq = col._spline64(DeviceImage.from_numpy(ctx, frame[None]), fs, fs).numpy()[0]
+    assert np.abs(sq.astype(int) - resample.resize_rgb8(frame, fs, fs).astype(int)).max() <= 1
     pre = tweaks.luma_adjusted_levels(sq, 0.3, 2.5, 0.6, 1.5, 0.5)
     assert np.abs(pre.astype(int) - sq.astype(int)).max() > 0
+    assert np.array_equal(F.luma_adjusted_levels_np(ctx, sq, 0.3, 2.5, 0.6, 1.5, 0.5), pre)          # the pre-tweak itself: bit-exact
     b = col._ddcolor_clip(pre[None], (rf // 2) * 32)[0]
     b = pipeline.post_process(tweaks.adjust_hue_range(b, HUE_ADJ), sq)
     want = pipeline.post_process(resample.resize_rgb8(b, frame.shape[1], frame.shape[0]), frame)

@@ -14,6 +14,8 @@ KERNEL = "conv_pipe_kernel<2, 4, 8, 1, 0>"
 
 def per_launch(kind, counter):
     cands = glob.glob(f"{src}/pmc_bench_{kind}/*/*counter_collection.csv") + glob.glob(f"{src}/*{kind}_size_counter_collection.csv")
+    if not cands:
+        sys.exit(f"pmc_to_json: no {kind} counter CSV under {src} (did the rocprofv3 pass of tools/pmc_bench.sh fail? see {src}/pmc_bench_{kind}.log)")
     f = cands[0]
     os.makedirs("profiles/pmc", exist_ok=True)
     dst = f"profiles/pmc/{label}_bench_{kind}_size_counter_collection.csv"
@@ -24,8 +26,12 @@ def per_launch(kind, counter):
 
 def split(vals):
     """two clusters (conv1 / conv2) around the midpoint of the extremes"""
+    if not vals:
+        sys.exit(f"pmc_to_json: kernel {KERNEL} has no rows in the counter CSV")
     mid = (min(vals) + max(vals)) / 2
     lo, hi = [v for v in vals if v < mid], [v for v in vals if v >= mid]
+    if not lo or not hi:
+        sys.exit("pmc_to_json: the launches do not fall into two clusters (conv1 / conv2): trace of another command?")
     return (sum(lo) / len(lo), len(lo)), (sum(hi) / len(hi), len(hi))
 
 

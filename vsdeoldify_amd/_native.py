@@ -26,6 +26,12 @@ F_OUT_PIXSHUF, F_OUT_TRANSPOSED, F_OUT_RGB8, F_LEAKY, F_FUSE_RGB8, F_PS_BLUR = 0
 F_GELU, F_W_FROM_BUF = 0x400, 0x800
 F_FUSE_PROJ = 0x2000
 
+
+def F_SPLITK(n):
+    """HAVC_F_SPLITK(n): split-K count of a conv op (2..15), part of the plan"""
+    assert 0 <= n <= 15
+    return (n if n > 1 else 0) << 16
+
 # numpy mirror of `struct havc_op` (natural C alignment; checked against sizeof in tests)
 OP_DTYPE = np.dtype([
     ("type", "<i4"), ("flags", "<i4"),

@@ -60,6 +60,30 @@ def _dino_pos(pos_embed, h0, w0):
     return cls.numpy(), patch[0].numpy()
 
 
+def splitk_for(rows, Npad, Kc):
+    """split-K count of a conv with `rows` GEMM rows (pixels x frames of its slice): a frame of ColorMNet is a chain of launches with 4 - 100
+    output tiles for 256 CUs and K up to 14 400 in series; cutting K puts ~256 blocks in flight.  Part of the PLAN (deterministic in the
+    shape), so every tile configuration of the autotuner produces the same bytes (include/havc_mi355.h HAVC_F_SPLITK)."""
+    stages = Kc // 8
+    tiles = ((rows + 127) // 128) * ((Npad + 127) // 128)
+    if tiles >= 128 or stages < 24:
+        return 0
+    n = min(15, 256 // tiles, stages // 4)
+    return n if n >= 2 else 0
+
+
+class _Builder(PlanBuilder):
+    """PlanBuilder that knows the batch count of the slice being emitted and adds the split-K count to its convs"""
+    slice_batch = 1
+    auto_split = True
+
+    def conv(self, name, pc, x, y, stride=1, pad=0, flags=0, **kw):
+        if self.auto_split and not (flags & (nat.F_W_FROM_BUF | nat.F_PS_BLUR | nat.F_FUSE_PROJ | nat.F_OUT_RGB8)):
+            Ho, Wo = _conv_out(x.H, pc.kh, stride, pad), _conv_out(x.W, pc.kw, stride, pad)
+            flags |= nat.F_SPLITK(splitk_for(Ho * Wo * self.slice_batch, pc.Npad, pc.Kc))
+        return super().conv(name, pc, x, y, stride=stride, pad=pad, flags=flags, **kw)
+
+
 class ColorMNetPlan:
     """packs a ColorMNet state dict once; emits the plan for a padded frame size (H, W multiples of 112)"""
 
@@ -282,7 +306,8 @@ class ColorMNetPlan:
     # ---- the plan ----
     def plan(self, H, W):
         assert H % 112 == 0 and W % 112 == 0, "frames are padded to multiples of 112 (inference_core.py:49)"
-        sd, b = self.sd, PlanBuilder()
+        sd, b = self.sd, _Builder()
+        b.auto_split = os.environ.get("HAVC_CMN_SPLITK", "1") != "0"       # A/B switch (profiling)
         consts, sl, io = [], {}, {}
         CK, CV, HD = self.key_dim, self.value_dim, self.hidden_dim
         h16, w16, h8, w8, h4, w4 = H // 16, W // 16, H // 8, W // 8, H // 4, W // 4
@@ -328,6 +353,7 @@ class ColorMNetPlan:
 
         # ================= slice "value": encode_value, one frame per object =================
         s0 = len(b.ops)
+        b.slice_batch = 2
         v0 = b.tensor(H, W, 5)
         b.planar_in("value_in", fbuf("value_in", 5 * H * W), 5, v0)
         ve = "value_encoder"
@@ -358,6 +384,7 @@ class ColorMNetPlan:
         # ================= slice "skip": the decoder's skip convs on the image features, one frame =================
         d = "decoder"
         s0 = len(b.ops)
+        b.slice_batch = 1
         skip8, skip4 = b.tensor(h8, w8, 512), b.tensor(h4, w4, 256)
         self._cv(b, d + ".up_16_8.skip_conv", g8, skip8, pad=1)
         self._cv(b, d + ".up_8_4.skip_conv", g4, skip4, pad=1)
@@ -365,6 +392,7 @@ class ColorMNetPlan:
 
         # ================= slice "segment": Decoder, one frame per object =================
         s0 = len(b.ops)
+        b.slice_batch = 2
         dc_span = 1024 + CV + HD
         dc_pitch = pitch_for(dc_span)
         dc_buf, dcr_buf = b.buf(P16 * dc_pitch, 2), b.buf(P16 * dc_pitch, 2)
@@ -416,6 +444,7 @@ class ColorMNetPlan:
 
         # ================= slice "short": depthwise 5x5 + Linear behind the local attention, one frame =================
         s0 = len(b.ops)
+        b.slice_batch = 1
         st = "short_term_attn"
         a_in = b.tensor(h16, w16, 2 * CV)
         b.planar_in(st + ".agg_in", fbuf("agg", 2 * CV * P16), 2 * CV, a_in, pixel_major=True)

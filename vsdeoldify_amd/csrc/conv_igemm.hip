@@ -201,6 +201,12 @@ const char* conv_config_name(const ConvArgs& a) {
 }
 
 int launch_conv(const ConvArgs& a, hipStream_t s) {
+    if (a.splitk > 1) {                                    // split-K runs on the plain pipelined tiles only (the count is the plan's, the tile the tuner's)
+        int cfg = a.cfg;
+        if (!conv_splitk_cfg_ok(cfg)) cfg = a.Npad % 256 == 0 ? 71 : (a.Npad % 128 == 0 ? 72 : (a.Npad <= 64 ? 92 : 72));
+        if (!conv_pipe_supported(a, 0)) return (int)hipErrorInvalidValue;
+        return launch_conv_pipe(a, cfg, s);
+    }
     if ((a.flags & HAVC_F_FUSE_PROJ) && a.cfg != 0 && a.cfg != 60) return (int)hipErrorInvalidValue;
     if (a.cfg >= 60) return launch_conv_pipe(a, a.cfg, s);
     if (a.cfg == 0) {

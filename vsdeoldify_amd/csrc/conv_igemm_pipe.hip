@@ -78,6 +78,10 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
         pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
     const int NT = (p.Npad - 16 * EXTRA + BN - 1) / BN;
+    // split-K (HAVC_F_SPLITK): consecutive blocks are the K parts of one tile
+    const int SK = (!EXTRA && p.splitk > 1) ? p.splitk : 1;
+    const int part = SK > 1 ? pid % SK : 0;
+    if (SK > 1) pid /= SK;
     const int m0 = (ABL == 9 ? (pid / NT) % 64 : pid / NT) * BM;      // ABL 9: L2-resident source, DMA ceiling
     const int n0 = (pid % NT) * BN;
     const bool has_extra = EXTRA && (n0 + BN + 16 == p.Npad);
@@ -125,6 +129,9 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
     const bool extra_wave = has_extra && wave >= 6;
 
     const int KT = p.Kc >> 3;
+    // this block's stages [kt0, kt1): the whole K, or part `part` of SK with EVEN boundaries (the LDS buffer of stage kt is kt & 1)
+    const int kt0 = SK > 1 ? ((KT * part / SK) & ~1) : 0;
+    const int kt1 = SK > 1 ? (part + 1 == SK ? KT : ((KT * (part + 1) / SK) & ~1)) : KT;
     const int2* kt_lane = p.ktab + c;                  // this lane's chunk of every stage: kt_lane[kt * 8]
 
     auto a_voff = [&](int it, int2 e) -> unsigned {
@@ -150,20 +157,22 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
 
     // ---- prologue: all of stage 0, the first two pieces of stage 1, the first fragments of stage 0 ----
     constexpr int P = G::PIECES;
-    constexpr int EARLY = 2;                               // pieces of stage kt+2 issued in the last two steps of stage kt
-    constexpr int NSD = NS / 2;                            // the other pieces go out in the first NSD steps of stage kt+1
+    // ABL 20 / 21 / 22 (round-3 schedule experiments, correct results): 20 = the remaining pieces in the first NS/4 steps instead of NS/2
+    // (more time to land before the barrier), 21 = three early pieces (steps NS-3 .. NS-1, the first one right behind the barrier), 22 = both
+    constexpr int EARLY = (ABL == 21 || ABL == 22) ? 3 : 2;    // pieces of stage kt+2 issued in the last steps of stage kt
+    constexpr int NSD = (ABL == 20 || ABL == 22) ? NS / 4 : NS / 2;   // the other pieces go out in the first NSD steps of stage kt+1
     auto dma_piece = [&](int q, char* buf, int2 e, int kstage) {
         if (q < A_IT) dma16(rx, buf + (wave + q * NW) * 1024, a_voff(q, e), 0);
         else dma16(rw, buf + BM * 128 + (wave + (q - A_IT) * NW) * 1024, b_voff[q - A_IT], (unsigned)kstage * 128u);
     };
-    int2 e_nx = kt_lane[0];
+    int2 e_nx = kt_lane[kt0 * 8];
 #pragma unroll
-    for (int q = 0; q < P; ++q) dma_piece(q, smem, e_nx, 0);
+    for (int q = 0; q < P; ++q) dma_piece(q, smem, e_nx, kt0);
     if (EXTRA && extra_wave) dma16(rw, smem + (BM + BN) * 128 + (wave & 1) * 1024, x_voff, 0);
-    e_nx = kt_lane[(KT > 1 ? 1 : 0) * 8];
-    if (KT > 1) {
+    e_nx = kt_lane[(kt1 - kt0 > 1 ? kt0 + 1 : kt0) * 8];
+    if (kt1 - kt0 > 1) {
 #pragma unroll
-        for (int q = 0; q < EARLY; ++q) dma_piece(q, smem + G::STAGE_BYTES, e_nx, 1);
+        for (int q = 0; q < EARLY; ++q) dma_piece(q, smem + G::STAGE_BYTES, e_nx, kt0 + 1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("" : "+v"(e_nx.x), "+v"(e_nx.y));         // (see the note at the stage barrier)
@@ -224,8 +233,8 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
             if (EXTRA && LVL >= 1 && DMA_ON && s == NSD) {
                 if (extra_wave) dma16(rw, nxt + (BM + BN) * 128 + (wave & 1) * 1024, x_voff, (unsigned)(kt + 1) * 128u);
             }
-            if (LVL == 2 && DMA_ON && s >= NS - 2)     //     and, behind the barrier, the first pieces of stage kt+2
-                dma_piece(s - (NS - 2), const_cast<char*>(cur), e_n2, kt + 2);
+            if (LVL == 2 && DMA_ON && s >= NS - EARLY) //     and, behind the barrier, the first pieces of stage kt+2
+                dma_piece(s - (NS - EARLY), const_cast<char*>(cur), e_n2, kt + 2);
             const half8 a = af[s % 4];                 // (4) the MFMAs of this step
 #pragma unroll
             for (int ni = 0; ni < FN; ++ni) {
@@ -239,13 +248,27 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
         }
         e_nx = e_n2;
     };
-    int kt = 0;
-    for (; kt + 2 < KT; ++kt) stage(kt, std::integral_constant<int, 2>{});
-    if (KT >= 2) { stage(kt, std::integral_constant<int, 1>{}); ++kt; }
+    int kt = kt0;
+    for (; kt + 2 < kt1; ++kt) stage(kt, std::integral_constant<int, 2>{});
+    if (kt1 - kt0 >= 2) { stage(kt, std::integral_constant<int, 1>{}); ++kt; }
     stage(kt, std::integral_constant<int, 0>{});
 
     auto gm = [&](int local_row) -> int { return m0 + local_row; };
     const int lp = lr;                                     // MFMA column lr carries pixel lr of its fragment
+    if (!EXTRA && SK > 1) {                                // split-K: raw fp32 partial sums, lane = pixel lr, channels lg*4 .. +3 of each fragment
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+            const int m = m0 + wm * (FM * 16) + mi * 16 + lr;
+            if (m >= p.M) continue;
+            float* row = p.ws + ((int64_t)part * p.M + m) * p.Npad;
+#pragma unroll
+            for (int ni = 0; ni < FN; ++ni) {
+                const int n = n0 + wn * 64 + ni * 16 + lg * 4;
+                if (n < p.Npad) *reinterpret_cast<float4v*>(row + n) = acc[ni][mi];
+            }
+        }
+        return;
+    }
 #include "conv_pipe_epilogue.inc"
 }
 
@@ -504,16 +527,45 @@ static int launch_halo(const ConvArgs& a0, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// split-K, second half: sum the parts of every (pixel, 4 channels) in the order 0 .. S-1, then the shared per-fragment epilogue
+__global__ void splitk_reduce_kernel(const ConvArgs p) {
+    const int n4 = p.Npad >> 2, HoWo = p.Ho * p.Wo;
+    const int64_t total = (int64_t)p.M * n4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n = (int)(i - (int64_t)m * n4) * 4;
+        float4v acc = *reinterpret_cast<const float4v*>(p.ws + (int64_t)m * p.Npad + n);
+        for (int sp = 1; sp < p.splitk; ++sp) {
+            const float4v t = *reinterpret_cast<const float4v*>(p.ws + ((int64_t)sp * p.M + m) * p.Npad + n);
+            acc[0] += t[0]; acc[1] += t[1]; acc[2] += t[2]; acc[3] += t[3];
+        }
+        epilogue_frag(p, acc, m, n, HoWo);
+    }
+}
+
 template <int WM, int WN, int FM, int EXTRA, int ABL = 0>
 static int launch_pipe(const ConvArgs& a, hipStream_t s) {
     using G = Geo<WM, WN, FM, EXTRA>;
     if ((a.Kc & 7) || !a.ktab || a.x_bytes == 0 || a.x_bytes >= OOB || a.w_bytes >= OOB) return (int)hipErrorInvalidValue;
     const int MT = (a.M + G::BM - 1) / G::BM, NT = (a.Npad - 16 * EXTRA + G::BN - 1) / G::BN;
+    const int SK = a.splitk > 1 ? a.splitk : 1;
+    if (SK > 1 && (EXTRA || ABL || !a.ws || (a.Kc >> 3) < 2 * SK || (a.Npad & 3) ||
+                   (a.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_FUSE_PROJ | HAVC_F_W_FROM_BUF))))
+        return (int)hipErrorInvalidValue;
     constexpr int LDS = G::LDS_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
     ensure_lds_optin<conv_pipe_kernel<WM, WN, FM, EXTRA, ABL>>(LDS);
-    hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, ABL>), dim3(MT * NT), dim3(G::NW * 64), LDS, s, a);
+    hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, ABL>), dim3(MT * NT * SK), dim3(G::NW * 64), LDS, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || SK == 1) return (int)e;
+    const int64_t work = (int64_t)a.M * (a.Npad >> 2);
+    const int64_t gb = (work + 255) / 256;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(gb > 8192 ? 8192 : gb)), dim3(256), 0, s, a);
     return (int)hipGetLastError();
+}
+
+bool conv_splitk_cfg_ok(int cfg) {
+    switch (cfg) { case 60: case 70: case 71: case 72: case 90: case 91: case 92: case 93: case 95: case 96: case 97: case 98: case 99: return true; }
+    return false;
 }
 
 bool conv_pipe_supported(const ConvArgs& a, int extra) {
@@ -524,6 +576,9 @@ int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
     switch (cfg) {
         case 60: return launch_pipe<2, 4, 8, 0>(a, s);        // 256 x 256
         case 61: return launch_pipe<2, 4, 8, 1>(a, s);        // 256 x (256 + 16)
+        case 101: return launch_pipe<2, 4, 8, 1, 20>(a, s);   // schedule experiments on the dominant kernel (same bytes as cfg 61)
+        case 102: return launch_pipe<2, 4, 8, 1, 21>(a, s);
+        case 103: return launch_pipe<2, 4, 8, 1, 22>(a, s);
         case 62: return launch_pipe<2, 4, 8, 0, 1>(a, s);     // ablations of cfg 60 (profiling only)
         case 64: return launch_pipe<2, 4, 8, 0, 4>(a, s);
         case 69: return launch_pipe<2, 4, 8, 0, 9>(a, s);

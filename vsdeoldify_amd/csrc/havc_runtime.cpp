@@ -44,8 +44,8 @@ struct havc_ctx {
     havc_stats stats{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // grow-only scratch (u8 staging + float resample rows): allocated once, reused every call
-    void* scratch[12] = {nullptr};         // 0-3 staging / model i-o, 4-5 plane staging, 6 small, 7 resample rows, 8-11 pipelined host clip
-    size_t scratch_sz[12] = {0};
+    void* scratch[13] = {nullptr};         // 0-3 staging / model i-o, 4-5 plane staging, 6 small, 7 resample rows, 8-11 pipelined host clip,
+    size_t scratch_sz[13] = {0};           // 12 split-K partial sums
     hipStream_t stream_h2d = nullptr, stream_d2h = nullptr;      // copy streams of havc_colorize_clip_host (created on first use)
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
     std::map<std::pair<int, int>, ResizeTable> resize_tables;
@@ -333,6 +333,16 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             a.C8a = (op.aux1 > 0 && op.aux1 < op.Ci / 8) ? op.aux1 : op.Ci / 8;
             a.f0 = op.f0; a.f1 = op.f1; a.f2 = op.f2;
             a.cfg = op.reserved;
+            a.splitk = HAVC_F_SPLITK_COUNT(op.flags);
+            if (a.splitk == 1) a.splitk = 0;
+            if (a.splitk) {
+                if ((op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_FUSE_PROJ | HAVC_F_W_FROM_BUF | HAVC_F_OUT_RGB8)) || (op.Kc >> 3) < 2 * a.splitk)
+                    return fail(c, HAVC_E_INVALID, "conv op: SPLITK needs a plain conv with at least 2 K stages per part");
+                if (s != c->stream) return fail(c, HAVC_E_INVALID, "conv op: SPLITK ops run on the main stream only (one scratch buffer per ctx)");
+                const size_t need = (size_t)a.splitk * batch * op.Ho * op.Wo * op.Npad * 4;
+                if (int rc2 = ensure_scratch(c, 12, need)) return rc2;
+                a.ws = (float*)c->scratch[12];
+            }
             {
                 const int oi = (int)(&op - n->ops.data());
                 a.ktab = n->ktab_off[oi] >= 0 ? n->d_ktab + n->ktab_off[oi] : nullptr;
@@ -1060,6 +1070,13 @@ int havc_net_run_ops(havc_net* n, int first_op, int n_ops, int batch) {
 // tile configurations an op may run with (all produce the same bytes); empty = the op has exactly one legal configuration
 static std::vector<int> tune_candidates(const havc_op& op) {
     if (op.type != HAVC_OP_CONV || (op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_OUT_RGB8 | HAVC_F_FUSE_PROJ))) return {};
+    if (HAVC_F_SPLITK_COUNT(op.flags) > 1) {                               // split-K: the plain pipelined tiles (same bytes for a given count)
+        std::vector<int> sk = {0};
+        if (op.Npad % 256 == 0 || op.Npad % 256 >= 192) for (int k : {60, 71, 90, 91, 96, 97}) sk.push_back(k);
+        for (int k : {70, 72, 93, 95, 98}) sk.push_back(k);
+        if (op.Npad <= 192) { sk.push_back(99); sk.push_back(92); }
+        return sk;
+    }
     std::vector<int> cand = {0};
     if (op.Npad <= 16) return cand;                                        // thin N: the 128x16 kernel only
     // column tiles of 256 / 128 channels: also when the last tile is >= 75 % full (ConvNeXt pwconv2 at stage 0, 768 -> 192: the
@@ -1287,6 +1304,7 @@ struct havc_batcher {
     std::condition_variable cv;
     std::deque<Req*> q;
     bool leader = false;
+    int inflight = 0;                                          // callers inside havc_batcher_submit (free waits for them to LEAVE, not only for an empty queue)
     uint8_t *h_in = nullptr, *h_out = nullptr;                 // pinned [max_batch][S * S * 3]
     int64_t calls = 0, batches = 0;
 };
@@ -1341,7 +1359,8 @@ void havc_batcher_free(havc_batcher* b) {
     if (!b) return;
     {
         std::unique_lock<std::mutex> lk(b->m);
-        b->cv.wait(lk, [&] { return !b->leader && b->q.empty(); });
+        // a follower woken by the leader still has to re-acquire b->m before it returns: wait until every submitter has left
+        b->cv.wait(lk, [&] { return !b->leader && b->q.empty() && b->inflight == 0; });
     }
     (void)hipHostFree(b->h_in);
     (void)hipHostFree(b->h_out);
@@ -1360,6 +1379,7 @@ int havc_batcher_submit(havc_batcher* b, const uint8_t* rgb_in, uint8_t* rgb_out
     if (!b || !rgb_in || !rgb_out) return HAVC_E_INVALID;
     havc_batcher::Req r{rgb_in, rgb_out, HAVC_OK, false};
     std::unique_lock<std::mutex> lk(b->m);
+    ++b->inflight;
     b->q.push_back(&r);
     ++b->calls;
     b->cv.notify_all();                                        // a leader collecting its batch re-checks the queue length
@@ -1385,6 +1405,7 @@ int havc_batcher_submit(havc_batcher* b, const uint8_t* rgb_in, uint8_t* rgb_out
         b->leader = false;
         b->cv.notify_all();
     }
+    if (--b->inflight == 0) b->cv.notify_all();                // (still under b->m) havc_batcher_free may be waiting for the last caller
     return r.rc;
 }
 

@@ -39,12 +39,15 @@ struct ConvArgs {
     float* fuse_out;       // FUSE_PROJ: fp32 output [M][Npad / 256][2]; fuse_w = fp32 [frame][2][256]
     unsigned x_bytes;      // size of the input allocation (buffer descriptor range; OOB lanes read zeros)
     unsigned w_bytes;      // Npad * Kc * 16
+    int splitk;            // > 1: the K range is cut into `splitk` parts, one block per (tile, part) stores its fp32 partial sums to `ws`
+    float* ws;             //      [splitk][M][Npad]; splitk_reduce_kernel adds them in a fixed order and runs the usual epilogue
 };
 #define HAVC_KTAB_PAD_DH 0x7fff
 
 // returns hipError_t as int
 int launch_conv(const ConvArgs& a, hipStream_t s);
 int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s);
+bool conv_splitk_cfg_ok(int cfg);      // tile configurations that may run with ConvArgs::splitk > 1 (the plain pipelined tiles)
 const char* conv_config_name(const ConvArgs& a);
 
 int launch_maxpool3x3s2(const half_t* x, half_t* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int x_cpitch,
