@@ -22,6 +22,27 @@ class OracleBackend:
         return mv @ aff[0]
 
 
+class OracleNetwork(net.Network):
+    """the oracle network with the extra methods ColorMNetRender asks of its network object (frame transforms, stream scope): lets the
+    drop-in class's state machine (vsdeoldify_amd/colormnet_render.py) run entirely on the CPU against the executed-reference scenarios"""
+
+    class _Null:
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+    def on_stream(self):
+        return self._Null()
+
+    def image_to_lab(self, rgb_u8):
+        return net.frame_to_lab_tensor(np.asarray(rgb_u8))
+
+    def lab_to_image(self, l_plane, ab, out=None):
+        return net.lab_tensor_to_rgb(l_plane, ab)
+
+
 def colorize_clip(sd, frames_rgb, refs, config_updates=None, vid_length=None):
     """frames_rgb: list of u8 [H, W, 3]; refs: {frame index: u8 RGB reference image}; -> list of u8 [H, W, 3]
     (colormnet_render.py:197-283 with reset_on_ref_update = False and FirstFrameIsNotExemplar = True: the HAVC_deepex default, method 0)"""

@@ -130,6 +130,30 @@ def test_oracle_network_matches_the_executed_reference():
         check("short", short, stride_of("short"), 2e-4)
 
 
+SCENARIOS = {"keep": (dict(reset_on_ref_update=False, max_memory_frames=0), False), "vivid": (dict(reset_on_ref_update=True, max_memory_frames=0), False),
+             "propagate": (dict(reset_on_ref_update=False, max_memory_frames=0), True), "capped": (dict(reset_on_ref_update=False, max_memory_frames=3), False)}
+
+
+def run_render_scenario(name, network, memory_backend=None):
+    """drive the drop-in ColorMNetRender exactly as tools/gen_golden_colormnet_net.py drove the reference's class; returns the 9 coloured frames"""
+    from PIL import Image
+    from vsdeoldify_amd.colormnet_render import ColorMNetRender
+    kw, propagate = SCENARIOS[name]
+    frames, refs = REN["frames"], REN["refs"]
+    rnd = ColorMNetRender(image_size=-1, vid_length=len(frames), enable_resize=False, encode_mode=1, propagate=propagate, network=network,
+                          memory_backend=memory_backend, **kw)
+    rnd.set_config("mem_every", int(REN["mem_every"]))
+    outs = []
+    for t, fr in enumerate(frames):
+        rnd.set_ref_frame(Image.fromarray(refs[0]) if t == 0 else (Image.fromarray(refs[1]) if t == 4 else None), propagate)
+        outs.append(np.asarray(rnd.colorize_frame(ti=t, frame_i=Image.fromarray(np.stack([fr] * 3, -1)))))
+    return np.stack(outs)
+
+
+def want_of(name):
+    return REN["outs" if name == "keep" else "outs_" + name]
+
+
 def test_oracle_frame_loop_matches_the_reference_render_class():
     """the reference's own ColorMNetRender.colorize_frame over 9 frames (exemplars with frames 0 and 4) vs oracle network + drop-in
     InferenceCore / MemoryManager: u8 frames, identical up to float noise at the rounding boundary"""
@@ -138,6 +162,18 @@ def test_oracle_frame_loop_matches_the_reference_render_class():
     got = np.stack(colormnet_clip.colorize_clip(tsd(), [np.stack([f] * 3, -1) for f in frames], {0: refs[0], 4: refs[1]}, {"mem_every": int(REN["mem_every"])}))
     d = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert got.shape == want.shape and d.max() <= 1 and (d > 0).mean() < 2e-3, (int(d.max()), float((d > 0).mean()))
+
+
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_render_state_machine_matches_the_reference_class_on_cpu(name):
+    """The DROP-IN ColorMNetRender (vsdeoldify_amd/colormnet_render.py: reference counters, the memory reset when a new reference arrives
+    (render_vivid) or max_memory_frames is reached, FirstFrameIsNotExemplar / step vs step_AnyExemplar) with the oracle network plugged in,
+    against the frames the reference's own class produced in the same four scenarios: <= 1 LSB."""
+    from oracle import colormnet_clip
+    got = run_render_scenario(name, colormnet_clip.OracleNetwork(tsd()), colormnet_clip.OracleBackend())
+    want = want_of(name)
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert got.shape == want.shape and d.max() <= 1 and (d > 0).mean() < 2e-3, (name, int(d.max()), float((d > 0).mean()))
 
 
 # =====================================================================================================================================
@@ -404,27 +440,20 @@ def test_gpu_lab_transforms_match_the_oracle():
 
 
 @pytest.mark.gpu
-def test_gpu_render_matches_the_reference_render_class():
-    """ColorMNetRender (drop-in) over the 9-frame clip of the fixture — exemplars with frames 0 and 4, memory frames every second frame —
-    against the frames the reference's own ColorMNetRender produced (tests/golden/colormnet_net_render.npz) and against the all-oracle loop.
-    fp16 activations vs fp32: CIEDE2000 statistics per frame; the memory read is a top-k softmax, so a handful of pixels may pick another
-    memory element (tolerated through the p99 / max split, as for the DeOldify path)."""
-    from PIL import Image
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_gpu_render_matches_the_reference_render_class(name):
+    """ColorMNetRender (drop-in) on the MI355X over the 9-frame clip of the fixture — exemplars with frames 0 and 4, memory frames every second
+    frame — in the four scenarios recorded from the reference's own ColorMNetRender (keep the memory / render_vivid reset / frame_propagate /
+    max_memory_frames reset).  fp16 activations vs fp32: CIEDE2000 statistics per frame; the memory read is a top-k softmax, so a handful of
+    pixels may pick another memory element (tolerated through the p99 / max split, as for the DeOldify path)."""
     from oracle import imaging
-    from vsdeoldify_amd.colormnet_render import ColorMNetRender
-    frames, refs, want = REN["frames"], REN["refs"], REN["outs"]
-    rnd = ColorMNetRender(image_size=-1, vid_length=len(frames), enable_resize=False, encode_mode=1, max_memory_frames=0, reset_on_ref_update=False,
-                          network=gpu_network())
-    rnd.set_config("mem_every", int(REN["mem_every"]))
+    got, want = run_render_scenario(name, gpu_network()), want_of(name)
     worst = (0.0, 0.0)
-    for t, fr in enumerate(frames):
-        rnd.set_ref_frame(Image.fromarray(refs[0]) if t == 0 else (Image.fromarray(refs[1]) if t == 4 else None), False)
-        got = np.asarray(rnd.colorize_frame(ti=t, frame_i=Image.fromarray(np.stack([fr] * 3, -1))))
-        de = imaging.delta_e00_images(got, want[t])
+    for t in range(len(want)):
+        de = imaging.delta_e00_images(got[t], want[t])
         worst = max(worst, (float(de.mean()), float(np.percentile(de, 99))))
-        assert got.shape == want[t].shape and de.mean() < 0.5 and np.percentile(de, 99) < 2.5, (t, float(de.mean()), float(np.percentile(de, 99)), float(de.max()))
-    print("worst frame: mean dE00 %.3f, p99 %.3f" % worst)
-    assert rnd.get_frame_count() == len(frames) - 1 + 0 or rnd.get_frame_count() >= 1
+        assert got[t].shape == want[t].shape and de.mean() < 0.5 and np.percentile(de, 99) < 2.5, (name, t, float(de.mean()), float(np.percentile(de, 99)), float(de.max()))
+    print(f"{name}: worst frame mean dE00 %.3f, p99 %.3f" % worst)
 
 
 @pytest.mark.gpu

@@ -75,6 +75,7 @@ class KeyValueMemoryStore:
         self.k = self.s = self.e = self.v = None
         self.objects = None
         self.use_count = self.life_count = None
+        self.version = 0                                       # bumped whenever keys / values change (not by usage updates): MemoryManager caches on it
 
     def add(self, key, value, shrinkage, selection, objects):
         import torch
@@ -90,6 +91,7 @@ class KeyValueMemoryStore:
             if len(value) != 1:
                 raise NotImplementedError("one object group only")
             value = value[0]
+        self.version += 1
         self.k = _cat(self.k, key)
         self.s = _cat(self.s, shrinkage) if shrinkage is not None else self.s
         self.e = _cat(self.e, selection) if selection is not None else self.e
@@ -104,6 +106,7 @@ class KeyValueMemoryStore:
             self.life_count = self.life_count + 1
 
     def _keep(self, pick):
+        self.version += 1
         self.k = pick(self.k)
         self.s = None if self.s is None else pick(self.s)
         self.e = None if self.e is None else pick(self.e)
@@ -209,10 +212,14 @@ class MemoryManager:
         qe = selection.flatten(start_dim=2) if selection is not None else None
         use_long = self.enable_long_term and self.long_mem.engaged()
         if use_long:
+            # the concatenated [long-term | working] banks change only when a frame is memorised or the memory is consolidated (every
+            # mem_every-th frame): between those frames the concatenation (57 MB of values at 14 000 elements) is reused, not rebuilt
             long_size = self.long_mem.size
-            mk = torch.cat([self.long_mem.key, self.work_mem.key], -1)
-            ms = torch.cat([self.long_mem.shrinkage, self.work_mem.shrinkage], -1)
-            mv = torch.cat([self.long_mem.v, self.work_mem.v], -1)
+            stamp = (id(self.long_mem), self.long_mem.version, self.work_mem.version)
+            if getattr(self, "_banks", (None,))[0] != stamp:
+                self._banks = (stamp, torch.cat([self.long_mem.key, self.work_mem.key], -1),
+                               torch.cat([self.long_mem.shrinkage, self.work_mem.shrinkage], -1), torch.cat([self.long_mem.v, self.work_mem.v], -1))
+            _, mk, ms, mv = self._banks
         else:
             long_size = 0
             mk, ms, mv = self.work_mem.key, self.work_mem.shrinkage, self.work_mem.v

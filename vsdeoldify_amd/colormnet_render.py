@@ -66,7 +66,7 @@ class ColorMNetRender:
     """renders one frame at a time (colormnet_render.py:47)"""
 
     def __init__(self, image_size=-1, vid_length=None, enable_resize=False, encode_mode=None, propagate=False, max_memory_frames=None,
-                 reset_on_ref_update=True, project_dir=None, state_dict=None, device_index=0, network=None):
+                 reset_on_ref_update=True, project_dir=None, state_dict=None, device_index=0, network=None, memory_backend=None):
         if image_size is not None and image_size >= 0:
             raise NotImplementedError("image_size >= 0 (resize inside the transform) is never used by HAVC (vsdeoldify/__init__.py:1700)")
         if vid_length is None:
@@ -82,11 +82,11 @@ class ColorMNetRender:
         self.total_colored_frames = self.frame_count = self.ref_count = self.ref_count_prv = 0
         self.ref_img = self.ref_img_valid = self.img = None
         self.first_mask_loaded = False
-        self.device_index = device_index
+        self.device_index, self._memory_backend = device_index, memory_backend          # memory_backend: CPU tests of the state machine only
         self.network = network if network is not None else _load_network(self.project_dir, state_dict, device_index)
         self.config = default_config(vid_length, self.max_memory_frames, propagate)
         self.config.update(key_dim=self.network.key_dim, value_dim=self.network.value_dim, hidden_dim=self.network.hidden_dim)
-        self.processor = InferenceCore(self.network, self.config, device_index=device_index)
+        self.processor = InferenceCore(self.network, self.config, device_index=device_index, memory_backend=memory_backend)
 
     # ---- colormnet_render.py:162-193 ----
     def set_config(self, param_name=None, param_value=None):
@@ -125,7 +125,7 @@ class ColorMNetRender:
         if reset_1 or reset_2:
             self.frame_count = 0
             self.config["FirstFrameIsNotExemplar"] = True              # the reference image is the previous coloured frame
-            self.processor = InferenceCore(self.network, self.config, device_index=self.device_index)
+            self.processor = InferenceCore(self.network, self.config, device_index=self.device_index, memory_backend=self._memory_backend)
             ref = self.ref_img_valid
         else:
             ref = self.ref_img
