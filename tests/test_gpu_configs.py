@@ -79,6 +79,52 @@ def test_colormnet_config_at_full_size_matches_the_oracle_loop(ctx):
         assert mean < 0.15 and p99 < 1.5 and w2 > 0.998, (t, mean, p99, w2)
 
 
+def test_deepex_colormnet_data_path_with_borders(ctx):
+    """DeepExColorMNet = HAVC_deepex(ex_model=0)'s data path: a 4:3 clip gets black side borders up to 16:9 (SmartResizeColorizer), Spline64 to
+    256 x 144 ('fast'), ColorMNet, Spline64 back, crop, luma of the source; vs the same flow assembled from the oracle pieces"""
+    import torch
+    from oracle import colormnet_clip
+    from vsdeoldify_amd.colormnet_render import DeepExColorMNet
+    from vsdeoldify_amd.synth import synth_colormnet_state_dict
+    sd = synth_colormnet_state_dict(1)
+    clip = np.stack([synthetic_gray_frame(i, 400, 300) for i in range(2)])
+    ref = np.clip(clip[0].astype(np.float32) * [1.05, 0.9, 0.75] + [10, 0, 12], 0, 255).astype(np.uint8)
+    dx = DeepExColorMNet(vid_length=100, render_speed="fast", render_vivid=False, state_dict=sd)
+    assert dx._borders(300, 400) == (0, 67) and dx._borders(1080, 1920) == (0, 0) and dx._borders(800, 1920)[0] > 0
+    got = dx.colorize_clip(clip, {0: ref})
+    pad = lambda a: np.pad(a, ((0, 0), (67, 67), (0, 0)))
+    smalls = [resample.resize_rgb8(pad(f), 256, 144) for f in clip]
+    cols = colormnet_clip.colorize_clip({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, smalls, {0: resample.resize_rgb8(pad(ref), 256, 144)}, vid_length=100)
+    for t in range(2):
+        want = pipeline.post_process(np.ascontiguousarray(resample.resize_rgb8(cols[t], 400 + 134, 300)[:, 67:467]), clip[t])
+        mean, p99, w2 = _stats(got[t], want)
+        print(f"deepex 4:3 frame {t}: mean dE00 {mean:.4f} p99 {p99:.3f} bytes within 2 LSB {w2:.5f}")
+        assert got[t].shape == clip[t].shape and mean < 0.3 and p99 < 2.0, (t, mean, p99)
+
+
+def test_colormnet_at_the_slow_deepex_size(ctx):
+    """HAVC_deepex render_speed 'slow': 512 x 288 (deepex/__init__.py:64-65) -> padded to 560 x 336 inside the step: odd 1/16 grid (21 x 35), DINOv2 grid
+    24 x 40 interpolated to it, pads on both axes; exemplar + one propagated frame vs the oracle loop"""
+    import torch
+    from PIL import Image
+    from oracle import colormnet_clip
+    from vsdeoldify_amd.colormnet_net import ColorMNetNetwork
+    from vsdeoldify_amd.colormnet_render import ColorMNetRender
+    from vsdeoldify_amd.synth import synth_colormnet_state_dict
+    sd = synth_colormnet_state_dict(1)
+    smalls = [resample.resize_rgb8(synthetic_gray_frame(i, 1920, 1080), 512, 288) for i in range(2)]
+    l = smalls[0][..., 0].astype(np.float32)
+    ref_img = np.clip(np.stack([l * 0.95 + 20, l * 0.9, l * 0.8 + 15], -1), 0, 255).astype(np.uint8)
+    want = colormnet_clip.colorize_clip({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, smalls, {0: ref_img}, vid_length=100)
+    rnd = ColorMNetRender(vid_length=100, reset_on_ref_update=False, network=ColorMNetNetwork(sd))
+    for t, s in enumerate(smalls):
+        rnd.set_ref_frame(Image.fromarray(ref_img) if t == 0 else None, False)
+        got = np.asarray(rnd.colorize_frame(t, Image.fromarray(s)))
+        mean, p99, w2 = _stats(got, want[t])
+        print(f"slow size frame {t}: mean dE00 {mean:.4f} p99 {p99:.3f} bytes within 2 LSB {w2:.5f}")
+        assert got.shape == s.shape and mean < 0.3 and p99 < 2.0, (t, mean, p99)
+
+
 # ---- weight files (f4) ----
 def _save_pth(path, sd, layout):
     import torch

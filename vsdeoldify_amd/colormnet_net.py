@@ -495,15 +495,23 @@ class ColorMNetNetwork:
     """the object InferenceCore drives: encode_key / encode_value / segment / short_term_attn on device tensors (torch, fp32, the
     reference's shapes), plus the frame transforms of ColorMNetRender.  One instance per (weights, GPU)."""
 
-    def __init__(self, state_dict, device_index=0, autotune=None):
+    def __init__(self, state_dict, device_index=0, autotune=None, worker=0, share=None):
+        """worker: index of the per-thread context on this GPU (render.get_context): networks built with different worker indices run
+        CONCURRENTLY from different threads, each on its own HIP stream (independent clips: replicas inside one GPU);
+        share: another ColorMNetNetwork of the same GPU whose packed plan and device weights are reused (read-only)."""
         import torch
         from .render import get_context
         if not torch.cuda.is_available():
             raise nat.NativeLibraryError("ColorMNetNetwork: torch sees no GPU (device tensors are the interface of the ColorMNet step)")
-        self.ctx = get_context(device_index)
-        self.plan = ColorMNetPlan(state_dict)
+        self.ctx = get_context(device_index, worker)
+        if share is not None:
+            if share.ctx.device_id != self.ctx.device_id:
+                raise ValueError("share: a network of the same GPU")
+            self.plan, self.weights, self._owns_weights = share.plan, share.weights, False
+        else:
+            self.plan = ColorMNetPlan(state_dict)
+            self.weights, self._owns_weights = nat.Weights(self.ctx, self.plan.blob), True
         self.key_dim, self.value_dim, self.hidden_dim = self.plan.key_dim, self.plan.value_dim, self.plan.hidden_dim
-        self.weights = nat.Weights(self.ctx, self.plan.blob)
         self.device = torch.device("cuda", device_index)
         self.stream = torch.cuda.ExternalStream(self.ctx.stream_ptr(), device=self.device)
         self.nets = {}
@@ -664,4 +672,5 @@ class ColorMNetNetwork:
         for n in self.nets.values():
             n.close()
         self.nets.clear()
-        self.weights.close()
+        if self._owns_weights:
+            self.weights.close()

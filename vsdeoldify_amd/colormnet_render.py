@@ -158,3 +158,74 @@ class ColorMNetRender:
             out = Image.fromarray(self.network.lab_to_image(lab[:1], prob))
         self.img = self.ref_img_valid = out                             # save_last_image (:303-305)
         return out
+
+
+DEEPEX_SIZES = {"medium": (216, 384), "fast": (144, 256), "slow": (288, 512), "slower": (360, 640)}      # get_deepex_size, deepex/__init__.py:50-83
+
+
+class DeepExColorMNet:
+    """The data path of HAVC_deepex(ex_model=0) (vsdeoldify/__init__.py:1665-1735) on arrays, without VapourSynth: SmartResizeColorizer
+    (vsslib/vsresize.py:271-329: black borders up to the target aspect ratio, Spline64 to the DeepEx size) -> ColorMNetRender per frame, the
+    reference frames arriving with the frames a scene detector flagged (colormnet/__init__.py:100-112) -> Spline64 back, borders cropped ->
+    luma of the source (vs_recover_clip_luma).  Scene detection itself, the HAVC-generated reference clip, ref_merge and the dark / smooth /
+    colormap tweaks of the reference frames stay in VapourSynth: pass the reference images.  Spline64 = the library's (zimg is outside the
+    parity contract)."""
+
+    def __init__(self, vid_length, render_speed="medium", enable_resize=False, render_vivid=True, max_memory_frames=0, frame_propagate=False,
+                 project_dir=None, state_dict=None, device_index=0, network=None):
+        if render_speed.lower() not in DEEPEX_SIZES:
+            raise ValueError("HAVC_deepex: unknown render_speed ->" + render_speed)
+        scale = 2 if enable_resize else 1
+        self.th, self.tw = (v * scale for v in DEEPEX_SIZES[render_speed.lower()])
+        if max_memory_frames > 0:
+            render_vivid = False                                          # __init__.py:1692-1693
+        self.propagate = frame_propagate
+        self.render = ColorMNetRender(image_size=-1, vid_length=vid_length, enable_resize=enable_resize, encode_mode=1, max_memory_frames=max_memory_frames,
+                                      reset_on_ref_update=render_vivid, project_dir=project_dir, state_dict=state_dict, device_index=device_index,
+                                      network=network)
+        self.ctx = self.render.network.ctx
+        self.t = 0
+
+    def _borders(self, h, w):
+        """SmartResizeColorizer.get_resized_clip: (pad_h, pad_w) of black borders that bring the clip to the target aspect ratio"""
+        rt, rc = round(self.tw / self.th, 2), round(w / h, 2)
+        if rc < rt:
+            return 0, int(round((round(h * rt, 0) - w) / 2, 0))
+        if rc > rt:
+            return int(round((round(w / rt, 0) - h) / 2, 0)), 0
+        return 0, 0
+
+    def _squash(self, img):
+        from .havc import spline64
+        h, w = img.shape[:2]
+        ph, pw = self._borders(h, w)
+        if ph or pw:
+            from .device import is_device
+            a = img.numpy() if is_device(img) else np.asarray(img)
+            img = np.pad(a, ((ph, ph), (pw, pw), (0, 0)))                  # std.AddBorders: black
+        return spline64(self.ctx, img, self.tw, self.th), (ph, pw)
+
+    def colorize_frame(self, frame, ref=None):
+        """frame: u8 [h, w, 3] (ndarray or DeviceImage); ref: the reference image for THIS frame (same size as the clip) or None"""
+        from PIL import Image
+        from .device import is_device
+        from .havc import spline64
+        h, w = frame.shape[:2]
+        small, (ph, pw) = self._squash(frame)
+        if ref is not None:
+            rs, _ = self._squash(ref)
+            ref = rs if is_device(rs) else np.asarray(rs)
+        self.render.set_ref_frame(ref, self.propagate)
+        col = self.render.colorize_frame(self.t, small if is_device(small) else Image.fromarray(small))
+        self.t += 1
+        col = col if is_device(col) else np.asarray(col)
+        if ph or pw:                                                         # restore_clip_size: Spline64 to the bordered size, crop, then the luma
+            up = spline64(self.ctx, col, w + 2 * pw, h + 2 * ph)
+            up = (up.numpy() if is_device(up) else up)[ph:ph + h, pw:pw + w]
+            from . import imfilters as F
+            return F.chroma_post_process_np(self.ctx, np.ascontiguousarray(up), frame.numpy() if is_device(frame) else np.asarray(frame))
+        return spline64(self.ctx, col, w, h, luma_from=frame)
+
+    def colorize_clip(self, clip, refs):
+        """clip: u8 [n, h, w, 3]; refs: {frame index: reference image}; -> u8 [n, h, w, 3]"""
+        return np.stack([np.asarray(self.colorize_frame(f, refs.get(i))) for i, f in enumerate(clip)])
