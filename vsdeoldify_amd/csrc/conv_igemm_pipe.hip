@@ -248,6 +248,10 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
         }
         e_nx = e_n2;
     };
+    // Static priority for the younger half of an 8-wave block (two waves per SIMD): waves 4-7 lose the VALU / issue arbitration to the older
+    // half on every stage (priority, then age: MI355X_MICROARCH.md "Two waves per SIMD", item 4).  ONE s_setprio before the loop, no flips:
+    // 5.99 -> 5.83 ms on the tail conv (interleaved same-box A/B, profiles/r3_conv_experiments.txt).  Scheduling only: same bytes.
+    if (NW == 8 && p.prio && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
     int kt = kt0;
     for (; kt + 2 < kt1; ++kt) stage(kt, std::integral_constant<int, 2>{});
     if (kt1 - kt0 >= 2) { stage(kt, std::integral_constant<int, 1>{}); ++kt; }

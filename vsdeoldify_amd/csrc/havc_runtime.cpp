@@ -333,6 +333,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             a.C8a = (op.aux1 > 0 && op.aux1 < op.Ci / 8) ? op.aux1 : op.Ci / 8;
             a.f0 = op.f0; a.f1 = op.f1; a.f2 = op.f2;
             a.cfg = op.reserved;
+            { static const int prio = [] { const char* e = getenv("HAVC_SETPRIO"); return e ? atoi(e) != 0 : 1; }(); a.prio = prio; }
             a.splitk = HAVC_F_SPLITK_COUNT(op.flags);
             if (a.splitk == 1) a.splitk = 0;
             if (a.splitk) {

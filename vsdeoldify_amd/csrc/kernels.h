@@ -39,6 +39,7 @@ struct ConvArgs {
     float* fuse_out;       // FUSE_PROJ: fp32 output [M][Npad / 256][2]; fuse_w = fp32 [frame][2][256]
     unsigned x_bytes;      // size of the input allocation (buffer descriptor range; OOB lanes read zeros)
     unsigned w_bytes;      // Npad * Kc * 16
+    int prio;              // 1: static s_setprio 1 for the younger half of an 8-wave block (HAVC_SETPRIO, default on)
     int splitk;            // > 1: the K range is cut into `splitk` parts, one block per (tile, part) stores its fp32 partial sums to `ws`
     float* ws;             //      [splitk][M][Npad]; splitk_reduce_kernel adds them in a fixed order and runs the usual epilogue
 };
