@@ -102,7 +102,7 @@ enum havc_op_type {
                                 k at res_coff, v at aux0, all in buffer src with pitch src_cpitch), Ho = live tokens, kh = heads, f0 = scale */
     HAVC_OP_CBAM = 24,       /* CBAM (cbam.py:27-77) fused with the residual of FeatureFusionBlock (modules.py:35-39): dst = x (1 + channel
                                 gate x spatial gate) = g + CBAM(g); w_off = fp32 {W1 [C/16][C], b1, W2 [C][C/16], b2, w7 [2][49], b7};
-                                aux0 / aux1 = fp32 scratch (scale [C], comp [Hi*Wi][2]); flags HAVC_EW_DUAL: relu(dst) -> buffer src2 at
+                                aux0 / aux1 = fp32 scratch (gate [3 C] = scale | avg | max, comp [Hi*Wi][2]); flags HAVC_EW_DUAL: relu(dst) -> buffer src2 at
                                 res_coff, pitch res_cpitch                                                                               */
     HAVC_OP_GRU = 25,        /* HiddenReinforcer / HiddenUpdater gates (modules.py:66-76): src = values view (3 Co channels), src2 = fp32 planar
                                 hidden [Co][Hi*Wi] per frame, dst = fp32 planar new hidden                                               */

@@ -322,7 +322,7 @@ def test_cbam_gru_planar_ops(ctx):
     pack, b = WeightPack(), PlanBuilder()
     xv, yv, y2 = b.tensor(H, W, C), b.tensor(H, W, C), b.tensor(H, W, C)
     woff = pack.add(np.concatenate([sd[k].reshape(-1) for k in sd]))
-    b.cbam("cbam", xv, yv, woff, b.buf(C, 4), b.buf(H * W * 2, 4), dual=y2)
+    b.cbam("cbam", xv, yv, woff, b.buf(3 * C, 4), b.buf(H * W * 2, 4), dual=y2)
     # GRU on fp32 planar hidden + planar in / out round trip with the KeyProjection activations
     vals = _f16(_rand(B, 3 * HD, H, W, seed=19))
     hid = _rand(B, HD, H, W, seed=20, scale=0.5)
@@ -467,3 +467,60 @@ def test_gpu_render_first_frames_without_a_reference_pass_through():
     assert rnd.colorize_frame(0, img) is img
     with pytest.raises(NotImplementedError):
         ColorMNetRender(image_size=256, vid_length=4, network=gpu_network())
+
+
+@pytest.mark.gpu
+def test_gpu_key_lookahead_equals_encode_key_frame_by_frame():
+    """prefetch_keys (the key encoder on several frames per pass, split-K counts chosen for the batch) against encode_key one frame at a time:
+    the same arithmetic up to the fp32 summation order of the split-K parts; the FIFO hands the entries out in order and only when armed."""
+    net = gpu_network()
+    dev = net.device
+    g = torch.Generator().manual_seed(5)
+    frames = [torch.tanh(torch.randn(1, 1, 112, 224, generator=g)).repeat(1, 3, 1, 1) for _ in range(5)]
+    single = [net.encode_key(f.to(dev)) for f in frames]
+    net.prefetch_keys([f[0].to(dev) for f in frames], max_batch=8)           # 5 of 8: a ragged last batch
+    assert len(net._ahead) == 5
+    h, w = 7, 14
+    for i, f in enumerate(frames):
+        if i == 2:                                                            # not armed: computed, the FIFO is left alone
+            k_plain = net.encode_key(f.to(dev))[0]
+            assert len(net._ahead) == 3 and rel(k_plain.cpu().numpy(), single[i][0].cpu().numpy())[0] == 0.0
+        net.expect_prefetched()
+        gk, gs, ge, gf, _, _ = net.encode_key(f.to(dev))
+        torch.cuda.synchronize()
+        sk, ss, se, sf, _, _ = single[i]
+        for n_, a, b_ in (("key", gk, sk), ("shrinkage", gs, ss), ("selection", ge, se)):
+            r = rel(a.cpu().numpy(), b_.cpu().numpy())
+            assert r[0] < 4e-3 and r[1] < 1e-3, (i, n_, r)
+        for n_, rows, C in (("g16", (h, w), 1024), ("g8", (2 * h, 2 * w), 512), ("g4", (4 * h, 4 * w), 256)):
+            r = rel(feat_nchw(getattr(gf, n_), rows, C), feat_nchw(getattr(sf, n_), rows, C))
+            assert r[0] < 4e-3 and r[1] < 1e-3, (i, n_, r)
+    assert len(net._ahead) == 0
+    net.expect_prefetched()                                                   # nothing waiting: the flag does not stick
+    assert not net._armed
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["keep", "capped"])
+def test_gpu_colorize_batch_frames_with_lookahead_matches_the_reference_render_class(name):
+    """ColorMNetRender.colorize_batch_frames (colormnet_render.py:186-195) knows its frames up front: the key encoder runs 4 frames per pass
+    ahead of the sequential step.  Same fixtures and tolerances as the frame-by-frame test (exemplars with frames 0 and 4; "capped" resets the
+    memory every 3 frames, i.e. inside a look-ahead window), and within 2 LSB of the frame-by-frame drop-in for 99.9 % of the bytes."""
+    from PIL import Image
+    from oracle import imaging
+    from vsdeoldify_amd.colormnet_render import ColorMNetRender
+    kw, propagate = SCENARIOS[name]
+    frames, refs, want = REN["frames"], REN["refs"], want_of(name)
+    rnd = ColorMNetRender(image_size=-1, vid_length=len(frames), enable_resize=False, encode_mode=1, propagate=propagate, network=gpu_network(),
+                          lookahead=4, **kw)
+    rnd.set_config("mem_every", int(REN["mem_every"]))
+    imgs = [Image.fromarray(np.stack([fr] * 3, -1)) for fr in frames]
+    ref_list = [Image.fromarray(refs[0]) if t == 0 else (Image.fromarray(refs[1]) if t == 4 else None) for t in range(len(frames))]
+    got = np.stack([np.asarray(o) for o in rnd.colorize_batch_frames(imgs, ref_list, propagate)])
+    assert not rnd._ahead and not rnd.network._ahead
+    for t in range(len(want)):
+        de = imaging.delta_e00_images(got[t], want[t])
+        assert de.mean() < 0.5 and np.percentile(de, 99) < 2.5, (name, t, float(de.mean()), float(np.percentile(de, 99)))
+    plain = run_render_scenario(name, gpu_network())
+    d = np.abs(got.astype(np.int32) - plain.astype(np.int32))
+    assert (d <= 2).mean() > 0.999, (int(d.max()), float((d <= 2).mean()))

@@ -300,11 +300,13 @@ class ColorMNetPlan:
                                     self._w(a + ".SpatialGate.spatial.conv.weight").reshape(-1), self._w(a + ".SpatialGate.spatial.conv.bias")]),)
         woff, = self._vecs(a, make)
         g2, g2r = b.tensor(cat.H, cat.W, mid), b.tensor(cat.H, cat.W, mid)
-        b.cbam(a, g1, g2, woff, b.buf(mid, 4), b.buf(cat.H * cat.W * 2, 4), dual=g2r)
+        b.cbam(a, g1, g2, woff, b.buf(3 * mid, 4), b.buf(cat.H * cat.W * 2, 4), dual=g2r)       # gate buffer: scale | avg | max
         return self._resblock(b, p + ".block2", g2, g2r, out)
 
     # ---- the plan ----
-    def plan(self, H, W):
+    def plan(self, H, W, key_batch=1):
+        """key_batch: frames per launch of the "key" slice.  encode_key does not depend on the memory, so the frames of a clip can go through
+        the key encoder several at a time (ColorMNetNetwork.prefetch_keys); the split-K counts of that slice are chosen for key_batch frames."""
         assert H % 112 == 0 and W % 112 == 0, "frames are padded to multiples of 112 (inference_core.py:49)"
         sd, b = self.sd, _Builder()
         b.auto_split = os.environ.get("HAVC_CMN_SPLITK", "1") != "0"       # A/B switch (profiling)
@@ -320,8 +322,9 @@ class ColorMNetPlan:
         def mark(name, first, batch):
             sl[name] = (first, len(b.ops) - first, batch)
 
-        # ================= slice "key": encode_key, one frame =================
+        # ================= slice "key": encode_key, one frame (key_batch frames for the look-ahead plan) =================
         s0 = len(b.ops)
+        b.slice_batch = key_batch
         x0 = b.tensor(H, W, 3)
         b.planar_in("frame", fbuf("image", 3 * H * W), 3, x0)
         f4, f8, f16 = self._trunk(b, "key_encoder", x0, "bottleneck", ("res2", "layer2", "layer3"))
@@ -349,7 +352,7 @@ class ColorMNetPlan:
         b.planar_out(kp + ".key", kpo, 0, CK, fbuf("key", CK * P16), 0)
         b.planar_out(kp + ".selection", kpo, CK, CK, fbuf("selection", CK * P16), 2)
         b.planar_out(kp + ".shrinkage", kpo, 2 * CK, 1, fbuf("shrinkage", P16), 1)
-        mark("key", s0, 1)
+        mark("key", s0, key_batch)
 
         # ================= slice "value": encode_value, one frame per object =================
         s0 = len(b.ops)
@@ -515,6 +518,8 @@ class ColorMNetNetwork:
         self.device = torch.device("cuda", device_index)
         self.stream = torch.cuda.ExternalStream(self.ctx.stream_ptr(), device=self.device)
         self.nets = {}
+        import collections
+        self._ahead, self._armed = collections.deque(), False
         self.autotune = (os.environ.get("HAVC_AUTOTUNE", "1") != "0") if autotune is None else autotune
         sd = self.plan.sd
         ws2 = (2 * MAX_DIS + 1) ** 2
@@ -541,9 +546,25 @@ class ColorMNetNetwork:
             self.nets[key] = n
         return self.nets[key]
 
-    def _run(self, net, name):
-        first, count, batch = net.slices[name]
-        net.enqueue_ops(first, count, batch)
+    def _key_net(self, H, W, B):
+        """the look-ahead plan: the same ops with the key slice laid out (and its split-K counts chosen) for B frames per launch"""
+        key = (H, W, "key", B)
+        if key not in self.nets:
+            ops, bufs, names, consts, sl, io = self.plan.plan(H, W, key_batch=B)
+            n = nat.Net(self.ctx, self.weights, ops, bufs, 0, 0, H, max(B, 2))
+            n.names, n.plan_ops, n.slices, n.io = names, ops, sl, io
+            for buf, arr, pitch, rows in consts:
+                a = np.zeros((max(B, 2), rows, pitch), np.float16)
+                a[:, :arr.shape[0], :arr.shape[1]] = arr.astype(np.float16)[None]
+                n.upload(buf, a)
+            if self.autotune:
+                n.autotune(B)
+            self.nets[key] = n
+        return self.nets[key]
+
+    def _run(self, net, name, batch=None):
+        first, count, b = net.slices[name]
+        net.enqueue_ops(first, count, b if batch is None else batch)
 
     def _new(self, *shape, dtype=None):
         import torch
@@ -554,10 +575,49 @@ class ColorMNetNetwork:
         pitch = int(net.bufs[net.io[name]]["elems_per_frame"]) // rows
         return torch.empty(rows * pitch + 128, dtype=torch.float16, device=self.device)     # + slack: vector loads may touch the tail
 
+    # ---- look-ahead: encode_key of the next frames of a clip in ONE batched pass (nothing in encode_key depends on the memory) ----
+    def prefetch_keys(self, frames, max_batch=None):
+        """frames: list of [3, H, W] device tensors, padded as InferenceCore pads them (pad_divide_by 112), in the order in which they will be
+        stepped.  Their keys / features wait in a FIFO; `expect_prefetched()` arms the next encode_key call to take the front entry."""
+        import torch
+        if not frames:
+            return
+        B = len(frames)
+        H, W = frames[0].shape[-2:]
+        net = self._key_net(H, W, max_batch or B)
+        h, w = H // 16, W // 16
+        with self.on_stream():
+            img = torch.stack([f.to(self.device, torch.float32) for f in frames], 0).contiguous()
+            key, sel, shr = self._new(B, self.key_dim, h, w), self._new(B, self.key_dim, h, w), self._new(B, 1, h, w)
+            big, epf = {}, {}
+            for name, rows in (("g16", h * w), ("g8", 4 * h * w), ("g4", 16 * h * w)):
+                epf[name] = int(net.bufs[net.io[name]]["elems_per_frame"])
+                big[name] = torch.empty(B * epf[name] + 128, dtype=torch.float16, device=self.device)
+            for name, t in (("image", img), ("key", key), ("selection", sel), ("shrinkage", shr), ("g16", big["g16"]), ("g8", big["g8"]), ("g4", big["g4"])):
+                net.bind(net.io[name], t.data_ptr())
+            self._run(net, "key", B)
+            for i in range(B):
+                f = _Feat(*(big[n_][i * epf[n_]:(i + 1) * epf[n_] + 128] for n_ in ("g16", "g8", "g4")), (H, W))
+                self._ahead.append((key[i:i + 1], shr[i:i + 1], sel[i:i + 1], f))
+            self._keep_ahead = (img,)
+
+    def expect_prefetched(self):
+        """the NEXT encode_key call is for the frame at the front of the prefetch FIFO (InferenceCore encodes the frame first, then an exemplar)"""
+        self._armed = bool(self._ahead)
+
+    def drop_prefetched(self):
+        if self._ahead:
+            self._ahead.popleft()
+
     # ---- network.py:52-85 ----
     def encode_key(self, frame, need_ek=True, need_sk=True):
         import torch
         assert frame.dim() == 4 and frame.shape[0] == 1, "one frame [1, 3, H, W]"
+        if self._armed:
+            self._armed = False
+            key, shr, sel, f = self._ahead.popleft()
+            if f.shape == tuple(frame.shape[-2:]):
+                return key, (shr if need_sk else None), (sel if need_ek else None), f, f, f
         H, W = frame.shape[-2:]
         net = self._net(H, W)
         h, w = H // 16, W // 16

@@ -15,6 +15,7 @@ Sequential in time by nature (every frame reads what the previous ones wrote) =>
 image_size: the reference's HAVC entry points always pass -1 (vsdeoldify/__init__.py:1700,1712; the clip is resized beforehand by
 SmartResizeColorizer, vsslib/vsresize.py:271-316); image_size >= 0 (torchvision Resize inside the transform) is refused.
 """
+import collections
 import os
 
 import numpy as np
@@ -66,7 +67,7 @@ class ColorMNetRender:
     """renders one frame at a time (colormnet_render.py:47)"""
 
     def __init__(self, image_size=-1, vid_length=None, enable_resize=False, encode_mode=None, propagate=False, max_memory_frames=None,
-                 reset_on_ref_update=True, project_dir=None, state_dict=None, device_index=0, network=None, memory_backend=None):
+                 reset_on_ref_update=True, project_dir=None, state_dict=None, device_index=0, network=None, memory_backend=None, lookahead=None):
         if image_size is not None and image_size >= 0:
             raise NotImplementedError("image_size >= 0 (resize inside the transform) is never used by HAVC (vsdeoldify/__init__.py:1700)")
         if vid_length is None:
@@ -82,6 +83,9 @@ class ColorMNetRender:
         self.total_colored_frames = self.frame_count = self.ref_count = self.ref_count_prv = 0
         self.ref_img = self.ref_img_valid = self.img = None
         self.first_mask_loaded = False
+        # frames per batched key-encoder pass when the caller announces frames ahead (colorize_batch_frames / prefetch); 1 = off
+        self.lookahead = int(os.environ.get("HAVC_CMN_LOOKAHEAD", "8")) if lookahead is None else int(lookahead)
+        self._ahead = collections.deque()
         self.device_index, self._memory_backend = device_index, memory_backend          # memory_backend: CPU tests of the state machine only
         self.network = network if network is not None else _load_network(self.project_dir, state_dict, device_index)
         self.config = default_config(vid_length, self.max_memory_frames, propagate)
@@ -102,11 +106,28 @@ class ColorMNetRender:
             self.ref_count = self.frame_count
 
     def colorize_batch_frames(self, frame_list=None, ref_list=None, frame_propagate=False):
+        """colormnet_render.py:186-195.  The list is known up front, so the key encoder runs `lookahead` frames at a time ahead of the
+        sequential step (prefetch): encode_key does not depend on the memory."""
         out = []
         for i, (frame_i, ref_i) in enumerate(zip(frame_list, ref_list)):
+            if self.lookahead > 1 and i % self.lookahead == 0:
+                self.prefetch(frame_list[i:i + self.lookahead])
             self.set_ref_frame(ref_i, frame_propagate)
             out.append(self.colorize_frame(i, frame_i))
         return out
+
+    def prefetch(self, frames):
+        """Look-ahead for frames that WILL be passed to colorize_frame next, in this order (the very same objects): their Lab planes and their
+        keys / image features are computed now, in one batched pass of the key encoder."""
+        from .device import is_device
+        from .colormnet_core import pad_divide_by, DIVIDE_BY
+        if not hasattr(self.network, "prefetch_keys") or len(frames) < 2:
+            return
+        with self.network.on_stream():
+            labs = [self.network.image_to_lab(f if is_device(f) else np.asarray(f)) for f in frames]
+            self.network.prefetch_keys([pad_divide_by(lab[:1].repeat(3, 1, 1), DIVIDE_BY)[0] for lab in labs], max_batch=self.lookahead)
+        for f, lab in zip(frames, labs):
+            self._ahead.append((f, lab))
 
     def get_frame_count(self):
         return self.frame_count
@@ -131,13 +152,20 @@ class ColorMNetRender:
             ref = self.ref_img
             self.frame_count += 1
         as_lab = lambda im: self.network.image_to_lab(im if is_device(im) else np.asarray(im))
-        lab = as_lab(frame_i)                                           # [3,H,W] normalised Lab on the device (get_image :285-301)
+        ahead = bool(self._ahead) and self._ahead[0][0] is frame_i       # this frame went through prefetch(): its Lab planes and its key are waiting
+        if self._ahead and not ahead:                                   # the caller left the announced order: forget the look-ahead
+            while self._ahead:
+                self._ahead.popleft()
+                self.network.drop_prefetched()
+        lab = self._ahead.popleft()[1] if ahead else as_lab(frame_i)    # [3,H,W] normalised Lab on the device (get_image :285-301)
         rgb = lab[:1].repeat(3, 1, 1)
         msk = as_lab(ref) if ref is not None else None
         if msk is not None and not self.config["FirstFrameIsNotExemplar"]:
             msk = msk[1:3]
         if not self.first_mask_loaded:
             if msk is None:
+                if ahead:
+                    self.network.drop_prefetched()
                 return frame_i                                          # nothing to propagate from yet
             self.first_mask_loaded = True
         labels = None
@@ -145,6 +173,8 @@ class ColorMNetRender:
             self.processor.set_all_labels(list(range(1, 3)))
             labels = range(1, 3)
         is_last = self.vid_length == self.total_colored_frames - 1
+        if ahead:
+            self.network.expect_prefetched()                            # the step's first encode_key call is for this frame
         if self.config["FirstFrameIsNotExemplar"]:
             if msk is None:
                 prob = self.processor.step_AnyExemplar(rgb, None, None, labels, end=is_last)
@@ -205,18 +235,24 @@ class DeepExColorMNet:
             img = np.pad(a, ((ph, ph), (pw, pw), (0, 0)))                  # std.AddBorders: black
         return spline64(self.ctx, img, self.tw, self.th), (ph, pw)
 
-    def colorize_frame(self, frame, ref=None):
-        """frame: u8 [h, w, 3] (ndarray or DeviceImage); ref: the reference image for THIS frame (same size as the clip) or None"""
+    def _small(self, frame):
+        """the frame as ColorMNetRender gets it (DeviceImage, or a PIL image) + the borders that were added"""
         from PIL import Image
+        from .device import is_device
+        small, pads = self._squash(frame)
+        return (small if is_device(small) else Image.fromarray(small)), pads
+
+    def colorize_frame(self, frame, ref=None, _small=None):
+        """frame: u8 [h, w, 3] (ndarray or DeviceImage); ref: the reference image for THIS frame (same size as the clip) or None"""
         from .device import is_device
         from .havc import spline64
         h, w = frame.shape[:2]
-        small, (ph, pw) = self._squash(frame)
+        small, (ph, pw) = _small if _small is not None else self._small(frame)
         if ref is not None:
             rs, _ = self._squash(ref)
             ref = rs if is_device(rs) else np.asarray(rs)
         self.render.set_ref_frame(ref, self.propagate)
-        col = self.render.colorize_frame(self.t, small if is_device(small) else Image.fromarray(small))
+        col = self.render.colorize_frame(self.t, small)
         self.t += 1
         col = col if is_device(col) else np.asarray(col)
         if ph or pw:                                                         # restore_clip_size: Spline64 to the bordered size, crop, then the luma
@@ -226,6 +262,19 @@ class DeepExColorMNet:
             return F.chroma_post_process_np(self.ctx, np.ascontiguousarray(up), frame.numpy() if is_device(frame) else np.asarray(frame))
         return spline64(self.ctx, col, w, h, luma_from=frame)
 
+    def colorize_frames(self, frames, refs):
+        """frames: a sequence of u8 [h, w, 3] frames (ndarrays or DeviceImages); refs: {index: reference image} -> list of coloured frames.
+        The frames are known up front: they are squashed `lookahead` at a time and announced to the render (ColorMNetRender.prefetch), whose
+        key encoder then runs that many frames per pass while the memory step stays frame by frame."""
+        out, L = [], max(1, self.render.lookahead)
+        for i0 in range(0, len(frames), L):
+            chunk = [frames[i] for i in range(i0, min(i0 + L, len(frames)))]
+            smalls = [self._small(f) for f in chunk]
+            if L > 1:
+                self.render.prefetch([s for s, _ in smalls])
+            out.extend(self.colorize_frame(f, refs.get(i0 + j), _small=smalls[j]) for j, f in enumerate(chunk))
+        return out
+
     def colorize_clip(self, clip, refs):
         """clip: u8 [n, h, w, 3]; refs: {frame index: reference image}; -> u8 [n, h, w, 3]"""
-        return np.stack([np.asarray(self.colorize_frame(f, refs.get(i))) for i, f in enumerate(clip)])
+        return np.stack([np.asarray(o) for o in self.colorize_frames(clip, refs)])

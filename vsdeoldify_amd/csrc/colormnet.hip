@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) mem_similarity_kernel(const float* __rest
 // read with consecutive threads on consecutive queries (coalesced rows); the running top-k set lives in LDS ([k][thread]) with
 // its minimum cached in registers.  Output: idx [B][k][HW], w [B][k][HW] (w = exp(v) / sum exp(v), no max subtraction: the
 // reference's top-k branch has none). ----
-constexpr int TOPK_MAX = 64, TOPK_THREADS = 64, TOPK_MAXSPLIT = 64;
+constexpr int TOPK_MAX = 64, TOPK_THREADS = 64, TOPK_MAXSPLIT = 128, TOPK_SLICE = 64;
 // Two levels, so that the scan of the N memory elements is spread over the chip (one thread per query alone is HW / 64 = 26 blocks at
 // 30 x 54 features): level 1 = block (64 queries, one slice of the memory axis) keeps the slice's top-k per query; level 2 = the same
 // selection over the S x k survivors, then the softmax weights.  SRC_IDX: the values come with their memory indices (level 2).
@@ -98,30 +98,66 @@ __global__ void __launch_bounds__(TOPK_THREADS) mem_topk_kernel(const float* __r
     const int first = cnt < K ? cnt : K;
     float vmin = INFINITY;
     int pmin = 0;
-    for (int j = 0; j < first; ++j) {
-        const float v = s[(int64_t)(n0 + j) * HW];
-        val[j * TOPK_THREADS + t] = v;
-        ind[j * TOPK_THREADS + t] = SRC_IDX ? si[(int64_t)(n0 + j) * HW] : n0 + j;
-        if (v < vmin) { vmin = v; pmin = j; }
+    for (int jb = 0; jb < first; jb += 8) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = jb + u < first ? s[(int64_t)(n0 + jb + u) * HW] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int j = jb + u;
+            if (j >= first) break;
+            const float v = v8[u];
+            val[j * TOPK_THREADS + t] = v;
+            ind[j * TOPK_THREADS + t] = SRC_IDX ? si[(int64_t)(n0 + j) * HW] : n0 + j;
+            if (v < vmin) { vmin = v; pmin = j; }
+        }
     }
     for (int j = first; j < K; ++j) { val[j * TOPK_THREADS + t] = -INFINITY; ind[j * TOPK_THREADS + t] = 0; }
-    for (int n = n0 + first; n < n1; ++n) {
-        const float v = s[(int64_t)n * HW];
-        if (v > vmin) {                                             // replace the current minimum, then find the new one
-            val[pmin * TOPK_THREADS + t] = v;
-            ind[pmin * TOPK_THREADS + t] = SRC_IDX ? si[(int64_t)n * HW] : n;
-            vmin = INFINITY;
-            for (int j = 0; j < K; ++j) {
-                const float u = val[j * TOPK_THREADS + t];
-                if (u < vmin) { vmin = u; pmin = j; }
+    for (int nb = n0 + first; nb < n1; nb += 8) {                  // 8 similarity rows in flight (one dependent load per element was 238 us of a 2.2 ms frame)
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v8[u] = nb + u < n1 ? s[(int64_t)(nb + u) * HW] : -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float v = v8[u];
+            const int n = nb + u;
+            if (n < n1 && v > vmin) {                               // replace the current minimum, then find the new one
+                val[pmin * TOPK_THREADS + t] = v;
+                ind[pmin * TOPK_THREADS + t] = SRC_IDX ? si[(int64_t)n * HW] : n;
+                vmin = INFINITY;
+                for (int j0 = 0; j0 < K; j0 += 8) {                 // 8 LDS reads in flight, then the compares in order (first minimum wins, as before)
+                    float w8[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) w8[jj] = j0 + jj < K ? val[(j0 + jj) * TOPK_THREADS + t] : INFINITY;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj)
+                        if (w8[jj] < vmin) { vmin = w8[jj]; pmin = j0 + jj; }
+                }
             }
         }
     }
-    if (!FINAL) {                                                   // survivors of this slice, query-major: [B][HW][S * K]
-        for (int j = 0; j < K; ++j) {
-            const int64_t o = ((int64_t)b * HW + q) * ((int64_t)S * K) + (int64_t)sl * K + j;
-            wgt[o] = val[j * TOPK_THREADS + t];                     // -inf marks an empty slot
-            idx[o] = ind[j * TOPK_THREADS + t];
+    if (!FINAL) {                                                   // survivors of this slice, query-major: [B][HW][S * K], in DESCENDING order
+        // (the merge then only ever compares the heads of the slices).  K rounds of arg-max over the K kept values, 8 LDS reads in flight;
+        // equal values leave in ascending memory index, i.e. as a single scan would rank them.
+        for (int r = 0; r < K; ++r) {
+            float best = -INFINITY;
+            int bj = -1, bi = 0x7fffffff;
+            for (int j0 = 0; j0 < K; j0 += 8) {
+                float w8[8];
+                int i8[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    w8[jj] = j0 + jj < K ? val[(j0 + jj) * TOPK_THREADS + t] : -INFINITY;
+                    i8[jj] = j0 + jj < K ? ind[(j0 + jj) * TOPK_THREADS + t] : 0x7fffffff;
+                }
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj)
+                    if (w8[jj] > best || (w8[jj] == best && w8[jj] != -INFINITY && i8[jj] < bi)) { best = w8[jj]; bj = j0 + jj; bi = i8[jj]; }
+            }
+            const int64_t o = ((int64_t)b * HW + q) * ((int64_t)S * K) + (int64_t)sl * K + r;
+            wgt[o] = best;                                          // -inf marks an empty slot
+            idx[o] = bj >= 0 ? bi : 0;
+            if (bj >= 0) val[bj * TOPK_THREADS + t] = -INFINITY;
         }
         return;
     }
@@ -139,8 +175,9 @@ __global__ void __launch_bounds__(TOPK_THREADS) mem_topk_kernel(const float* __r
     }
 }
 
-// level 2: one wave per query picks the K largest of its M = S * K survivors (K rounds of a wave-wide arg-max over the LDS copy; ties go
-// to the earlier slice, as in a single scan) and turns them into softmax weights.
+// level 2: one wave per query merges the S slices, each sorted in descending order: lane l holds the heads of slices l and l + 64, a round is
+// one wave-wide arg-max over the heads (ties go to the earlier slice, as in a single scan) and the winning slice advances; then the softmax
+// weights.  (Round 2's merge re-scanned all S * K survivors in every round; with 64-element slices that would be 2 000 values x 30 rounds.)
 __global__ void __launch_bounds__(64) mem_topk_merge_kernel(const float* __restrict__ cand_val, const int* __restrict__ cand_idx, int* __restrict__ idx,
                                                             float* __restrict__ wgt, int M, int HW, int K) {
     extern __shared__ float sh[];
@@ -148,30 +185,34 @@ __global__ void __launch_bounds__(64) mem_topk_merge_kernel(const float* __restr
     int* ci = reinterpret_cast<int*>(sh + M);
     __shared__ float sel_v[TOPK_MAX];
     __shared__ int sel_i[TOPK_MAX];
-    const int q = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+    const int q = blockIdx.x, b = blockIdx.y, lane = threadIdx.x, S = M / K;
     const int64_t base = ((int64_t)b * HW + q) * M;
     for (int i = lane; i < M; i += 64) { cv[i] = cand_val[base + i]; ci[i] = cand_idx[base + i]; }
     __syncthreads();
+    int h0 = 0, h1 = 0;                                             // heads of slices lane and lane + 64
     for (int k = 0; k < K; ++k) {
-        float best = -INFINITY;
-        int pos = M;
-        for (int i = lane; i < M; i += 64) {
-            const float v = cv[i];
-            if (v > best) { best = v; pos = i; }                    // ascending i: the earliest of equal values
-        }
+        const float v0 = (lane < S && h0 < K) ? cv[lane * K + h0] : -INFINITY;
+        const float v1 = (lane + 64 < S && h1 < K) ? cv[(lane + 64) * K + h1] : -INFINITY;
+        float best = v1 > v0 ? v1 : v0;
+        int pos = v1 > v0 ? (lane + 64) * K + h1 : lane * K + h0;
+        if (best == -INFINITY) pos = M;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float ov = __shfl_xor(best, o);
             const int op = __shfl_xor(pos, o);
             if (ov > best || (ov == best && op < pos)) { best = ov; pos = op; }
         }
+        if (pos < M) {
+            const int sw = pos / K;
+            if (sw == lane) ++h0;
+            else if (sw == lane + 64) ++h1;
+        }
         if (lane == 0) {
             sel_v[k] = best;
             sel_i[k] = pos < M ? ci[pos] : 0;
-            if (pos < M) cv[pos] = -INFINITY;
         }
-        __syncthreads();
     }
+    __syncthreads();
     const float v = lane < K ? sel_v[lane] : -INFINITY;
     const float e = v == -INFINITY ? 0.f : expf(v);                // exp(v) / sum exp(v), no max subtraction (memory_util.py:44-47)
     float sum = e;
@@ -291,63 +332,68 @@ int launch_mem_dense_readout(const float* sim, const float* mv, float* out, int 
 namespace {
 
 // ---- local correlation (attention.py:827-835): out[n][(dy+R)*ws+(dx+R)][y*w+x] = sum_c q[n][c][y][x] k[n][c][y+dy*dil][x+dx*dil] ----
-// Block = 8 x 8 query pixels; K halo tile ((8 + 2 R dil)^2 pixels) staged in LDS 16 channels at a time; thread = pixel p (tid & 63)
-// and a quarter of the window rows (tid >> 6): for its rows dy it keeps the ws accumulators of one row at a time.
-constexpr int LC_T = 8, LC_CC = 16, LC_MAXWS = 15;     // window up to 15 x 15 (max_dis 7): 4 row-quarters x 15 accumulators per thread
+// Block = (8 x 8 query pixels, ONE window row dy): thread = pixel p (tid & 63) x a group of 4 window columns (tid >> 6), channels summed in
+// ascending order.  The K rows the window row touches (8 rows x (8 + 2 R dil) columns) and the Q tile are staged in LDS LC_CC channels at a
+// time.  Round 3: the window rows are spread over the grid -- a 28 x 14 feature map is 8 tiles, and 8 blocks of 4 waves walking all 225
+// offsets took 155 us of a 2.2 ms ColorMNet frame; 8 x 15 blocks take a tenth of that.
+constexpr int LC_T = 8, LC_CC = 64, LC_MAXWS = 16;     // window up to 16 x 16 columns (max_dis 7: 15): 4 column groups x 4 accumulators per thread
 __global__ void __launch_bounds__(256) local_corr_kernel(const float* __restrict__ q, const float* __restrict__ k, float* __restrict__ out, int C, int H,
                                                          int W, int R, int dil, float qscale) {
-    extern __shared__ float lds[];                                  // k tile [LC_CC][HT][HT + 1], q tile [LC_CC][64]
+    extern __shared__ float lds[];                                  // k rows [LC_CC][8][HT + 1], q tile [LC_CC][64]
     const int ws = 2 * R + 1, HT = LC_T + 2 * R * dil, HP = HT + 1;
     float* kt = lds;
-    float* qt = lds + LC_CC * HT * HP;
-    const int n = blockIdx.z, ty0 = blockIdx.y * LC_T, tx0 = blockIdx.x * LC_T;
-    const int tid = threadIdx.x, p = tid & 63, py = p >> 3, px = p & 7, part = tid >> 6;
+    float* qt = lds + LC_CC * LC_T * HP;
+    const int n = blockIdx.z / ws, dyi = blockIdx.z % ws, ty0 = blockIdx.y * LC_T, tx0 = blockIdx.x * LC_T;
+    const int tid = threadIdx.x, p = tid & 63, py = p >> 3, px = p & 7, grp = tid >> 6;
     const int y = ty0 + py, x = tx0 + px;
     const float* qb = q + (int64_t)n * C * H * W;
     const float* kb = k + (int64_t)n * C * H * W;
     float* ob = out + (int64_t)n * ws * ws * H * W;
-    // thread `part` owns window rows dy = part, part + 4, ... (at most 4 of the 15): all of their accumulators stay in registers
-    // while the K halo is staged ONCE per 16-channel chunk (uniform trip counts: every thread reaches every barrier)
-    float acc[4][LC_MAXWS];
-#pragma unroll
-    for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int j = 0; j < LC_MAXWS; ++j) acc[it][j] = 0.f;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int row0 = ty0 + (dyi - R) * dil;                         // image row of the K row that pixel row 0 of the tile reads
     for (int c0 = 0; c0 < C; c0 += LC_CC) {
         __syncthreads();
-        for (int i = tid; i < LC_CC * HT * HT; i += 256) {
-            const int c = i / (HT * HT), r = i - c * HT * HT, hy = r / HT, hx = r - hy * HT;
-            const int iy = ty0 - R * dil + hy, ix = tx0 - R * dil + hx;
-            kt[(c * HT + hy) * HP + hx] = (c0 + c < C && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? kb[((int64_t)(c0 + c) * H + iy) * W + ix] : 0.f;
+        for (int i0 = tid; i0 < LC_CC * LC_T * HT; i0 += 256 * 8) {                      // 8 loads in flight per thread
+            float v[8];
+            int dst[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                const int c = i / (LC_T * HT), r = i - c * (LC_T * HT), hy = r / HT, hx = r - hy * HT;
+                const int iy = row0 + hy, ix = tx0 - R * dil + hx;
+                dst[u] = i < LC_CC * LC_T * HT ? (c * LC_T + hy) * HP + hx : -1;
+                v[u] = (dst[u] >= 0 && c0 + c < C && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? kb[((int64_t)(c0 + c) * H + iy) * W + ix] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (dst[u] >= 0) kt[dst[u]] = v[u];
         }
-        for (int i = tid; i < LC_CC * 64; i += 256) {
-            const int c = i >> 6, pp = i & 63, yy = ty0 + (pp >> 3), xx = tx0 + (pp & 7);
-            qt[i] = (c0 + c < C && yy < H && xx < W) ? qb[((int64_t)(c0 + c) * H + yy) * W + xx] * qscale : 0.f;
+        for (int i0 = tid; i0 < LC_CC * 64; i0 += 256 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + u * 256;
+                const int c = i >> 6, pp = i & 63, yy = ty0 + (pp >> 3), xx = tx0 + (pp & 7);
+                v[u] = (i < LC_CC * 64 && c0 + c < C && yy < H && xx < W) ? qb[((int64_t)(c0 + c) * H + yy) * W + xx] * qscale : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * 256 < LC_CC * 64) qt[i0 + u * 256] = v[u];
         }
         __syncthreads();
+        const float* krow = kt + py * HP + px + grp * 4 * dil;
+#pragma unroll 4
         for (int c = 0; c < LC_CC; ++c) {
             const float qv = qt[c * 64 + p];
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int dyi = it * 4 + part;
-                if (dyi < ws) {
-                    const float* krow = kt + (c * HT + py + dyi * dil) * HP + px;
-#pragma unroll
-                    for (int j = 0; j < LC_MAXWS; ++j)
-                        if (j < ws) acc[it][j] += qv * krow[j * dil];
-                }
-            }
+            for (int j = 0; j < 4; ++j)
+                if (grp * 4 + j < ws) acc[j] += qv * krow[c * LC_T * HP + j * dil];
         }
     }
     if (y < H && x < W) {
 #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int dyi = it * 4 + part;
-            if (dyi >= ws) continue;
-#pragma unroll
-            for (int j = 0; j < LC_MAXWS; ++j)
-                if (j < ws) ob[((int64_t)(dyi * ws + j) * H + y) * W + x] = acc[it][j];
-        }
+        for (int j = 0; j < 4; ++j)
+            if (grp * 4 + j < ws) ob[((int64_t)(dyi * ws + grp * 4 + j) * H + y) * W + x] = acc[j];
     }
 }
 
@@ -426,14 +472,33 @@ __global__ void __launch_bounds__(256) local_agg_kernel(const float* __restrict_
     const int n = blockIdx.z, ty0 = (blockIdx.x / tiles_x) * LC_T, tx0 = (blockIdx.x % tiles_x) * LC_T, c0 = blockIdx.y * LA_CC;
     const int tid = threadIdx.x, p = tid & 63, py = p >> 3, px = p & 7, cg = tid >> 6;
     const float* vb = v + (int64_t)n * CV * HWp;
-    for (int i = tid; i < LA_CC * HT * HT; i += 256) {
-        const int c = i / (HT * HT), r = i - c * HT * HT, hy = r / HT, hx = r - hy * HT;
-        const int iy = ty0 - R * dil + hy, ix = tx0 - R * dil + hx;
-        vt[(c * HT + hy) * HP + hx] = (c0 + c < CV && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? vb[((int64_t)(c0 + c) * H + iy) * W + ix] : 0.f;
+    // staging with 8 loads in flight per thread (see local_corr_kernel)
+    for (int i0 = tid; i0 < LA_CC * HT * HT; i0 += 256 * 8) {
+        float vv[8];
+        int dst[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            const int c = i / (HT * HT), r = i - c * HT * HT, hy = r / HT, hx = r - hy * HT;
+            const int iy = ty0 - R * dil + hy, ix = tx0 - R * dil + hx;
+            dst[u] = i < LA_CC * HT * HT ? (c * HT + hy) * HP + hx : -1;
+            vv[u] = (dst[u] >= 0 && c0 + c < CV && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) ? vb[((int64_t)(c0 + c) * H + iy) * W + ix] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (dst[u] >= 0) vt[dst[u]] = vv[u];
     }
-    for (int i = tid; i < WW * 64; i += 256) {
-        const int d = i >> 6, pp = i & 63, yy = ty0 + (pp >> 3), xx = tx0 + (pp & 7);
-        at[i] = (yy < H && xx < W) ? attn[((int64_t)n * WW + d) * HWp + yy * W + xx] : 0.f;
+    for (int i0 = tid; i0 < WW * 64; i0 += 256 * 8) {
+        float vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256;
+            const int d = i >> 6, pp = i & 63, yy = ty0 + (pp >> 3), xx = tx0 + (pp & 7);
+            vv[u] = (i < WW * 64 && yy < H && xx < W) ? attn[((int64_t)n * WW + d) * HWp + yy * W + xx] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (i0 + u * 256 < WW * 64) at[i0 + u * 256] = vv[u];
     }
     __syncthreads();
     const int y = ty0 + py, x = tx0 + px;
@@ -466,7 +531,7 @@ int launch_mem_similarity(const float* mk, const float* ms, const float* qk, con
 }
 
 int mem_topk_splits(int N) {                                  // slices of the memory axis at level 1 (1 = single level)
-    const int S = (N + 255) / 256;
+    const int S = (N + TOPK_SLICE - 1) / TOPK_SLICE;          // 64 elements per slice while that gives <= 128 slices (the merge holds two heads per lane)
     return S < 2 ? 1 : (S > TOPK_MAXSPLIT ? TOPK_MAXSPLIT : S);
 }
 // cand_val / cand_idx: workspace of B * S * K * HW floats / ints each (S = mem_topk_splits(N)); unused when S == 1
@@ -492,9 +557,9 @@ int launch_mem_topk_readout(const float* sim, const float* mv, int* idx, float* 
 int launch_local_correlation(const float* q, const float* k, float* out, int n, int C, int H, int W, int R, int dil, float qscale, hipStream_t s) {
     const int ws = 2 * R + 1, HT = LC_T + 2 * R * dil;
     if (ws > LC_MAXWS || R < 0 || dil < 1) return (int)hipErrorInvalidValue;
-    const size_t lds = (size_t)(LC_CC * HT * (HT + 1) + LC_CC * 64) * sizeof(float);
+    const size_t lds = (size_t)(LC_CC * LC_T * (HT + 1) + LC_CC * 64) * sizeof(float);
     if (lds > 64 * 1024) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(local_corr_kernel, dim3(cdiv(W, LC_T), cdiv(H, LC_T), n), dim3(256), lds, s, q, k, out, C, H, W, R, dil, qscale);
+    hipLaunchKernelGGL(local_corr_kernel, dim3(cdiv(W, LC_T), cdiv(H, LC_T), n * ws), dim3(256), lds, s, q, k, out, C, H, W, R, dil, qscale);
     return (int)hipGetLastError();
 }
 

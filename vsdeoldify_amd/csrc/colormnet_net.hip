@@ -372,44 +372,61 @@ int launch_mha64(const half_t* qkv, int cp, int q_co, int k_co, int v_co, int to
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// CBAM channel gate: one block per frame.  avg / max over the pixels per channel, the shared MLP on both, sigmoid -> scale[C] (fp32).
-__global__ void __launch_bounds__(512) cbam_channel_kernel(const half_t* __restrict__ x, int cp, int co, int64_t fs, int P, int C, int Ch,
-                                                           const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
-                                                           const float* __restrict__ b2, float* __restrict__ scale) {
-    extern __shared__ float sm[];                                 // avg[C], mx[C], hid[2 * Ch]
-    float* avg = sm; float* mxs = sm + C; float* hid = sm + 2 * C;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const half_t* xb = x + (int64_t)b * fs + co;
-    for (int c = tid; c < C; c += blockDim.x) {
-        float s0 = 0.f, s1 = 0.f, m0 = -INFINITY, m1 = -INFINITY;
-        int p = 0;
-        for (; p + 1 < P; p += 2) {
-            const float a0 = (float)xb[(int64_t)p * cp + c], a1 = (float)xb[(int64_t)(p + 1) * cp + c];
+// CBAM channel gate.  gate[b] = [scale C | avg C | max C] (fp32, frame stride gfs = 3 C).
+// (1) pool: one block per (64 channels, frame): 8 pixel lanes x 64 channels, the lanes' partial sums / maxima combined in a fixed order.
+//     (One block per FRAME took 104 us of a 2.2 ms ColorMNet frame: 2 blocks on 256 CUs walking 392 pixels one after the other.)
+__global__ void __launch_bounds__(512) cbam_pool_kernel(const half_t* __restrict__ x, int cp, int co, int64_t fs, int P, int C, float* __restrict__ gate,
+                                                        int64_t gfs) {
+    __shared__ float ssum[8][64], smax[8][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    const half_t* xb = x + (int64_t)b * fs + co + c;
+    float s0 = 0.f, s1 = 0.f, m0 = -INFINITY, m1 = -INFINITY;
+    if (c < C) {
+        int p = pl;
+        for (; p + 8 < P; p += 16) {
+            const float a0 = (float)xb[(int64_t)p * cp], a1 = (float)xb[(int64_t)(p + 8) * cp];
             s0 += a0; s1 += a1; m0 = fmaxf(m0, a0); m1 = fmaxf(m1, a1);
         }
-        if (p < P) { const float a0 = (float)xb[(int64_t)p * cp + c]; s0 += a0; m0 = fmaxf(m0, a0); }
-        avg[c] = (s0 + s1) / (float)P;
-        mxs[c] = fmaxf(m0, m1);
+        if (p < P) { const float a0 = (float)xb[(int64_t)p * cp]; s0 += a0; m0 = fmaxf(m0, a0); }
     }
+    ssum[pl][threadIdx.x & 63] = s0 + s1;
+    smax[pl][threadIdx.x & 63] = fmaxf(m0, m1);
     __syncthreads();
-    for (int t = tid; t < 2 * Ch; t += blockDim.x) {
+    if (pl == 0 && c < C) {
+        float sm_ = 0.f, mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sm_ += ssum[i][threadIdx.x]; mx = fmaxf(mx, smax[i][threadIdx.x]); }
+        gate[(int64_t)b * gfs + C + c] = sm_ / (float)P;
+        gate[(int64_t)b * gfs + 2 * C + c] = mx;
+    }
+}
+
+// (2) the shared MLP on both pooled vectors, sigmoid -> scale[C]: one block per frame, one wave per hidden unit (coalesced rows of w1)
+__global__ void __launch_bounds__(512) cbam_mlp_kernel(int C, int Ch, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                       const float* __restrict__ b2, float* __restrict__ gate, int64_t gfs) {
+    extern __shared__ float hid[];                                // [2 * Ch]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* g = gate + (int64_t)b * gfs;
+    for (int t = wave; t < 2 * Ch; t += 8) {
         const int kk = t % Ch;
-        const float* v = t < Ch ? avg : mxs;
-        float acc = b1[kk];
-        for (int c = 0; c < C; ++c) acc += w1[kk * C + c] * v[c];
-        hid[t] = fmaxf(acc, 0.f);
+        const float* v = g + (t < Ch ? C : 2 * C);
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc += w1[kk * C + c] * v[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) hid[t] = fmaxf(acc + b1[kk], 0.f);
     }
     __syncthreads();
     for (int c = tid; c < C; c += blockDim.x) {
         float acc = 2.f * b2[c];
         for (int kk = 0; kk < Ch; ++kk) acc += w2[c * Ch + kk] * (hid[kk] + hid[Ch + kk]);
-        scale[(int64_t)b * C + c] = 1.f / (1.f + __expf(-acc));
+        g[c] = 1.f / (1.f + __expf(-acc));
     }
 }
 
 // spatial pool: one wave per pixel: max_c and mean_c of x * scale -> comp[B][P][2]
 __global__ void cbam_spatial_pool_kernel(const half_t* __restrict__ x, int cp, int co, int64_t fs, int B, int P, int C, const float* __restrict__ scale,
-                                         float* __restrict__ comp) {
+                                         int64_t gfs, float* __restrict__ comp) {
     const int lane = threadIdx.x & 63;
     const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t i = wave0; i < (int64_t)B * P; i += nw) {
@@ -418,7 +435,7 @@ __global__ void cbam_spatial_pool_kernel(const half_t* __restrict__ x, int cp, i
         for (int c8 = lane; c8 < C / 8; c8 += 64) {
             const half8 v = *reinterpret_cast<const half8*>(x + (int64_t)b * fs + (int64_t)p * cp + co + c8 * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float t = (float)v[e] * scale[(int64_t)b * C + c8 * 8 + e]; mx = fmaxf(mx, t); sum += t; }
+            for (int e = 0; e < 8; ++e) { const float t = (float)v[e] * scale[(int64_t)b * gfs + c8 * 8 + e]; mx = fmaxf(mx, t); sum += t; }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o)); sum += __shfl_xor(sum, o); }
@@ -428,7 +445,7 @@ __global__ void cbam_spatial_pool_kernel(const half_t* __restrict__ x, int cp, i
 
 // apply: one wave per pixel: sg = sigmoid(conv7x7(comp) + bias); y = x (1 + scale[c] sg)  (= g + CBAM(g)); y2 (optional) = relu(y)
 __global__ void cbam_apply_kernel(const half_t* __restrict__ x, int cp, int co, int64_t fs, int B, int H, int W, int C, const float* __restrict__ scale,
-                                  const float* __restrict__ comp, const float* __restrict__ w7, const float* __restrict__ b7, half_t* __restrict__ y,
+                                  int64_t gfs, const float* __restrict__ comp, const float* __restrict__ w7, const float* __restrict__ b7, half_t* __restrict__ y,
                                   int y_cp, int y_co, int64_t y_fs, half_t* __restrict__ y2, int y2_cp, int y2_co, int64_t y2_fs) {
     const int lane = threadIdx.x & 63, P = H * W;
     const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -447,7 +464,7 @@ __global__ void cbam_apply_kernel(const half_t* __restrict__ x, int cp, int co, 
             half8 o, o2;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float t = (float)v[e] * (1.f + scale[(int64_t)b * C + c8 * 8 + e] * sg);
+                const float t = (float)v[e] * (1.f + scale[(int64_t)b * gfs + c8 * 8 + e] * sg);
                 o[e] = (half_t)t;
                 o2[e] = (half_t)fmaxf(t, 0.f);
             }
@@ -462,13 +479,17 @@ int launch_cbam(const half_t* x, int cp, int co, int64_t fs, int B, int H, int W
                 int64_t y2_fs, hipStream_t s) {
     const int Ch = C / 16, P = H * W;
     if ((C & 15) || C > 4096) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(cbam_channel_kernel, dim3(B), dim3(512), (2 * C + 2 * Ch) * sizeof(float), s, x, cp, co, fs, P, C, Ch, w1, b1, w2, b2, scale);
+    const int64_t gfs = 3 * (int64_t)C;                       // scale | avg | max per frame (the runtime checks the buffer)
+    hipLaunchKernelGGL(cbam_pool_kernel, dim3((C + 63) / 64, B), dim3(512), 0, s, x, cp, co, fs, P, C, scale, gfs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(cbam_spatial_pool_kernel, dim3(grid_for((int64_t)B * P, 4)), dim3(256), 0, s, x, cp, co, fs, B, P, C, scale, comp);
+    hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(512), 2 * Ch * sizeof(float), s, C, Ch, w1, b1, w2, b2, scale, gfs);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(cbam_apply_kernel, dim3(grid_for((int64_t)B * P, 4)), dim3(256), 0, s, x, cp, co, fs, B, H, W, C, scale, comp, w7, b7, y, y_cp, y_co,
+    hipLaunchKernelGGL(cbam_spatial_pool_kernel, dim3(grid_for((int64_t)B * P, 4)), dim3(256), 0, s, x, cp, co, fs, B, P, C, scale, gfs, comp);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(cbam_apply_kernel, dim3(grid_for((int64_t)B * P, 4)), dim3(256), 0, s, x, cp, co, fs, B, H, W, C, scale, gfs, comp, w7, b7, y, y_cp, y_co,
                        y_fs, y2, y2_cp, y2_co, y2_fs);
     return (int)hipGetLastError();
 }

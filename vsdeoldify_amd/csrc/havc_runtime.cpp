@@ -370,6 +370,17 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                     const int nch = (batch + chunk - 1) / chunk;           // equal launches (32 frames of the 560 x 560 tail: 16 + 16, not 18 + 14)
                     chunk = (batch + nch - 1) / nch;
                 }
+                // A multi-frame launch walks M = frames x rows CONTIGUOUS rows.  A view that covers only part of its buffer's frame (the h0 x w0
+                // patch rows of a DINOv2 token buffer whose frame also holds the class row) does not continue into the next frame:
+                // one launch per frame, each at its buffer's own frame stride.
+                {
+                    const bool plain_out = !(op.flags & (HAVC_F_OUT_PIXSHUF | HAVC_F_OUT_TRANSPOSED | HAVC_F_OUT_RGB8 | HAVC_F_FUSE_RGB8 | HAVC_F_FUSE_PROJ | HAVC_F_PS_BLUR)) && a.oss == 1;
+                    bool contiguous = (uint64_t)op.Hi * op.Wi * op.src_cpitch == (uint64_t)n->bufdesc[op.src].elems_per_frame;
+                    if (plain_out && (uint64_t)op.Ho * op.Wo * op.dst_cpitch != (uint64_t)n->bufdesc[op.dst].elems_per_frame) contiguous = false;
+                    if (plain_out && a.res && !(op.flags & HAVC_F_W_FROM_BUF) && (uint64_t)op.Ho * op.Wo * op.res_cpitch != (uint64_t)n->bufdesc[op.src2].elems_per_frame)
+                        contiguous = false;
+                    if (!contiguous && batch > 1) chunk = 1;
+                }
                 const char* w0 = (const char*)a.w;
                 uint64_t wf = 0;
                 if (op.flags & HAVC_F_W_FROM_BUF) {        // per-frame weights taken from an activation buffer: one launch per frame
@@ -560,7 +571,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
         case HAVC_OP_CBAM: {
             const int C = op.Ci, Ch = C / 16;
             const bool dual = op.flags & HAVC_EW_DUAL;
-            if (op.w_off < 0 || (C & 15) || op.aux0 < 0 || op.aux1 < 0 || (dual && op.src2 < 0) || (uint64_t)n->bufdesc[op.aux0].elems_per_frame < (uint64_t)C ||
+            if (op.w_off < 0 || (C & 15) || op.aux0 < 0 || op.aux1 < 0 || (dual && op.src2 < 0) || (uint64_t)n->bufdesc[op.aux0].elems_per_frame != 3 * (uint64_t)C ||
                 (uint64_t)n->bufdesc[op.aux1].elems_per_frame < (uint64_t)op.Hi * op.Wi * 2)
                 return fail(c, HAVC_E_INVALID, "cbam op: weights / channels / scratch buffers");
             const float* w1 = wptr<float>(n, op.w_off);
@@ -569,7 +580,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                             w2, b2, w7, b7, (float*)bufptr(n, op.aux0), (float*)bufptr(n, op.aux1), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
                             n->bufdesc[op.dst].elems_per_frame, dual ? (half_t*)bufptr(n, op.src2) : nullptr, op.res_cpitch, op.res_coff,
                             dual ? n->bufdesc[op.src2].elems_per_frame : 0, s);
-            c->stats.launches += 2;
+            c->stats.launches += 3;
             break;
         }
         case HAVC_OP_GRU:
