@@ -387,11 +387,12 @@ class ColorMNetPlan:
         # ================= slice "skip": the decoder's skip convs on the image features, one frame =================
         d = "decoder"
         s0 = len(b.ops)
-        b.slice_batch = 1
+        b.slice_batch = key_batch                                    # (like the key slice it depends on the frame alone: it runs ahead with it)
         skip8, skip4 = b.tensor(h8, w8, 512), b.tensor(h4, w4, 256)
+        io["skip8"], io["skip4"] = skip8.buf, skip4.buf
         self._cv(b, d + ".up_16_8.skip_conv", g8, skip8, pad=1)
         self._cv(b, d + ".up_8_4.skip_conv", g4, skip4, pad=1)
-        mark("skip", s0, 1)
+        mark("skip", s0, key_batch)
 
         # ================= slice "segment": Decoder, one frame per object =================
         s0 = len(b.ops)
@@ -463,11 +464,12 @@ class ColorMNetPlan:
 
 
 class _Feat:
-    """multi-scale image features of one encode_key call (NHWC fp16 device tensors the plan wrote through bound buffers)"""
-    __slots__ = ("g16", "g8", "g4", "shape")
+    """multi-scale image features of one encode_key call (NHWC fp16 device tensors the plan wrote through bound buffers); skip8 / skip4: the
+    decoder's skip convs of these features when the look-ahead pass already ran them (else None: segment() runs them)"""
+    __slots__ = ("g16", "g8", "g4", "shape", "skip8", "skip4")
 
-    def __init__(self, g16, g8, g4, shape):
-        self.g16, self.g8, self.g4, self.shape = g16, g8, g4, shape
+    def __init__(self, g16, g8, g4, shape, skip8=None, skip4=None):
+        self.g16, self.g8, self.g4, self.shape, self.skip8, self.skip4 = g16, g8, g4, shape, skip8, skip4
 
 
 class _OnStream:
@@ -590,15 +592,17 @@ class ColorMNetNetwork:
             img = torch.stack([f.to(self.device, torch.float32) for f in frames], 0).contiguous()
             key, sel, shr = self._new(B, self.key_dim, h, w), self._new(B, self.key_dim, h, w), self._new(B, 1, h, w)
             big, epf = {}, {}
-            for name, rows in (("g16", h * w), ("g8", 4 * h * w), ("g4", 16 * h * w)):
+            feats = ("g16", "g8", "g4", "skip8", "skip4")
+            for name in feats:
                 epf[name] = int(net.bufs[net.io[name]]["elems_per_frame"])
                 big[name] = torch.empty(B * epf[name] + 128, dtype=torch.float16, device=self.device)
-            for name, t in (("image", img), ("key", key), ("selection", sel), ("shrinkage", shr), ("g16", big["g16"]), ("g8", big["g8"]), ("g4", big["g4"])):
+            for name, t in (("image", img), ("key", key), ("selection", sel), ("shrinkage", shr)) + tuple((n_, big[n_]) for n_ in feats):
                 net.bind(net.io[name], t.data_ptr())
             self._run(net, "key", B)
+            self._run(net, "skip", B)                                  # the decoder's skip convs read only these features: they run ahead too
             for i in range(B):
-                f = _Feat(*(big[n_][i * epf[n_]:(i + 1) * epf[n_] + 128] for n_ in ("g16", "g8", "g4")), (H, W))
-                self._ahead.append((key[i:i + 1], shr[i:i + 1], sel[i:i + 1], f))
+                v = [big[n_][i * epf[n_]:(i + 1) * epf[n_] + 128] for n_ in feats]
+                self._ahead.append((key[i:i + 1], shr[i:i + 1], sel[i:i + 1], _Feat(v[0], v[1], v[2], (H, W), v[3], v[4])))
             self._keep_ahead = (img,)
 
     def expect_prefetched(self):
@@ -671,7 +675,13 @@ class ColorMNetNetwork:
             prob = self._new(1, 2, H, W)
             for name, t in (("g16", f.g16), ("g8", f.g8), ("g4", f.g4), ("readout", ro), ("hidden", hin), ("prob", prob)):
                 net.bind(net.io[name], t.data_ptr())
-            self._run(net, "skip")
+            if f.skip8 is not None:                                   # the look-ahead pass has run the skip convs of this frame
+                net.bind(net.io["skip8"], f.skip8.data_ptr())
+                net.bind(net.io["skip4"], f.skip4.data_ptr())
+            else:
+                net.bind(net.io["skip8"], None)
+                net.bind(net.io["skip4"], None)
+                self._run(net, "skip")
             self._run(net, "segment")
             hidden = None
             if h_out:

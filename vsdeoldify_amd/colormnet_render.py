@@ -84,7 +84,7 @@ class ColorMNetRender:
         self.ref_img = self.ref_img_valid = self.img = None
         self.first_mask_loaded = False
         # frames per batched key-encoder pass when the caller announces frames ahead (colorize_batch_frames / prefetch); 1 = off
-        self.lookahead = int(os.environ.get("HAVC_CMN_LOOKAHEAD", "8")) if lookahead is None else int(lookahead)
+        self.lookahead = int(os.environ.get("HAVC_CMN_LOOKAHEAD", "16")) if lookahead is None else int(lookahead)
         self._ahead = collections.deque()
         self.device_index, self._memory_backend = device_index, memory_backend          # memory_backend: CPU tests of the state machine only
         self.network = network if network is not None else _load_network(self.project_dir, state_dict, device_index)
