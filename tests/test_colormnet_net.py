@@ -176,6 +176,89 @@ def test_render_state_machine_matches_the_reference_class_on_cpu(name):
     assert got.shape == want.shape and d.max() <= 1 and (d > 0).mean() < 2e-3, (name, int(d.max()), float((d > 0).mean()))
 
 
+class _LookaheadOracleNetwork:
+    """the oracle network + the look-ahead protocol of ColorMNetNetwork (prefetch_keys / expect_prefetched / drop_prefetched), with the keys
+    computed by the oracle's own encode_key: exercises the FIFO bookkeeping of the drop-in render on the CPU"""
+
+    def __new__(cls, sd):
+        import collections
+        from oracle import colormnet_clip
+
+        class Net(colormnet_clip.OracleNetwork):
+            def __init__(self, sd_):
+                super().__init__(sd_)
+                self._ahead, self._armed, self.served, self.batches = collections.deque(), False, 0, []
+
+            def prefetch_keys(self, frames, max_batch=None):
+                self.batches.append(len(frames))
+                for f in frames:
+                    self._ahead.append(super().encode_key(f.unsqueeze(0)))
+
+            def expect_prefetched(self):
+                self._armed = bool(self._ahead)
+
+            def drop_prefetched(self):
+                if self._ahead:
+                    self._ahead.popleft()
+
+            def encode_key(self, frame, need_ek=True, need_sk=True):
+                if self._armed:
+                    self._armed = False
+                    self.served += 1
+                    key, shr, sel, f16, f8, f4 = self._ahead.popleft()
+                    return key, (shr if need_sk else None), (sel if need_ek else None), f16, f8, f4
+                return super().encode_key(frame, need_ek=need_ek, need_sk=need_sk)
+        return Net(sd)
+
+
+@pytest.mark.parametrize("name", ["keep", "vivid", "capped"])
+def test_render_lookahead_bookkeeping_on_cpu(name):
+    """colorize_batch_frames with a look-ahead window of 4 over the 9-frame fixture clip: every frame's key comes out of the prefetch FIFO
+    exactly once (exemplar images are encoded on the spot), windows are 4 + 4 + 1 frames, nothing is left behind, and the frames equal the
+    reference's recorded ones (<= 1 LSB) — memory resets inside a window ("vivid" at frame 4, "capped" every 3 frames) included."""
+    from PIL import Image
+    from oracle import colormnet_clip
+    from vsdeoldify_amd.colormnet_render import ColorMNetRender
+    kw, propagate = SCENARIOS[name]
+    frames, refs, want = REN["frames"], REN["refs"], want_of(name)
+    network = _LookaheadOracleNetwork(tsd())
+    rnd = ColorMNetRender(image_size=-1, vid_length=len(frames), enable_resize=False, encode_mode=1, propagate=propagate, network=network,
+                          memory_backend=colormnet_clip.OracleBackend(), lookahead=4, **kw)
+    rnd.set_config("mem_every", int(REN["mem_every"]))
+    imgs = [Image.fromarray(np.stack([fr] * 3, -1)) for fr in frames]
+    ref_list = [Image.fromarray(refs[0]) if t == 0 else (Image.fromarray(refs[1]) if t == 4 else None) for t in range(len(frames))]
+    got = np.stack([np.asarray(o) for o in rnd.colorize_batch_frames(imgs, ref_list, propagate)])
+    assert network.batches == [4, 4] and network.served == 8 and not network._ahead and not rnd._ahead      # the last window is one frame: no prefetch
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 2e-3, (name, int(d.max()), float((d > 0).mean()))
+
+
+def test_render_lookahead_forgets_frames_the_caller_skips():
+    """prefetch() announces frames; a caller that then passes OTHER frames gets them computed on the spot and the stale look-ahead is dropped
+    on both sides (render FIFO and network FIFO stay in step); frames before the first reference pass through and consume their entry."""
+    from PIL import Image
+    from oracle import colormnet_clip
+    from vsdeoldify_amd.colormnet_render import ColorMNetRender
+    frames, refs = REN["frames"], REN["refs"]
+    network = _LookaheadOracleNetwork(tsd())
+    rnd = ColorMNetRender(image_size=-1, vid_length=6, network=network, memory_backend=colormnet_clip.OracleBackend(), lookahead=4,
+                          reset_on_ref_update=False)
+    imgs = [Image.fromarray(np.stack([fr] * 3, -1)) for fr in frames[:6]]
+    rnd.prefetch(imgs[:3])
+    assert len(network._ahead) == 3 and len(rnd._ahead) == 3
+    rnd.set_ref_frame(None)
+    assert rnd.colorize_frame(0, imgs[0]) is imgs[0]                     # no reference yet: passthrough, its entry is consumed
+    assert len(network._ahead) == 2 and len(rnd._ahead) == 2
+    rnd.set_ref_frame(Image.fromarray(refs[0]))
+    out = rnd.colorize_frame(1, imgs[4])                                 # not the announced frame: look-ahead dropped, frame computed
+    assert not network._ahead and not rnd._ahead and network.served == 0 and np.asarray(out).shape == np.asarray(imgs[4]).shape
+    rnd.prefetch(imgs[2:4])
+    rnd.set_ref_frame(None)
+    rnd.colorize_frame(2, imgs[2])
+    rnd.colorize_frame(3, imgs[3])
+    assert network.served == 2 and not network._ahead and not rnd._ahead
+
+
 # =====================================================================================================================================
 # GPU: the new plan ops one by one (tests/gpu_util.run_plan: upload fp16 NHWC, run, download) against plain torch fp32 on the CPU
 # =====================================================================================================================================

@@ -121,8 +121,10 @@ class ColorMNetRender:
         keys / image features are computed now, in one batched pass of the key encoder."""
         from .device import is_device
         from .colormnet_core import pad_divide_by, DIVIDE_BY
-        if not hasattr(self.network, "prefetch_keys") or len(frames) < 2:
+        if not hasattr(self.network, "prefetch_keys") or len(frames) < 2 or self.lookahead <= 1:
             return
+        if len({tuple(getattr(f, "shape", None) or np.asarray(f).shape) for f in frames}) != 1:
+            return                                                      # frames of different sizes: no batched pass
         with self.network.on_stream():
             labs = [self.network.image_to_lab(f if is_device(f) else np.asarray(f)) for f in frames]
             self.network.prefetch_keys([pad_divide_by(lab[:1].repeat(3, 1, 1), DIVIDE_BY)[0] for lab in labs], max_batch=self.lookahead)
