@@ -48,6 +48,8 @@ SHAPES = {  # name: (Cin, Cout, k, stride, pad, H, W, flags)
     "e1_c2_3x3": (64, 64, 3, 1, 1, 140, 140, nat.F_RELU_PRE),
     "stem7x7": (3, 64, 7, 2, 3, 560, 560, nat.F_RELU_PRE),
     "attn_qk": (512, 128, 1, 1, 0, 70, 70, 0),
+    "ddkv2": (256, 512, 1, 1, 0, 64, 64, 0),                        # DDColor colour decoder: K / V projection of the 1/8 feature level (+res: the position term)
+    "ddkv1": (256, 512, 1, 1, 0, 32, 32, 0),
     "l4ps": (2048, 2048, 1, 1, 0, 18, 18, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),
     "l5ps": (512, 2048, 1, 1, 0, 35, 35, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),
 }
@@ -93,7 +95,7 @@ if __name__ == "__main__":
     filt = sys.argv[3] if len(sys.argv) > 3 else ""
     cfgs = [int(c) for c in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0]
     ctx = get_context(0)
-    names = list(SHAPES) + [n + "+res" for n in SHAPES if (n.startswith("e") and "c3" in n) or n.startswith("pw2")]
+    names = list(SHAPES) + [n + "+res" for n in SHAPES if (n.startswith("e") and "c3" in n) or n.startswith("pw2") or n.startswith("ddkv")]
     filts = [f for f in filt.split(",") if f]
     for name in names:
         if filts and not any(f in name for f in filts):
