@@ -22,5 +22,5 @@ find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/bench_kernel_stats_raw.csv
 find $O/prof -name "*kernel_trace.csv" -exec python tools/trace_summary.py {} 3 \; > $O/bench_kernel_stats.csv
 find $O/prof_c5 -name "*kernel_stats.csv" -exec cp {} $O/bench_c5_kernel_stats_raw.csv \;
 find $O/prof_c5 -name "*kernel_trace.csv" -exec python tools/c5_trace_summary.py {} 96 \; > $O/c5_kernels.txt
-rm -rf $O/prof $O/prof_c5
+rm -rf $O/prof $O/prof_c5 gpurun_out/pmc_bench_fetch gpurun_out/pmc_bench_write gpurun_out/pmc_bench_sq1 gpurun_out/pmc_bench_sq2
 tail -6 $O/pytest_all.txt; tail -2 $O/smoke.txt; cut -c1-600 $O/bench.json; for c in c3 c4 c5; do cut -c1-300 $O/bench_$c.json; tail -2 $O/bench_$c.err; done; head -8 $O/bench_kernel_stats.csv; head -12 $O/pmc_to_json.txt
