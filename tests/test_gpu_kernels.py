@@ -356,3 +356,42 @@ def torch_conv(x, w, bias, pad):
     import torch.nn.functional as F
     return F.conv2d(torch.from_numpy(x.astype(np.float16).astype(np.float32)), torch.from_numpy(w.astype(np.float16).astype(np.float32)),
                     torch.from_numpy(bias), padding=pad).numpy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [0, 70, 1])
+def test_conv_views_that_do_not_fill_their_frame_run_frame_by_frame(ctx, cfg):
+    """A ViT token buffer holds h x w patch rows + one class row per frame; the patch-embedding conv writes an h x w VIEW of it and a later conv
+    reads such a view (colormnet_net.py _dino).  With batch > 1 the rows of a view do not continue into the next frame: the runtime launches per
+    frame at the buffer's own frame stride.  (As one launch over contiguous rows, frame 1's first patch row landed on frame 0's class row.)"""
+    r = np.random.default_rng(8)
+    B, h, w, Cin, Cout, P = 3, 5, 7, 24, 64, 4
+    T = h * w + 1
+    pack, b = WeightPack(), PlanBuilder()
+    x = b.tensor(h * P, w * P, Cin)
+    from vsdeoldify_amd.plan import pitch_for
+    pc_ = pitch_for(pad_to(Cout, 8))
+    tok = View(b.buf(T * pc_, 2), 0, pc_, 1, T, Cout, pad_to(Cout, 8))
+    W1 = (r.standard_normal((Cout, Cin, P, P)) / np.sqrt(Cin * P * P)).astype(np.float32)
+    c1 = pack_conv(pack, W1, x.cmap, x.span, bias=r.standard_normal(Cout).astype(np.float32))
+    b.conv("patch_embed", c1, x, View(tok.buf, 0, tok.cpitch, h, w, Cout, tok.span), stride=P)
+    patches = View(tok.buf, 0, tok.cpitch, h, w, Cout, tok.span)
+    y = b.tensor(h, w, 32)
+    W2 = (r.standard_normal((32, Cout, 1, 1)) / np.sqrt(Cout)).astype(np.float32)
+    c2 = pack_conv(pack, W2, patches.cmap, patches.span)
+    b.conv("head", c2, patches, y)
+    xin = (r.standard_normal((B, Cin, h * P, w * P)) * 0.5).astype(np.float32)
+    tok0 = np.zeros((B, T, tok.cpitch), np.float16)
+    tok0[:, T - 1, :Cout] = (np.arange(Cout) / 8.0 + 1.0).astype(np.float16)          # the class row: must survive
+    out = gu.run_plan(ctx, pack, b, {x.buf: gu.nhwc_pad(xin, x.cpitch), tok.buf: tok0},
+                      {tok.buf: ((B, T, tok.cpitch), np.float16), y.buf: ((B, h, w, y.cpitch), np.float16)}, B, cfg)
+    f16 = lambda a: a.astype(np.float16).astype(np.float32)
+    xt, w1 = torch.from_numpy(f16(xin)), torch.from_numpy(f16(W1))
+    ref = F.conv2d(xt, w1, None, stride=P).numpy()
+    got = out[tok.buf].astype(np.float32)
+    bias = got[:, :h * w, :Cout].reshape(B, h, w, Cout).transpose(0, 3, 1, 2) - ref                  # what was added must be ONE bias vector
+    assert np.abs(bias - bias[0, :, 0, 0][None, :, None, None]).max() < 2e-2
+    assert np.array_equal(got[:, T - 1, :Cout], tok0[:, T - 1, :Cout].astype(np.float32))          # class rows untouched in every frame
+    head = F.conv2d(torch.from_numpy(got[:, :h * w, :Cout].reshape(B, h, w, Cout).transpose(0, 3, 1, 2).copy()), torch.from_numpy(f16(W2))).numpy()
+    gy = out[y.buf][..., :32].astype(np.float32).transpose(0, 3, 1, 2)
+    assert np.abs(gy - head).max() < 2e-2 * max(1.0, float(np.abs(head).max()))
