@@ -187,25 +187,19 @@ class _LookaheadOracleNetwork:
         class Net(colormnet_clip.OracleNetwork):
             def __init__(self, sd_):
                 super().__init__(sd_)
-                self._ahead, self._armed, self.served, self.batches = collections.deque(), False, 0, []
+                self._armed, self.served, self.batches = None, 0, []
 
             def prefetch_keys(self, frames, max_batch=None):
                 self.batches.append(len(frames))
-                for f in frames:
-                    self._ahead.append(super().encode_key(f.unsqueeze(0)))
+                return [super(Net, self).encode_key(f.unsqueeze(0)) for f in frames]
 
-            def expect_prefetched(self):
-                self._armed = bool(self._ahead)
-
-            def drop_prefetched(self):
-                if self._ahead:
-                    self._ahead.popleft()
+            def expect_prefetched(self, entry):
+                self._armed = entry
 
             def encode_key(self, frame, need_ek=True, need_sk=True):
-                if self._armed:
-                    self._armed = False
+                if self._armed is not None:
+                    (key, shr, sel, f16, f8, f4), self._armed = self._armed, None
                     self.served += 1
-                    key, shr, sel, f16, f8, f4 = self._ahead.popleft()
                     return key, (shr if need_sk else None), (sel if need_ek else None), f16, f8, f4
                 return super().encode_key(frame, need_ek=need_ek, need_sk=need_sk)
         return Net(sd)
@@ -228,7 +222,7 @@ def test_render_lookahead_bookkeeping_on_cpu(name):
     imgs = [Image.fromarray(np.stack([fr] * 3, -1)) for fr in frames]
     ref_list = [Image.fromarray(refs[0]) if t == 0 else (Image.fromarray(refs[1]) if t == 4 else None) for t in range(len(frames))]
     got = np.stack([np.asarray(o) for o in rnd.colorize_batch_frames(imgs, ref_list, propagate)])
-    assert network.batches == [4, 4] and network.served == 8 and not network._ahead and not rnd._ahead      # the last window is one frame: no prefetch
+    assert network.batches == [4, 4] and network.served == 8 and network._armed is None and not rnd._ahead      # the last window is one frame: no prefetch
     d = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 2e-3, (name, int(d.max()), float((d > 0).mean()))
 
@@ -245,18 +239,18 @@ def test_render_lookahead_forgets_frames_the_caller_skips():
                           reset_on_ref_update=False)
     imgs = [Image.fromarray(np.stack([fr] * 3, -1)) for fr in frames[:6]]
     rnd.prefetch(imgs[:3])
-    assert len(network._ahead) == 3 and len(rnd._ahead) == 3
+    assert len(rnd._ahead) == 3
     rnd.set_ref_frame(None)
     assert rnd.colorize_frame(0, imgs[0]) is imgs[0]                     # no reference yet: passthrough, its entry is consumed
-    assert len(network._ahead) == 2 and len(rnd._ahead) == 2
+    assert len(rnd._ahead) == 2 and network._armed is None
     rnd.set_ref_frame(Image.fromarray(refs[0]))
     out = rnd.colorize_frame(1, imgs[4])                                 # not the announced frame: look-ahead dropped, frame computed
-    assert not network._ahead and not rnd._ahead and network.served == 0 and np.asarray(out).shape == np.asarray(imgs[4]).shape
+    assert not rnd._ahead and network.served == 0 and np.asarray(out).shape == np.asarray(imgs[4]).shape
     rnd.prefetch(imgs[2:4])
     rnd.set_ref_frame(None)
     rnd.colorize_frame(2, imgs[2])
     rnd.colorize_frame(3, imgs[3])
-    assert network.served == 2 and not network._ahead and not rnd._ahead
+    assert network.served == 2 and network._armed is None and not rnd._ahead
 
 
 # =====================================================================================================================================
@@ -561,15 +555,16 @@ def test_gpu_key_lookahead_equals_encode_key_frame_by_frame():
     g = torch.Generator().manual_seed(5)
     frames = [torch.tanh(torch.randn(1, 1, 112, 224, generator=g)).repeat(1, 3, 1, 1) for _ in range(5)]
     single = [net.encode_key(f.to(dev)) for f in frames]
-    net.prefetch_keys([f[0].to(dev) for f in frames], max_batch=8)           # 5 of 8: a ragged last batch
-    assert len(net._ahead) == 5
+    entries = net.prefetch_keys([f[0].to(dev) for f in frames], max_batch=8)           # 5 of 8: a ragged last batch
+    assert len(entries) == 5
     h, w = 7, 14
     for i, f in enumerate(frames):
-        if i == 2:                                                            # not armed: computed, the FIFO is left alone
+        if i == 2:                                                            # not armed: computed on the spot
             k_plain = net.encode_key(f.to(dev))[0]
-            assert len(net._ahead) == 3 and rel(k_plain.cpu().numpy(), single[i][0].cpu().numpy())[0] == 0.0
-        net.expect_prefetched()
+            assert rel(k_plain.cpu().numpy(), single[i][0].cpu().numpy())[0] == 0.0
+        net.expect_prefetched(entries[i])
         gk, gs, ge, gf, _, _ = net.encode_key(f.to(dev))
+        assert net._armed is None                                             # one shot
         torch.cuda.synchronize()
         sk, ss, se, sf, _, _ = single[i]
         for n_, a, b_ in (("key", gk, sk), ("shrinkage", gs, ss), ("selection", ge, se)):
@@ -578,9 +573,6 @@ def test_gpu_key_lookahead_equals_encode_key_frame_by_frame():
         for n_, rows, C in (("g16", (h, w), 1024), ("g8", (2 * h, 2 * w), 512), ("g4", (4 * h, 4 * w), 256)):
             r = rel(feat_nchw(getattr(gf, n_), rows, C), feat_nchw(getattr(sf, n_), rows, C))
             assert r[0] < 4e-3 and r[1] < 1e-3, (i, n_, r)
-    assert len(net._ahead) == 0
-    net.expect_prefetched()                                                   # nothing waiting: the flag does not stick
-    assert not net._armed
 
 
 @pytest.mark.gpu
@@ -600,7 +592,7 @@ def test_gpu_colorize_batch_frames_with_lookahead_matches_the_reference_render_c
     imgs = [Image.fromarray(np.stack([fr] * 3, -1)) for fr in frames]
     ref_list = [Image.fromarray(refs[0]) if t == 0 else (Image.fromarray(refs[1]) if t == 4 else None) for t in range(len(frames))]
     got = np.stack([np.asarray(o) for o in rnd.colorize_batch_frames(imgs, ref_list, propagate)])
-    assert not rnd._ahead and not rnd.network._ahead
+    assert not rnd._ahead and rnd.network._armed is None
     for t in range(len(want)):
         de = imaging.delta_e00_images(got[t], want[t])
         assert de.mean() < 0.5 and np.percentile(de, 99) < 2.5, (name, t, float(de.mean()), float(np.percentile(de, 99)))

@@ -520,8 +520,8 @@ class ColorMNetNetwork:
         self.device = torch.device("cuda", device_index)
         self.stream = torch.cuda.ExternalStream(self.ctx.stream_ptr(), device=self.device)
         self.nets = {}
-        import collections
-        self._ahead, self._armed = collections.deque(), False
+        self._armed, self._helper, self.worker = None, None, worker
+        self.async_lookahead = os.environ.get("HAVC_CMN_ASYNC_LOOKAHEAD", "1") != "0"      # look-ahead pass on its own stream (0: on this network's stream)
         self.autotune = (os.environ.get("HAVC_AUTOTUNE", "1") != "0") if autotune is None else autotune
         sd = self.plan.sd
         ws2 = (2 * MAX_DIS + 1) ** 2
@@ -578,49 +578,69 @@ class ColorMNetNetwork:
         return torch.empty(rows * pitch + 128, dtype=torch.float16, device=self.device)     # + slack: vector loads may touch the tail
 
     # ---- look-ahead: encode_key of the next frames of a clip in ONE batched pass (nothing in encode_key depends on the memory) ----
+    def _helper_net(self):
+        """the network object the look-ahead pass runs on: another context (its own HIP stream and activation arena) of the same GPU, same packed
+        weights.  The pass for the NEXT frames then overlaps the frame-by-frame memory step, whose small launches leave most CUs idle."""
+        if self._helper is None:
+            self._helper = ColorMNetNetwork(None, device_index=self.ctx.device_id, autotune=self.autotune, worker=("lookahead", self.worker), share=self)
+        return self._helper
+
     def prefetch_keys(self, frames, max_batch=None):
         """frames: list of [3, H, W] device tensors, padded as InferenceCore pads them (pad_divide_by 112), in the order in which they will be
-        stepped.  Their keys / features wait in a FIFO; `expect_prefetched()` arms the next encode_key call to take the front entry."""
+        stepped.  Returns one entry per frame; the caller (ColorMNetRender) keeps them and hands the frame's entry back through
+        `expect_prefetched(entry)` right before the step, whose first encode_key call then takes it instead of computing.
+        The pass is only ENQUEUED here, on the helper context's stream, behind everything this network's stream holds so far; an event marks
+        its end and the consumer (encode_key) makes this network's stream wait for it."""
         import torch
         if not frames:
-            return
+            return []
         B = len(frames)
         H, W = frames[0].shape[-2:]
-        net = self._key_net(H, W, max_batch or B)
+        hn = self._helper_net() if self.async_lookahead else self
+        net = hn._key_net(H, W, max_batch or B)
         h, w = H // 16, W // 16
         with self.on_stream():
             img = torch.stack([f.to(self.device, torch.float32) for f in frames], 0).contiguous()
-            key, sel, shr = self._new(B, self.key_dim, h, w), self._new(B, self.key_dim, h, w), self._new(B, 1, h, w)
-            big, epf = {}, {}
-            feats = ("g16", "g8", "g4", "skip8", "skip4")
-            for name in feats:
-                epf[name] = int(net.bufs[net.io[name]]["elems_per_frame"])
-                big[name] = torch.empty(B * epf[name] + 128, dtype=torch.float16, device=self.device)
-            for name, t in (("image", img), ("key", key), ("selection", sel), ("shrinkage", shr)) + tuple((n_, big[n_]) for n_ in feats):
-                net.bind(net.io[name], t.data_ptr())
-            self._run(net, "key", B)
-            self._run(net, "skip", B)                                  # the decoder's skip convs read only these features: they run ahead too
+            if hn is not self:
+                hn.stream.wait_stream(self.stream)                    # the frames (and whatever produced them) first
+                img.record_stream(hn.stream)
+            with torch.cuda.stream(hn.stream):
+                key, sel, shr = self._new(B, self.key_dim, h, w), self._new(B, self.key_dim, h, w), self._new(B, 1, h, w)
+                big, epf = {}, {}
+                feats = ("g16", "g8", "g4", "skip8", "skip4")
+                for name in feats:
+                    epf[name] = int(net.bufs[net.io[name]]["elems_per_frame"])
+                    big[name] = torch.empty(B * epf[name] + 128, dtype=torch.float16, device=self.device)
+                for name, t in (("image", img), ("key", key), ("selection", sel), ("shrinkage", shr)) + tuple((n_, big[n_]) for n_ in feats):
+                    net.bind(net.io[name], t.data_ptr())
+                hn._run(net, "key", B)
+                hn._run(net, "skip", B)                                # the decoder's skip convs read only these features: they run ahead too
+                done = None
+                if hn is not self:
+                    done = torch.cuda.Event()
+                    done.record(hn.stream)
+                    for t in (key, sel, shr) + tuple(big.values()):
+                        t.record_stream(self.stream)                   # allocated on the helper's stream, read on this one
+            entries = []
             for i in range(B):
                 v = [big[n_][i * epf[n_]:(i + 1) * epf[n_] + 128] for n_ in feats]
-                self._ahead.append((key[i:i + 1], shr[i:i + 1], sel[i:i + 1], _Feat(v[0], v[1], v[2], (H, W), v[3], v[4])))
-            self._keep_ahead = (img,)
+                entries.append((key[i:i + 1], shr[i:i + 1], sel[i:i + 1], _Feat(v[0], v[1], v[2], (H, W), v[3], v[4]), done, img))
+        return entries
 
-    def expect_prefetched(self):
-        """the NEXT encode_key call is for the frame at the front of the prefetch FIFO (InferenceCore encodes the frame first, then an exemplar)"""
-        self._armed = bool(self._ahead)
-
-    def drop_prefetched(self):
-        if self._ahead:
-            self._ahead.popleft()
+    def expect_prefetched(self, entry):
+        """the NEXT encode_key call is for the frame `entry` was computed from (InferenceCore encodes the frame first, then an exemplar)"""
+        self._armed = entry
 
     # ---- network.py:52-85 ----
     def encode_key(self, frame, need_ek=True, need_sk=True):
         import torch
         assert frame.dim() == 4 and frame.shape[0] == 1, "one frame [1, 3, H, W]"
-        if self._armed:
-            self._armed = False
-            key, shr, sel, f = self._ahead.popleft()
+        if self._armed is not None:
+            (key, shr, sel, f, done, _img), self._armed = self._armed, None
             if f.shape == tuple(frame.shape[-2:]):
+                if done is not None:
+                    with self.on_stream():
+                        torch.cuda.current_stream(self.device).wait_event(done)     # the look-ahead pass that produced this entry
                 return key, (shr if need_sk else None), (sel if need_ek else None), f, f, f
         H, W = frame.shape[-2:]
         net = self._net(H, W)
@@ -739,6 +759,9 @@ class ColorMNetNetwork:
         return out
 
     def close(self):
+        if self._helper is not None:
+            self._helper.close()
+            self._helper = None
         for n in self.nets.values():
             n.close()
         self.nets.clear()

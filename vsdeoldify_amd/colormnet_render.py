@@ -108,10 +108,12 @@ class ColorMNetRender:
     def colorize_batch_frames(self, frame_list=None, ref_list=None, frame_propagate=False):
         """colormnet_render.py:186-195.  The list is known up front, so the key encoder runs `lookahead` frames at a time ahead of the
         sequential step (prefetch): encode_key does not depend on the memory."""
-        out = []
+        out, L = [], self.lookahead
         for i, (frame_i, ref_i) in enumerate(zip(frame_list, ref_list)):
-            if self.lookahead > 1 and i % self.lookahead == 0:
-                self.prefetch(frame_list[i:i + self.lookahead])
+            if L > 1 and i % L == 0:
+                if i == 0:
+                    self.prefetch(frame_list[:L])
+                self.prefetch(frame_list[i + L:i + 2 * L])              # the window AFTER this one: its pass overlaps this window's frame steps
             self.set_ref_frame(ref_i, frame_propagate)
             out.append(self.colorize_frame(i, frame_i))
         return out
@@ -127,9 +129,9 @@ class ColorMNetRender:
             return                                                      # frames of different sizes: no batched pass
         with self.network.on_stream():
             labs = [self.network.image_to_lab(f if is_device(f) else np.asarray(f)) for f in frames]
-            self.network.prefetch_keys([pad_divide_by(lab[:1].repeat(3, 1, 1), DIVIDE_BY)[0] for lab in labs], max_batch=self.lookahead)
-        for f, lab in zip(frames, labs):
-            self._ahead.append((f, lab))
+            entries = self.network.prefetch_keys([pad_divide_by(lab[:1].repeat(3, 1, 1), DIVIDE_BY)[0] for lab in labs], max_batch=self.lookahead)
+        for f, lab, ent in zip(frames, labs, entries):
+            self._ahead.append((f, lab, ent))
 
     def get_frame_count(self):
         return self.frame_count
@@ -154,21 +156,19 @@ class ColorMNetRender:
             ref = self.ref_img
             self.frame_count += 1
         as_lab = lambda im: self.network.image_to_lab(im if is_device(im) else np.asarray(im))
-        ahead = bool(self._ahead) and self._ahead[0][0] is frame_i       # this frame went through prefetch(): its Lab planes and its key are waiting
-        if self._ahead and not ahead:                                   # the caller left the announced order: forget the look-ahead
-            while self._ahead:
-                self._ahead.popleft()
-                self.network.drop_prefetched()
-        lab = self._ahead.popleft()[1] if ahead else as_lab(frame_i)    # [3,H,W] normalised Lab on the device (get_image :285-301)
+        ahead = None                                                    # this frame went through prefetch(): its Lab planes and its key are waiting
+        if self._ahead and self._ahead[0][0] is frame_i:
+            ahead = self._ahead.popleft()
+        elif self._ahead:                                               # the caller left the announced order: forget the look-ahead
+            self._ahead.clear()
+        lab = ahead[1] if ahead else as_lab(frame_i)                    # [3,H,W] normalised Lab on the device (get_image :285-301)
         rgb = lab[:1].repeat(3, 1, 1)
         msk = as_lab(ref) if ref is not None else None
         if msk is not None and not self.config["FirstFrameIsNotExemplar"]:
             msk = msk[1:3]
         if not self.first_mask_loaded:
             if msk is None:
-                if ahead:
-                    self.network.drop_prefetched()
-                return frame_i                                          # nothing to propagate from yet
+                return frame_i                                          # nothing to propagate from yet (a prefetched entry is simply dropped)
             self.first_mask_loaded = True
         labels = None
         if msk is not None:
@@ -176,7 +176,7 @@ class ColorMNetRender:
             labels = range(1, 3)
         is_last = self.vid_length == self.total_colored_frames - 1
         if ahead:
-            self.network.expect_prefetched()                            # the step's first encode_key call is for this frame
+            self.network.expect_prefetched(ahead[2])                    # the step's first encode_key call is for this frame
         if self.config["FirstFrameIsNotExemplar"]:
             if msk is None:
                 prob = self.processor.step_AnyExemplar(rgb, None, None, labels, end=is_last)
@@ -217,6 +217,7 @@ class DeepExColorMNet:
                                       network=network)
         self.ctx = self.render.network.ctx
         self.t = 0
+        self._announced = {}                                                 # id(frame) -> (frame, squashed frame + borders): look-ahead of colorize_frames
 
     def _borders(self, h, w):
         """SmartResizeColorizer.get_resized_clip: (pad_h, pad_w) of black borders that bring the clip to the target aspect ratio"""
@@ -264,17 +265,29 @@ class DeepExColorMNet:
             return F.chroma_post_process_np(self.ctx, np.ascontiguousarray(up), frame.numpy() if is_device(frame) else np.asarray(frame))
         return spline64(self.ctx, col, w, h, luma_from=frame)
 
-    def colorize_frames(self, frames, refs):
+    def _announce(self, frames):
+        """squash frames that will be coloured next and hand them to the render's look-ahead (once per frame object)"""
+        new = [f for f in frames if id(f) not in self._announced]
+        if len(new) < 2 or self.render.lookahead <= 1:
+            return
+        smalls = [self._small(f) for f in new]
+        self.render.prefetch([s for s, _ in smalls])
+        for f, sm in zip(new, smalls):
+            self._announced[id(f)] = (f, sm)                                 # (holding f keeps its id unique)
+
+    def colorize_frames(self, frames, refs, upcoming=()):
         """frames: a sequence of u8 [h, w, 3] frames (ndarrays or DeviceImages); refs: {index: reference image} -> list of coloured frames.
-        The frames are known up front: they are squashed `lookahead` at a time and announced to the render (ColorMNetRender.prefetch), whose
-        key encoder then runs that many frames per pass while the memory step stays frame by frame."""
-        out, L = [], max(1, self.render.lookahead)
+        The frames are known up front: they are squashed `lookahead` at a time and announced to the render (ColorMNetRender.prefetch) ONE WINDOW
+        AHEAD, so that the key-encoder pass of the next window runs (on its own stream) while the memory step walks this window frame by frame.
+        upcoming: the frame objects the NEXT call will start with (a streaming caller knows them): announced during the last window of this call."""
+        frames, out, L = list(frames), [], max(1, self.render.lookahead)
         for i0 in range(0, len(frames), L):
-            chunk = [frames[i] for i in range(i0, min(i0 + L, len(frames)))]
-            smalls = [self._small(f) for f in chunk]
-            if L > 1:
-                self.render.prefetch([s for s, _ in smalls])
-            out.extend(self.colorize_frame(f, refs.get(i0 + j), _small=smalls[j]) for j, f in enumerate(chunk))
+            if i0 == 0:
+                self._announce(frames[:L])
+            self._announce(frames[i0 + L:i0 + 2 * L] or list(upcoming)[:L])
+            for j, f in enumerate(frames[i0:i0 + L]):
+                ent = self._announced.pop(id(f), None)
+                out.append(self.colorize_frame(f, refs.get(i0 + j), _small=ent[1] if ent else None))
         return out
 
     def colorize_clip(self, clip, refs):
