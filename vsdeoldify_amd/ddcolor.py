@@ -17,10 +17,15 @@ from .render import get_context
 class DDColorRuntime:
     """Packed DDColor weights on one GPU + a cache of nets keyed by (input size, max_batch)."""
 
-    def __init__(self, ctx, state_dict, depths=(3, 3, 27, 3), dec_layers=9):
+    def __init__(self, ctx, state_dict, depths=(3, 3, 27, 3), dec_layers=9, share=None):
+        """share: another DDColorRuntime of the same GPU whose packed plan and device weights are reused (read-only): a second context
+        (its own HIP stream and activation arena) for frames that run CONCURRENTLY with the first one's (DDColorRender num_streams)."""
         self.ctx = ctx
-        self.gen = DDColorGenerator(state_dict, depths, dec_layers)
-        self.weights = nat.Weights(ctx, self.gen.blob)
+        if share is not None:
+            self.gen, self.weights, self._owns_weights = share.gen, share.weights, False
+        else:
+            self.gen = DDColorGenerator(state_dict, depths, dec_layers)
+            self.weights, self._owns_weights = nat.Weights(ctx, self.gen.blob), True
         self.nets = {}
 
     def net(self, S, max_batch=1):
@@ -38,9 +43,9 @@ class DDColorRuntime:
             self.nets[key] = n
         return self.nets[key]
 
-    def colorize(self, frames, input_size=None, max_batch=None):
+    def colorize(self, frames, input_size=None, max_batch=None, out=None):
         """frames: uint8 [N, H, W, 3] -> uint8 [N, H, W, 3]; the network runs at input_size (default: the frame size, which
-        must then be square and a multiple of 32)."""
+        must then be square and a multiple of 32).  out: where to write (same kind and shape as frames)."""
         from .device import is_device, operand_ptr
         dev = is_device(frames)
         if not dev:
@@ -50,7 +55,8 @@ class DDColorRuntime:
         assert S % 32 == 0 and (input_size is not None or frames.shape[1] == frames.shape[2])
         n = frames.shape[0]
         net = self.net(S, max_batch or min(n, 8))
-        out = frames.empty_like() if dev else np.empty_like(frames)
+        if out is None:
+            out = frames.empty_like() if dev else np.empty_like(frames)
         nat.check(self.ctx.lib.havc_ddcolor_frames(self.ctx.h, net.h, operand_ptr(frames), operand_ptr(out), n, frames.shape[2],
                                                    frames.shape[1]), self.ctx.h)
         return out
@@ -76,7 +82,8 @@ class DDColorRuntime:
         for n in self.nets.values():
             n.close()
         self.nets.clear()
-        self.weights.close()
+        if self._owns_weights:
+            self.weights.close()
 
 
 def load_state_dict(path):
@@ -96,7 +103,7 @@ class DDColorRender:
     MODEL_FILES = {0: "ddcolor_modelscope.pth", 1: "ddcolor_artistic.pth"}          # __init__.py:2367-2371
 
     def __init__(self, model=1, input_size=512, device_index=0, state_dict=None, model_dir=None, depths=(3, 3, 27, 3), dec_layers=9,
-                 coalesce=0):
+                 coalesce=0, num_streams=None):
         """coalesce = N > 0: colorize_frame calls made concurrently by N threads (the filter's num_streams / VapourSynth's worker pool)
         are merged into batches of up to N frames (havc_batcher): a DDColor pass is 7.7 ms for one frame and 1.2 ms per frame at 16."""
         if model not in self.MODEL_FILES:
@@ -107,12 +114,17 @@ class DDColorRender:
             raise ValueError("device_index=99 (CPU) is not supported: this library is MI355X only")
         self.input_size = input_size
         if state_dict is None:
-            import os
             if model_dir is None:
                 raise ValueError("ddcolor: pass state_dict or model_dir (the vsddcolor models folder)")
             state_dict = load_state_dict(os.path.join(model_dir, self.MODEL_FILES[model]))
         self.rt = DDColorRuntime(get_context(device_index), state_dict, depths, dec_layers)
         self._coalesce, self._batchers = coalesce, {}
+        # num_streams (vsddcolor's parameter, vsslib/vsmodels.py:356; the reference's callers leave it at 1): clips of >= 8 frames are cut into
+        # that many parts which run concurrently, each on its own context / HIP stream with the same packed weights.  Frames are independent:
+        # same bytes.  Default 1: at 32 frames per call one chain already fills the chip better than two chains of 16 (c3: 883 vs 859 frames/s,
+        # c4: 655 vs 662; profiles/r3_conv_experiments.txt) -- the knob is for callers that hand over small clips from several places.
+        self.num_streams = int(os.environ.get("HAVC_DD_STREAMS", "1")) if num_streams is None else int(num_streams)
+        self._device_index, self._workers, self._pool = device_index, [], None
 
     def colorize_frame(self, frame):
         """u8 HWC in -> u8 HWC out, any frame size (the network runs at input_size)."""
@@ -138,7 +150,36 @@ class DDColorRender:
 
     def colorize_frames(self, frames, max_batch=None):
         """[N, H, W, 3] u8 (ndarray or DeviceImage) -> same kind"""
-        return self.rt.colorize(frames, self.input_size, max_batch)
+        from .device import is_device
+        n, S = frames.shape[0], max(1, self.num_streams)
+        if S == 1 or n < 8:
+            return self.rt.colorize(frames, self.input_size, max_batch)
+        import concurrent.futures
+        while len(self._workers) < S - 1:
+            k = len(self._workers) + 1
+            self._workers.append(DDColorRuntime(get_context(self._device_index, ("ddcolor", k)), None, share=self.rt))
+        if self._pool is None:
+            self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=S - 1)
+        dev = is_device(frames)
+        if not dev:
+            frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        out = frames.empty_like() if dev else np.empty_like(frames)
+        per = (n + S - 1) // S
+        cuts = [(k * per, min(n, (k + 1) * per)) for k in range(S) if k * per < n]
+        part_batch = min(per, max_batch) if max_batch else per
+        sub = (lambda a, lo, hi: a.frames(lo, hi)) if dev else (lambda a, lo, hi: a[lo:hi])
+        if dev:
+            self.rt.ctx.synchronize()                                  # the clip was produced on this context's stream; the others do not see it
+
+        def run(rt, lo, hi):
+            rt.colorize(sub(frames, lo, hi), self.input_size, part_batch, out=sub(out, lo, hi))
+            if dev and rt is not self.rt:
+                rt.ctx.synchronize()                                   # device clips are only enqueued: this context's stream must not run ahead of the others' parts
+        futs = [self._pool.submit(run, self._workers[k - 1], lo, hi) for k, (lo, hi) in enumerate(cuts) if k]
+        run(self.rt, *cuts[0])
+        for f in futs:
+            f.result()
+        return out
 
     def colorize_planar_float(self, planes):
         return self.rt.colorize_planar_float(planes, self.input_size)
