@@ -585,7 +585,7 @@ class ColorMNetNetwork:
             self._helper = ColorMNetNetwork(None, device_index=self.ctx.device_id, autotune=self.autotune, worker=("lookahead", self.worker), share=self)
         return self._helper
 
-    def prefetch_keys(self, frames, max_batch=None):
+    def prefetch_keys(self, frames, max_batch=None, _ordered=False):
         """frames: list of [3, H, W] device tensors, padded as InferenceCore pads them (pad_divide_by 112), in the order in which they will be
         stepped.  Returns one entry per frame; the caller (ColorMNetRender) keeps them and hands the frame's entry back through
         `expect_prefetched(entry)` right before the step, whose first encode_key call then takes it instead of computing.
@@ -600,11 +600,10 @@ class ColorMNetNetwork:
         net = hn._key_net(H, W, max_batch or B)
         h, w = H // 16, W // 16
         with self.on_stream():
-            img = torch.stack([f.to(self.device, torch.float32) for f in frames], 0).contiguous()
-            if hn is not self:
-                hn.stream.wait_stream(self.stream)                    # the frames (and whatever produced them) first
-                img.record_stream(hn.stream)
+            if hn is not self and not _ordered:
+                hn.stream.wait_stream(self.stream)                    # whatever this stream still owes the frames first
             with torch.cuda.stream(hn.stream):
+                img = torch.stack([f.to(self.device, torch.float32) for f in frames], 0).contiguous()
                 key, sel, shr = self._new(B, self.key_dim, h, w), self._new(B, self.key_dim, h, w), self._new(B, 1, h, w)
                 big, epf = {}, {}
                 feats = ("g16", "g8", "g4", "skip8", "skip4")
@@ -627,6 +626,50 @@ class ColorMNetNetwork:
                 entries.append((key[i:i + 1], shr[i:i + 1], sel[i:i + 1], _Feat(v[0], v[1], v[2], (H, W), v[3], v[4]), done, img))
         return entries
 
+    def lookahead_context(self):
+        """the libhavc context whose stream runs the look-ahead (callers that prepare frames for prefetch -- the Spline64 squash of
+        DeepExColorMNet -- enqueue there, off the memory step's stream); this network's own context when the look-ahead is synchronous"""
+        return self._helper_net().ctx if self.async_lookahead else self.ctx
+
+    def prefetch_frames(self, frames, max_batch=None):
+        """The whole look-ahead of ColorMNetRender for frames that will be stepped next, in order: RGB -> Lab, the L plane repeated and padded as
+        InferenceCore does it (pad_divide_by 112), then prefetch_keys -- ALL on the look-ahead stream, so that the memory step's stream is not
+        held up by any of it.  frames: u8 [H, W, 3] host arrays or DeviceImages of one size.  -> (Lab tensors, entries); the consumer calls
+        wait_prefetched(entry) before it touches the frame's Lab planes."""
+        import ctypes as C
+        import torch
+        from .colormnet_core import DIVIDE_BY, pad_divide_by
+        from .device import is_device
+        hn = self._helper_net() if self.async_lookahead else self
+        with self.on_stream():
+            if hn is not self:
+                hn.stream.wait_stream(self.stream)                    # frames the caller produced on this stream
+            with torch.cuda.stream(hn.stream):
+                labs, keep = [], []
+                for f in frames:
+                    if is_device(f):
+                        shape, ptr = f.shape, f.ptr
+                    else:
+                        a = np.ascontiguousarray(f, dtype=np.uint8)
+                        keep.append(a)
+                        shape, ptr = a.shape, nat.as_ptr(a)
+                    lab = self._new(3, shape[0], shape[1])
+                    nat.check(hn.ctx.lib.havc_colormnet_rgb_to_lab(hn.ctx.h, ptr, C.c_void_p(lab.data_ptr()), shape[1], shape[0]), hn.ctx.h)
+                    if hn is not self:
+                        lab.record_stream(self.stream)
+                    labs.append(lab)
+                padded = [pad_divide_by(lab[:1].repeat(3, 1, 1), DIVIDE_BY)[0] for lab in labs]
+            entries = self.prefetch_keys(padded, max_batch=max_batch, _ordered=True)
+        return labs, entries
+
+    def wait_prefetched(self, entry):
+        """make this network's stream wait for the look-ahead pass `entry` came from (its Lab planes and squashed frame included)"""
+        import torch
+        done = entry[4]
+        if done is not None:
+            with self.on_stream():
+                torch.cuda.current_stream(self.device).wait_event(done)
+
     def expect_prefetched(self, entry):
         """the NEXT encode_key call is for the frame `entry` was computed from (InferenceCore encodes the frame first, then an exemplar)"""
         self._armed = entry
@@ -640,7 +683,7 @@ class ColorMNetNetwork:
             if f.shape == tuple(frame.shape[-2:]):
                 if done is not None:
                     with self.on_stream():
-                        torch.cuda.current_stream(self.device).wait_event(done)     # the look-ahead pass that produced this entry
+                        torch.cuda.current_stream(self.device).wait_event(done)     # the look-ahead pass that produced this entry (idempotent)
                 return key, (shr if need_sk else None), (sel if need_ek else None), f, f, f
         H, W = frame.shape[-2:]
         net = self._net(H, W)

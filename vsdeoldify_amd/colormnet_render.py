@@ -128,8 +128,12 @@ class ColorMNetRender:
         if len({tuple(getattr(f, "shape", None) or np.asarray(f).shape) for f in frames}) != 1:
             return                                                      # frames of different sizes: no batched pass
         with self.network.on_stream():
-            labs = [self.network.image_to_lab(f if is_device(f) else np.asarray(f)) for f in frames]
-            entries = self.network.prefetch_keys([pad_divide_by(lab[:1].repeat(3, 1, 1), DIVIDE_BY)[0] for lab in labs], max_batch=self.lookahead)
+            srcs = [f if is_device(f) else np.asarray(f) for f in frames]
+            if hasattr(self.network, "prefetch_frames"):
+                labs, entries = self.network.prefetch_frames(srcs, max_batch=self.lookahead)
+            else:
+                labs = [self.network.image_to_lab(f) for f in srcs]
+                entries = self.network.prefetch_keys([pad_divide_by(lab[:1].repeat(3, 1, 1), DIVIDE_BY)[0] for lab in labs], max_batch=self.lookahead)
         for f, lab, ent in zip(frames, labs, entries):
             self._ahead.append((f, lab, ent))
 
@@ -161,6 +165,8 @@ class ColorMNetRender:
             ahead = self._ahead.popleft()
         elif self._ahead:                                               # the caller left the announced order: forget the look-ahead
             self._ahead.clear()
+        if ahead and hasattr(self.network, "wait_prefetched"):
+            self.network.wait_prefetched(ahead[2])                      # its Lab planes were computed on the look-ahead stream
         lab = ahead[1] if ahead else as_lab(frame_i)                    # [3,H,W] normalised Lab on the device (get_image :285-301)
         rgb = lab[:1].repeat(3, 1, 1)
         msk = as_lab(ref) if ref is not None else None
@@ -185,7 +191,7 @@ class ColorMNetRender:
         else:
             prob = self.processor.step(rgb, msk, labels, end=is_last)
         if is_device(frame_i):                                          # a frame that lives in HBM stays there: nothing blocks
-            out = self.network.lab_to_image(lab[:1], prob, out=DeviceImage(frame_i.ctx, frame_i.shape))
+            out = self.network.lab_to_image(lab[:1], prob, out=DeviceImage(getattr(self.network, "ctx", frame_i.ctx), frame_i.shape))
         else:
             out = Image.fromarray(self.network.lab_to_image(lab[:1], prob))
         self.img = self.ref_img_valid = out                             # save_last_image (:303-305)
@@ -228,7 +234,7 @@ class DeepExColorMNet:
             return int(round((round(w / rt, 0) - h) / 2, 0)), 0
         return 0, 0
 
-    def _squash(self, img):
+    def _squash(self, img, ctx=None):
         from .havc import spline64
         h, w = img.shape[:2]
         ph, pw = self._borders(h, w)
@@ -236,13 +242,13 @@ class DeepExColorMNet:
             from .device import is_device
             a = img.numpy() if is_device(img) else np.asarray(img)
             img = np.pad(a, ((ph, ph), (pw, pw), (0, 0)))                  # std.AddBorders: black
-        return spline64(self.ctx, img, self.tw, self.th), (ph, pw)
+        return spline64(ctx or self.ctx, img, self.tw, self.th), (ph, pw)
 
-    def _small(self, frame):
+    def _small(self, frame, ctx=None):
         """the frame as ColorMNetRender gets it (DeviceImage, or a PIL image) + the borders that were added"""
         from PIL import Image
         from .device import is_device
-        small, pads = self._squash(frame)
+        small, pads = self._squash(frame, ctx)
         return (small if is_device(small) else Image.fromarray(small)), pads
 
     def colorize_frame(self, frame, ref=None, _small=None):
@@ -270,7 +276,9 @@ class DeepExColorMNet:
         new = [f for f in frames if id(f) not in self._announced]
         if len(new) < 2 or self.render.lookahead <= 1:
             return
-        smalls = [self._small(f) for f in new]
+        net = self.render.network                                            # frames announced ahead are squashed on the look-ahead context's stream
+        la_ctx = net.lookahead_context() if hasattr(net, "lookahead_context") else None
+        smalls = [self._small(f, la_ctx) for f in new]
         self.render.prefetch([s for s, _ in smalls])
         for f, sm in zip(new, smalls):
             self._announced[id(f)] = (f, sm)                                 # (holding f keeps its id unique)
