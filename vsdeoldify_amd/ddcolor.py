@@ -103,7 +103,7 @@ class DDColorRender:
     MODEL_FILES = {0: "ddcolor_modelscope.pth", 1: "ddcolor_artistic.pth"}          # __init__.py:2367-2371
 
     def __init__(self, model=1, input_size=512, device_index=0, state_dict=None, model_dir=None, depths=(3, 3, 27, 3), dec_layers=9,
-                 coalesce=0, num_streams=None):
+                 coalesce=0, num_streams=None, worker=0):
         """coalesce = N > 0: colorize_frame calls made concurrently by N threads (the filter's num_streams / VapourSynth's worker pool)
         are merged into batches of up to N frames (havc_batcher): a DDColor pass is 7.7 ms for one frame and 1.2 ms per frame at 16."""
         if model not in self.MODEL_FILES:
@@ -117,7 +117,9 @@ class DDColorRender:
             if model_dir is None:
                 raise ValueError("ddcolor: pass state_dict or model_dir (the vsddcolor models folder)")
             state_dict = load_state_dict(os.path.join(model_dir, self.MODEL_FILES[model]))
-        self.rt = DDColorRuntime(get_context(device_index), state_dict, depths, dec_layers)
+        # worker: which context of the GPU the model lives on (render.get_context): a caller that runs DDColor next to another model (HAVC's
+        # DeOldify + DDColor methods) gives it a context of its own, i.e. its own HIP stream
+        self.rt = DDColorRuntime(get_context(device_index, worker), state_dict, depths, dec_layers)
         self._coalesce, self._batchers = coalesce, {}
         # num_streams (vsddcolor's parameter, vsslib/vsmodels.py:356; the reference's callers leave it at 1): clips of >= 8 frames are cut into
         # that many parts which run concurrently, each on its own context / HIP stream with the same packed weights.  Frames are independent:

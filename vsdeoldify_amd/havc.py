@@ -19,6 +19,7 @@ contract).
     col = HAVCFrameColorizer(method=2, mweight=0.4, package_dir=...); out = col.colorize(frame)
 """
 import math
+import os
 
 import numpy as np
 
@@ -88,6 +89,11 @@ class HAVCFrameColorizer:
         self._dd_kwargs = dict(ddcolor_kwargs or {})
         self._deoldify = self._ddcolor = self._zhang = None
         self._dd_size = None
+        # Methods that run BOTH models on a device clip run them side by side: DDColor on a context (HIP stream) of its own, from a second
+        # thread, while DeOldify runs on this one -- two independent chains of launches fill the chip better than one after the other
+        # (HAVC_OVERLAP_MODELS=0: one after the other on one stream).  Same bytes either way.
+        self.overlap_models = os.environ.get("HAVC_OVERLAP_MODELS", "1") != "0"
+        self._pool = None
 
     def _read_ddtweak(self, flags, tweaks):
         """vs_sc_ddcolor's tweak handling WITHOUT scene detection (vsslib/vsmodels.py:304-344,365-374; scenechange = False because
@@ -115,24 +121,26 @@ class HAVCFrameColorizer:
                                           "with neutral bright / cont (the defaults) is computed here")
             self.dd_levels = (luma_min, gamma, gamma_luma_min, gamma_alpha, gamma_min)
 
-    def _ddcolor_branch(self, sq, input_size):
-        """vs_sc_ddcolor (vsmodels.py:290-375) on the squashed clip: [pre-tweak ->] DDColor / Zhang [-> hue adjust] [-> luma of the clip back]"""
+    def _ddcolor_branch(self, sq, input_size, ctx=None):
+        """vs_sc_ddcolor (vsmodels.py:290-375) on the squashed clip: [pre-tweak ->] DDColor / Zhang [-> hue adjust] [-> luma of the clip back].
+        ctx: the context the branch's filters run on (the DDColor context when the two models run side by side)"""
+        ctx = ctx or self.ctx
         src = sq
         if self.dd_levels is not None:                                # sc_constrained_tweak(scenechange=False): luma_adjusted_levels per frame
-            frames = [F.luma_adjusted_levels_np(self.ctx, sq.frame(i) if is_device(sq) else sq[i], *self.dd_levels) for i in range(sq.shape[0])]
+            frames = [F.luma_adjusted_levels_np(ctx, sq.frame(i) if is_device(sq) else sq[i], *self.dd_levels) for i in range(sq.shape[0])]
             if is_device(sq):
-                src = DeviceImage(self.ctx, sq.shape)
+                src = DeviceImage(ctx, sq.shape)
                 for i, f in enumerate(frames):
                     src.frame(i).copy_from(f)
             else:
                 src = np.stack(frames)
         b = self._ddcolor_clip(src, input_size)
         if self.dd_hue_adjust not in ("none", ""):
-            b = F.adjust_hue_range_np(self.ctx, b if is_device(b) else b.reshape((-1,) + b.shape[2:]), self.dd_hue_adjust)
+            b = F.adjust_hue_range_np(ctx, b if is_device(b) else b.reshape((-1,) + b.shape[2:]), self.dd_hue_adjust)
             if not is_device(b):
                 b = b.reshape(sq.shape)
         if self.dd_tweaks_enabled:
-            b = F.chroma_post_process_np(self.ctx, b if is_device(b) else b.reshape((-1,) + b.shape[2:]),
+            b = F.chroma_post_process_np(ctx, b if is_device(b) else b.reshape((-1,) + b.shape[2:]),
                                          sq if is_device(sq) else sq.reshape((-1,) + sq.shape[2:]))
             if not is_device(b):
                 b = b.reshape(sq.shape)
@@ -147,19 +155,27 @@ class HAVCFrameColorizer:
                                               state_dicts=self._sds, max_batch=self.max_batch)
         return self._deoldify
 
+    def _ddcolor_model(self, input_size):
+        if self._ddcolor is None or self._dd_size != input_size:
+            from .ddcolor import DDColorRender
+            kw = dict(self._dd_kwargs)
+            if self._side_by_side():
+                kw.setdefault("worker", ("havc-ddcolor", 0))
+            self._ddcolor = DDColorRender(self.ddcolor_model, input_size, self.device_index, state_dict=self._dd_sd, model_dir=self._dd_dir, **kw)
+            self._dd_size = input_size
+        return self._ddcolor
+
     def _ddcolor_clip(self, sq, input_size):
         """sq: [n, fs, fs, 3] ndarray or DeviceImage -> same kind"""
         if self.ddcolor_model in (0, 1):
-            if self._ddcolor is None or self._dd_size != input_size:
-                from .ddcolor import DDColorRender
-                self._ddcolor = DDColorRender(self.ddcolor_model, input_size, self.device_index, state_dict=self._dd_sd, model_dir=self._dd_dir,
-                                              **self._dd_kwargs)
-                self._dd_size = input_size
-            return self._ddcolor.colorize_frames(sq, max_batch=self.max_batch)
+            return self._ddcolor_model(input_size).colorize_frames(sq, max_batch=self.max_batch)
         from .colorization import ModelColorization                                               # vsmodels.py:346-350
         if self._zhang is None:
             self._zhang = ModelColorization("siggraph17" if self.ddcolor_model == 2 else "eccv16", True, self.device_index, state_dict=self._zh_sd)
         return self._zhang.colorize_frames(sq)                                                    # host or device clip: havc_zhang_frames takes both
+
+    def _side_by_side(self):
+        return self.overlap_models and self.method not in (0, 1) and self.ddcolor_model in (0, 1)
 
     def _deoldify_clip(self, sq):
         """ModelImageRender over a clip.  Frames at the model's render size (the usual case: frame_size is derived from the larger
@@ -197,10 +213,26 @@ class HAVCFrameColorizer:
         dclip = DeviceImage.from_numpy(self.ctx, clip) if host_in else clip
         sq = dclip if (w, h) == (fs, fs) else self._spline64(dclip, fs, fs)
         a = b = None
-        if self.method != 1:
+        dd_size = math.trunc(dd_rf / 2) * 32                                                      # vsmodels.py:302
+        if self._side_by_side() and is_device(sq):
+            import concurrent.futures
+            if self._pool is None:
+                self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+            self.ctx.synchronize()                                                                # the squashed clip is complete: the other context may read it
+
+            def branch():
+                bctx = self._ddcolor_model(dd_size).rt.ctx
+                out = self._ddcolor_branch(sq, dd_size, bctx)
+                bctx.synchronize()                                                                # (only enqueued: this context must not run ahead of it)
+                return out
+            fut = self._pool.submit(branch)
             a = self._deoldify_clip(sq)
-        if self.method != 0:
-            b = self._ddcolor_branch(sq, math.trunc(dd_rf / 2) * 32)                             # vsmodels.py:302
+            b = fut.result()
+        else:
+            if self.method != 1:
+                a = self._deoldify_clip(sq)
+            if self.method != 0:
+                b = self._ddcolor_branch(sq, dd_size)
         col = self._combine(a, b)
         out = self._spline64(col, w, h, luma_from=dclip)
         if host_in:
