@@ -216,3 +216,27 @@ def test_legacy_entry_points_forward_like_the_reference(ctx):
         assert np.array_equal(havc.ddeoldify(frame, cmc_tresh=0.2, **kw), want)
     with pytest.raises(NotImplementedError):
         havc.HAVC_ddeoldify(frame, ddtweak=True, ddtweak_p=([5.0, 1.0, 2.5, True, 0.3, 0.6, 1.5, 0.5], "none"), **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("method", [2, 5])
+def test_two_models_side_by_side_give_the_bytes_of_one_after_the_other(ctx, method):
+    """Methods that run DeOldify AND DDColor put DDColor on a context (HIP stream) of its own and run the two from two threads
+    (HAVCFrameColorizer.overlap_models).  Outputs live in the pool of the context that produced them and cross contexts only behind a
+    synchronize(): repeated clips, device-resident and host, give exactly the bytes of the sequential path, call after call."""
+    from vsdeoldify_amd.device import DeviceImage
+    sds, dsd = _weights()
+    clip = np.stack([_frame(20 + i, 96, 160) for i in range(5)])
+    kw = dict(method=method, mweight=0.4, deoldify_p=(0, 6, 1.0, 0.0), ddcolor_p=(1, 12, 1.0, 0.0, True), state_dicts=sds, ddcolor_state_dict=dsd,
+              ddcolor_kwargs=SMALL_DD, ddtweak=[True, False, False])
+    seq = havc.HAVCFrameColorizer(**kw)
+    seq.overlap_models = False
+    want = seq.colorize_clip(clip)
+    par = havc.HAVCFrameColorizer(**kw)
+    assert par.overlap_models and par._side_by_side()
+    dclip = DeviceImage.from_numpy(par.ctx, clip)
+    for rep in range(6):
+        got = par.colorize_clip(dclip if rep % 2 else clip)
+        got = got.numpy() if rep % 2 else got
+        assert np.array_equal(got, want), (method, rep, int(np.abs(got.astype(int) - want.astype(int)).max()))
+    assert par._ddcolor.rt.ctx is not par.ctx

@@ -78,7 +78,8 @@ class ModelColorization:
         if not dev:
             frames = np.ascontiguousarray(frames, dtype=np.uint8)
         n, h, w, _ = frames.shape
-        out = frames.empty_like() if dev else np.empty_like(frames)
+        from .device import DeviceImage
+        out = DeviceImage(self.ctx, frames.shape) if dev else np.empty_like(frames)
         nat.check(self.ctx.lib.havc_zhang_frames(self.ctx.h, self.net.h, operand_ptr(frames), operand_ptr(out), n, w, h), self.ctx.h)
         return out
 

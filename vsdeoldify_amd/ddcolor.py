@@ -56,7 +56,8 @@ class DDColorRuntime:
         n = frames.shape[0]
         net = self.net(S, max_batch or min(n, 8))
         if out is None:
-            out = frames.empty_like() if dev else np.empty_like(frames)
+            from .device import DeviceImage
+            out = DeviceImage(self.ctx, frames.shape) if dev else np.empty_like(frames)      # this context's pool: its stream orders the reuse
         nat.check(self.ctx.lib.havc_ddcolor_frames(self.ctx.h, net.h, operand_ptr(frames), operand_ptr(out), n, frames.shape[2],
                                                    frames.shape[1]), self.ctx.h)
         return out
@@ -152,7 +153,7 @@ class DDColorRender:
 
     def colorize_frames(self, frames, max_batch=None):
         """[N, H, W, 3] u8 (ndarray or DeviceImage) -> same kind"""
-        from .device import is_device
+        from .device import DeviceImage, is_device
         n, S = frames.shape[0], max(1, self.num_streams)
         if S == 1 or n < 8:
             return self.rt.colorize(frames, self.input_size, max_batch)
@@ -165,7 +166,7 @@ class DDColorRender:
         dev = is_device(frames)
         if not dev:
             frames = np.ascontiguousarray(frames, dtype=np.uint8)
-        out = frames.empty_like() if dev else np.empty_like(frames)
+        out = DeviceImage(self.rt.ctx, frames.shape) if dev else np.empty_like(frames)
         per = (n + S - 1) // S
         cuts = [(k * per, min(n, (k + 1) * per)) for k in range(S) if k * per < n]
         part_batch = min(per, max_batch) if max_batch else per

@@ -8,7 +8,11 @@ merge method -> up-sample + luma) composes without a single PCIe hop, and nothin
 
 Allocation goes through a per-context free list (`hipMalloc` / `hipFree` synchronise the device): a buffer released by
 `__del__` is handed to the next request of the same size.  All work of a ctx is ordered on its one stream, so recycling a
-buffer behind work that is still queued is safe.
+buffer behind work that is still queued is safe -- AS LONG AS the buffer comes from the pool of the context that runs the work.
+That is the rule the wrappers follow: an output is allocated in the pool of the EXECUTING context (`DeviceImage(ctx, shape)`), never
+in the pool of an operand that may belong to another context (two models side by side on two contexts, havc.py: a buffer taken from
+the other context's pool could still be in use by work queued on that context's stream).  A buffer that crosses contexts (an operand
+produced on one, consumed on the other) is handed over behind a `synchronize()` of the producer.
 """
 import ctypes as C
 

@@ -13,7 +13,7 @@ from .render import get_context
 def _one(ctx, a):
     """operand + matching output buffer: ndarray -> ndarray, DeviceImage -> DeviceImage"""
     if is_device(a):
-        return a, a.empty_like()
+        return a, DeviceImage(ctx or a.ctx, a.shape)           # the output lives in the pool of the context that RUNS the filter (device.py)
     a = np.ascontiguousarray(a, dtype=np.uint8)
     if a.ndim != 3 or a.shape[2] != 3:
         raise ValueError("not an RGB image")
@@ -27,7 +27,7 @@ def _prep(a, b, ctx=None):
         b = b if is_device(b) else DeviceImage.from_numpy(ctx, b)
         if a.shape != b.shape:
             raise ValueError("images do not match")
-        return a, b, a.empty_like()
+        return a, b, DeviceImage(ctx, a.shape)
     a = np.ascontiguousarray(a, dtype=np.uint8)
     b = np.ascontiguousarray(b, dtype=np.uint8)
     if a.shape != b.shape or a.ndim != 3 or a.shape[2] != 3:
@@ -109,7 +109,7 @@ def color_temporal_stabilizer_np(ctx, frames, weight_list):
         raise ValueError("frames / weight_list mismatch (1..9 frames of one size)")
     ptrs = (C.c_void_p * len(frames))(*[(f.ptr.value if is_device(f) else f.ctypes.data) for f in frames])
     w = np.array([float(x) / 100.0 for x in weight_list], np.float64)         # weight_list is in percent (imfilters.py:690)
-    out = frames[0].empty_like() if dev else np.empty_like(frames[0])
+    out = DeviceImage(ctx, frames[0].shape) if dev else np.empty_like(frames[0])
     nat.check(ctx.lib.havc_color_temporal_stabilizer(ctx.h, C.cast(ptrs, C.c_void_p), nat.as_ptr(w), len(frames), _p(out),
                                                      *_wh(out)), ctx.h)
     return out

@@ -140,7 +140,7 @@ class ModelImageRender:
     # -- raw batched entry (frames already S x S, uint8 [n,S,S,3]) ------------------------------
     def render_square_batch(self, frames, post_process=True):
         """uint8 [n, S, S, 3] (ndarray, or a device.DeviceImage: then nothing leaves HBM and the call does not block)"""
-        from .device import is_device, operand_ptr
+        from .device import DeviceImage, is_device, operand_ptr
         dev = is_device(frames)
         if not dev:
             frames = np.ascontiguousarray(frames, dtype=np.uint8)
@@ -148,7 +148,7 @@ class ModelImageRender:
         assert tuple(frames.shape[1:]) == (S, S, 3) and S == self._render_factor * RENDER_BASE
         v = self._video.net(S, self._max_batch)
         s = self._second.net(S, self._max_batch) if self._second else None
-        out = frames.empty_like() if dev else np.empty_like(frames)
+        out = DeviceImage(self.ctx, frames.shape) if dev else np.empty_like(frames)
         nat.check(self.ctx.lib.havc_deoldify_frames(self.ctx.h, v.h, s.h if s else None, float(self._video_weight),
                                                     1 if post_process else 0, operand_ptr(frames), operand_ptr(out), n),
                   self.ctx.h)
