@@ -502,15 +502,15 @@ def c5_reference_image(gray_small):
 
 def bench_c5(args, rank, local_rank, world, dist):
     """BASELINE configs[4]: ColorMNet exemplar path, 1 reference frame, 1080p clip (HAVC_deepex(ex_model=0), __init__.py:1421-1735):
-    Spline64 1080p -> 384 x 216 (SmartResizeColorizer) -> ColorMNetRender.colorize_frame, frame after frame (the memory carries state:
-    strictly sequential) -> Spline64 back to 1080p + luma of the source (vs_recover_clip_luma).  The clip stays in HBM; the reference
+    Spline64 1080p -> 384 x 216 (SmartResizeColorizer) -> ColorMNetRender.colorize_frame, frame after frame (the memory carries state: that
+    step is strictly sequential; the key encoder, which depends on the frame alone, runs `lookahead` frames ahead on its own stream)
+    -> Spline64 back to 1080p + luma of the source (vs_recover_clip_luma).  The clip stays in HBM; the reference
     image arrives with frame 0 (in the warm-up), the timed steps are steady-state frames incl. memory frames every 5th frame and the
     long-term consolidation.  One step = --batch consecutive frames.  Sequential in time => replicas only across GPUs (one clip per GPU)."""
     import torch
     from vsdeoldify_amd import _native as nat
     from vsdeoldify_amd.clip import synthetic_gray_frame
     from vsdeoldify_amd.colormnet_net import ColorMNetNetwork
-    from vsdeoldify_amd.colormnet_render import ColorMNetRender
     from vsdeoldify_amd.device import DeviceImage
     from vsdeoldify_amd.synth import synth_colormnet_state_dict
     sd = synth_colormnet_state_dict(1)

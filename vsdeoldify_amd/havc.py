@@ -249,7 +249,6 @@ class HAVCFrameColorizer:
 def spline64(ctx, img, w, h, luma_from=None):
     """the harness stand-in of `resize.Spline64` (+ vs_recover_clip_luma when luma_from is given) on frames or clips,
     host or device operands"""
-    import ctypes as C
     dev = is_device(img) or is_device(luma_from)
     if dev:
         img = img if is_device(img) else DeviceImage.from_numpy(ctx, img)
