@@ -86,7 +86,10 @@ class KeyValueMemoryStore:
                 self.objects = objs
             elif objs != self.objects:
                 raise NotImplementedError("objects entering after the first frame (a second object group) are not supported")
-            value = value[objs]
+            # (value[objs] with a Python list builds its index tensor on the host and uploads it from pageable memory: the call BLOCKS until the
+            #  stream has drained -- 3.3 ms per memory frame, half the host time of a clip, found with tools/cmn_host_probe.py)
+            if objs != list(range(value.shape[0])):
+                value = torch.stack([value[o] for o in objs], 0)
         else:                                                  # long-term memory: list of per-group tensors
             if len(value) != 1:
                 raise NotImplementedError("one object group only")

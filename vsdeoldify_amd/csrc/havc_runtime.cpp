@@ -111,6 +111,10 @@ hipError_t sync_streams(havc_ctx* c) {
 
 int ensure_scratch(havc_ctx* c, int slot, size_t nbytes) {
     if (c->scratch_sz[slot] >= nbytes) return HAVC_OK;
+    // a regrow costs a device synchronisation (hipFree / hipMalloc): grow by at least half, so that a request that creeps up call after call
+    // (ColorMNet's memory read: the memory gains a frame every fifth frame) stalls the stream a handful of times, not every time
+    if (c->scratch[slot]) nbytes = std::max(nbytes, c->scratch_sz[slot] + c->scratch_sz[slot] / 2);
+    nbytes = (nbytes + 4095) & ~(size_t)4095;
     if (c->scratch[slot]) {
         HIP_TRY(c, sync_streams(c));
         (void)hipFree(c->scratch[slot]);
