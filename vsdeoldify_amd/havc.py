@@ -93,7 +93,7 @@ class HAVCFrameColorizer:
         # thread, while DeOldify runs on this one -- two independent chains of launches fill the chip better than one after the other
         # (HAVC_OVERLAP_MODELS=0: one after the other on one stream).  Same bytes either way.
         self.overlap_models = os.environ.get("HAVC_OVERLAP_MODELS", "1") != "0"
-        self._pool = None
+        self._pool, self._warmed = None, set()
 
     def _read_ddtweak(self, flags, tweaks):
         """vs_sc_ddcolor's tweak handling WITHOUT scene detection (vsslib/vsmodels.py:304-344,365-374; scenechange = False because
@@ -214,7 +214,8 @@ class HAVCFrameColorizer:
         sq = dclip if (w, h) == (fs, fs) else self._spline64(dclip, fs, fs)
         a = b = None
         dd_size = math.trunc(dd_rf / 2) * 32                                                      # vsmodels.py:302
-        if self._side_by_side() and is_device(sq):
+        shape_key = (tuple(sq.shape), dd_size)
+        if self._side_by_side() and is_device(sq) and shape_key in self._warmed:
             import concurrent.futures
             if self._pool is None:
                 self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
@@ -229,10 +230,18 @@ class HAVCFrameColorizer:
             a = self._deoldify_clip(sq)
             b = fut.result()
         else:
+            # (also the FIRST clip of a shape: building the two models, their nets and the tile autotuning -- allocations, trial launches, first
+            #  loads of every kernel -- happens one model after the other; only warmed-up launch chains run side by side)
             if self.method != 1:
                 a = self._deoldify_clip(sq)
             if self.method != 0:
-                b = self._ddcolor_branch(sq, dd_size)
+                bctx = self._ddcolor_model(dd_size).rt.ctx if self._side_by_side() else None
+                if bctx is not None:
+                    self.ctx.synchronize()
+                b = self._ddcolor_branch(sq, dd_size, bctx)
+                if bctx is not None:
+                    bctx.synchronize()
+            self._warmed.add(shape_key)
         col = self._combine(a, b)
         out = self._spline64(col, w, h, luma_from=dclip)
         if host_in:
