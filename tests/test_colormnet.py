@@ -85,6 +85,23 @@ def test_gpu_local_attention_matches_reference_vectors(ctx, gl):
 
 
 @pytest.mark.gpu
+def test_gpu_memory_read_with_ties_at_the_threshold(ctx):
+    """a memory that holds the same frames twice (a static shot): every similarity occurs twice, the k-th largest value is tied.  The selection
+    takes the values above it and then, in ascending memory index, as many of the tied ones as still fit (wave-per-query radix select); which of
+    two identical elements is taken does not change the readout.  k odd: a tie is split.  Also: the same call twice gives the same bytes."""
+    from vsdeoldify_amd import colormnet as M
+    g = torch.Generator().manual_seed(77)
+    B, CK, CV, n, HW, k = 1, 64, 24, 700, 130, 31
+    mk1, mv1, ms1 = torch.randn(B, CK, n, generator=g) * 0.4, torch.randn(B, CV, n, generator=g), torch.rand(B, n, generator=g) + 1
+    mk, mv, ms = torch.cat([mk1, mk1], -1), torch.cat([mv1, mv1], -1), torch.cat([ms1, ms1], -1)
+    qk, qe = torch.randn(B, CK, HW, generator=g) * 0.4, torch.rand(B, CK, HW, generator=g)
+    ref = O.memory_read(mk, ms, qk, qe, mv, k)
+    got = M.match_memory_readout(mk, ms, qk, qe, mv, k)
+    assert torch.allclose(got, ref, rtol=2e-4, atol=2e-4), float((got - ref).abs().max())
+    assert torch.equal(got, M.match_memory_readout(mk, ms, qk, qe, mv, k))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,C,Cv,h,w,R,dil", [(1, 64, 96, 23, 37, 7, 1), (2, 64, 32, 9, 8, 7, 1), (1, 32, 40, 17, 5, 3, 2), (1, 64, 33, 30, 30, 7, 1)])
 def test_gpu_local_attention_matches_oracle(ctx, n, C, Cv, h, w, R, dil):
     """sizes that are not multiples of the 8 x 8 tile, a smaller window, dilation 2, value widths off the 32-channel chunk"""

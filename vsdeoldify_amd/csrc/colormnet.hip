@@ -16,7 +16,8 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // ---- similarity[n][q] = (-sum_c mk^2 qe + 2 sum_c mk (qk qe) - sum_c qe qk^2) * ms[n] / sqrt(CK)   (memory_util.py:19-37) ----
 // Block = 64 memory entries x 64 queries, 256 threads, thread = 4 x 4 outputs; the three sums are kept apart and combined as the
 // reference combines them (-a_sq + two_ab - b_sq).
-template <bool HAS_QE>
+// TRANSPOSED: the result goes out query-major, simT[b][q][n] (the wave-per-query top-k below reads one contiguous row per query)
+template <bool HAS_QE, bool TRANSPOSED = false>
 __global__ void __launch_bounds__(256) mem_similarity_kernel(const float* __restrict__ mk, const float* __restrict__ ms, const float* __restrict__ qk,
                                                              const float* __restrict__ qe, float* __restrict__ sim, int CK, int N, int HW, float sqrt_ck) {
     __shared__ float Ms[16][64 + 1], Qs[16][64 + 1], Es[16][64 + 1];
@@ -71,7 +72,8 @@ __global__ void __launch_bounds__(256) mem_similarity_kernel(const float* __rest
             if (q >= HW) continue;
             float s = HAS_QE ? (-a_sq[i][j] + 2.f * two_ab[i][j] - b_sq[j]) : (-a_sq[i][0] + 2.f * two_ab[i][j]);
             s = ms ? s * sc / sqrt_ck : s / sqrt_ck;                  // `similarity * ms / math.sqrt(CK)`
-            sim[((int64_t)b * N + n) * HW + q] = s;
+            if (TRANSPOSED) sim[((int64_t)b * HW + q) * N + n] = s;
+            else sim[((int64_t)b * N + n) * HW + q] = s;
         }
     }
 }
@@ -222,6 +224,90 @@ __global__ void __launch_bounds__(64) mem_topk_merge_kernel(const float* __restr
         const int64_t o = ((int64_t)b * K + lane) * HW + q;
         idx[o] = sel_i[lane];
         wgt[o] = sum > 0.f ? e / sum : 0.f;
+    }
+}
+
+// ---- top-k, wave per query (round 3): the query's similarity row (query-major simT, N <= 64 NV elements) is loaded ONCE into registers as
+// order-preserving integer keys; the k-th largest key is built bit by bit (32 rounds of "how many keys >= candidate": compare + add over the
+// registers, one wave reduction per round); then the keys above it and, in ascending memory index, as many of the keys EQUAL to it as are still
+// needed are compacted with ballots into the k slots, with their softmax weights exp(v) / sum (no max subtraction: memory_util.py:44-47).
+// Exactly k outputs by construction, no candidate lists, no sort; ties resolved as a single ascending scan would.  (The two-level kernels above
+// keep a running top-k per thread in LDS: 118 + 27 us per ColorMNet frame at 4 288 memory elements; this one: a tenth of that.)
+__device__ __forceinline__ unsigned f2key(float v) {
+    const unsigned b = __float_as_uint(v);
+    return b ^ ((unsigned)((int)b >> 31) | 0x80000000u);
+}
+template <int NV>
+__global__ void __launch_bounds__(256) mem_topk_select_kernel(const float* __restrict__ simT, int* __restrict__ idx, float* __restrict__ wgt, int N, int HW, int K) {
+    const int lane = threadIdx.x & 63, q = blockIdx.x * 4 + (threadIdx.x >> 6), b = blockIdx.y;
+    if (q >= HW) return;
+    const float* row = simT + ((int64_t)b * HW + q) * N;
+    unsigned key[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {                                  // (clamped, unconditional loads: all of them in flight at once)
+        const int n = i * 64 + lane;
+        const float v = row[n < N ? n : N - 1];
+        key[i] = n < N ? f2key(v) : 0u;                             // 0 is below the key of every float (incl. -inf): padding never wins
+    }
+    const int Keff = K < N ? K : N;
+    unsigned thr = 0u;
+    if (N > K) {
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned cand = thr | (1u << bit);
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) cnt += key[i] >= cand ? 1 : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if (cnt >= K) thr = cand;
+        }
+    }
+    // how many are strictly above the threshold, and the softmax denominator over the selected set
+    int ngt = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) ngt += (key[i] > thr && i * 64 + lane < N) ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ngt += __shfl_xor(ngt, o);
+    const int need_eq = Keff - ngt;                                 // ties at the threshold that still fit, lowest memory index first
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    // softmax denominator over the selected set: the keys above the threshold + need_eq copies of the threshold value itself
+    auto unkey = [](unsigned kb) { return __uint_as_float((kb & 0x80000000u) ? (kb ^ 0x80000000u) : ~kb); };
+    auto expv = [](float v) { return v == -INFINITY ? 0.f : expf(v); };
+    float part = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (key[i] > thr && i * 64 + lane < N) part += expv(unkey(key[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+    const float e_thr = need_eq > 0 ? expv(unkey(thr)) : 0.f;       // (no ties wanted, e.g. fewer memory elements than k: thr = 0 is no float's key)
+    part += (float)need_eq * e_thr;
+    const float inv = part > 0.f ? 1.f / part : 0.f;
+    int base_g = 0, base_e = 0;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const bool live = i * 64 + lane < N;
+        const bool g = live && key[i] > thr, e = live && key[i] == thr;
+        const unsigned long long mg = __ballot(g), me = __ballot(e);
+        int sl = -1;
+        if (g) sl = base_g + __popcll(mg & lt);
+        else if (e) {
+            const int r = base_e + __popcll(me & lt);
+            if (r < need_eq) sl = ngt + r;
+        }
+        base_g += __popcll(mg);
+        base_e += __popcll(me);
+        if (sl >= 0) {
+            const int64_t o = ((int64_t)b * K + sl) * HW + q;
+            idx[o] = i * 64 + lane;
+            unsigned kk = key[i];
+            asm volatile("" : "+v"(kk));                                // (recompute exp here: otherwise NV exponentials of the loop above are kept alive)
+            wgt[o] = (g ? expv(unkey(kk)) : e_thr) * inv;
+        }
+    }
+    for (int j = Keff + lane; j < K; j += 64) {                     // fewer memory elements than k: the remaining slots carry no weight
+        const int64_t o = ((int64_t)b * K + j) * HW + q;
+        idx[o] = 0;
+        wgt[o] = 0.f;
     }
 }
 
@@ -527,6 +613,31 @@ int launch_mem_similarity(const float* mk, const float* ms, const float* qk, con
     const float sq = sqrtf((float)CK);
     if (qe) hipLaunchKernelGGL(mem_similarity_kernel<true>, grid, dim3(256), 0, s, mk, ms, qk, qe, sim, CK, N, HW, sq);
     else hipLaunchKernelGGL(mem_similarity_kernel<false>, grid, dim3(256), 0, s, mk, ms, qk, qe, sim, CK, N, HW, sq);
+    return (int)hipGetLastError();
+}
+
+int launch_mem_similarity_t(const float* mk, const float* ms, const float* qk, const float* qe, float* simT, int B, int CK, int N, int HW, hipStream_t s) {
+    dim3 grid(cdiv(HW, 64), cdiv(N, 64), B);
+    const float sq = sqrtf((float)CK);
+    if (qe) hipLaunchKernelGGL((mem_similarity_kernel<true, true>), grid, dim3(256), 0, s, mk, ms, qk, qe, simT, CK, N, HW, sq);
+    else hipLaunchKernelGGL((mem_similarity_kernel<false, true>), grid, dim3(256), 0, s, mk, ms, qk, qe, simT, CK, N, HW, sq);
+    return (int)hipGetLastError();
+}
+
+// the wave-per-query selection holds the row in registers: up to 64 x 128 = 8 192 memory elements (beyond: the two-level kernels)
+bool mem_topk_select_supported(int N) { return N <= 64 * 128; }
+
+int launch_mem_topk_select_readout(const float* simT, const float* mv, int* idx, float* wgt, float* out, int B, int CV, int N, int HW, int K, hipStream_t s) {
+    if (K < 1 || K > TOPK_MAX || !mem_topk_select_supported(N)) return (int)hipErrorInvalidValue;
+    dim3 grid(cdiv(HW, 4), B);
+    const int nv = cdiv(N, 64);
+    if (nv <= 32) hipLaunchKernelGGL(mem_topk_select_kernel<32>, grid, dim3(256), 0, s, simT, idx, wgt, N, HW, K);
+    else if (nv <= 64) hipLaunchKernelGGL(mem_topk_select_kernel<64>, grid, dim3(256), 0, s, simT, idx, wgt, N, HW, K);
+    else if (nv <= 96) hipLaunchKernelGGL(mem_topk_select_kernel<96>, grid, dim3(256), 0, s, simT, idx, wgt, N, HW, K);
+    else hipLaunchKernelGGL(mem_topk_select_kernel<128>, grid, dim3(256), 0, s, simT, idx, wgt, N, HW, K);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(mem_readout_kernel, dim3(cdiv(HW, 64), cdiv(CV, 64), B), dim3(256), 0, s, mv, idx, wgt, out, CV, N, HW, K);
     return (int)hipGetLastError();
 }
 

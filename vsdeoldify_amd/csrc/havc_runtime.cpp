@@ -1977,9 +1977,18 @@ int havc_memory_read_topk_usage(havc_ctx* c, const float* mk, const float* ms, c
     const size_t lst = (size_t)B * top_k * HW, cand = lst * (mem_topk_splits(N) > 1 ? mem_topk_splits(N) : 0);
     if ((rc = ensure_scratch(c, 8, (size_t)B * N * HW * 4)) || (rc = ensure_scratch(c, 9, (lst + cand) * 4)) ||
         (rc = ensure_scratch(c, 10, (lst + cand) * 4))) return rc;
-    int e = launch_mem_similarity(d_mk, d_ms, d_qk, d_qe, (float*)c->scratch[8], B, CK, N, HW, c->stream);
-    if (!e) e = launch_mem_topk_readout((const float*)c->scratch[8], d_mv, (int*)c->scratch[9], (float*)c->scratch[10], (float*)c->scratch[10] + lst,
-                                        (int*)c->scratch[9] + lst, (float*)d_out, B, CV, N, HW, top_k, c->stream);
+    // wave-per-query selection on a query-major similarity (HAVC_TOPK_WAVE=0: the two-level kernels; also beyond 8 192 memory elements)
+    static const bool wave_topk = [] { const char* e = getenv("HAVC_TOPK_WAVE"); return !e || atoi(e) != 0; }();
+    int e;
+    if (wave_topk && mem_topk_select_supported(N)) {
+        e = launch_mem_similarity_t(d_mk, d_ms, d_qk, d_qe, (float*)c->scratch[8], B, CK, N, HW, c->stream);
+        if (!e) e = launch_mem_topk_select_readout((const float*)c->scratch[8], d_mv, (int*)c->scratch[9], (float*)c->scratch[10], (float*)d_out, B, CV, N, HW,
+                                                   top_k, c->stream);
+    } else {
+        e = launch_mem_similarity(d_mk, d_ms, d_qk, d_qe, (float*)c->scratch[8], B, CK, N, HW, c->stream);
+        if (!e) e = launch_mem_topk_readout((const float*)c->scratch[8], d_mv, (int*)c->scratch[9], (float*)c->scratch[10], (float*)c->scratch[10] + lst,
+                                            (int*)c->scratch[9] + lst, (float*)d_out, B, CV, N, HW, top_k, c->stream);
+    }
     c->stats.launches += 3;
     if (e) return hip_fail(c, (hipError_t)e, "memory_read_topk");
     if (usage) {                                               // row sums of the sparse affinity (do_softmax(..., return_usage=True))

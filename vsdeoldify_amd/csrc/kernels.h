@@ -149,6 +149,9 @@ int launch_mem_similarity(const float* mk, const float* ms, const float* qk, con
 int launch_mem_usage(const int* idx, const float* wgt, unsigned long long* acc, float* usage, int B, int N, int HW, int K, hipStream_t s);
 int launch_mem_dense_readout(const float* sim, const float* mv, float* out, int B, int CV, int N, int P, hipStream_t s);
 int mem_topk_splits(int N);
+int launch_mem_similarity_t(const float* mk, const float* ms, const float* qk, const float* qe, float* simT, int B, int CK, int N, int HW, hipStream_t s);
+bool mem_topk_select_supported(int N);
+int launch_mem_topk_select_readout(const float* simT, const float* mv, int* idx, float* wgt, float* out, int B, int CV, int N, int HW, int K, hipStream_t s);
 int launch_mem_topk_readout(const float* sim, const float* mv, int* idx, float* wgt, float* cand_val, int* cand_idx, float* out, int B, int CV, int N,
                             int HW, int K, hipStream_t s);
 int launch_local_correlation(const float* q, const float* k, float* out, int n, int C, int H, int W, int R, int dil, float qscale, hipStream_t s);
