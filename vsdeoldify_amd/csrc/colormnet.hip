@@ -6,6 +6,7 @@
 // (157 TF/s = the vector rate): the similarity is a 64-deep contraction, everything else is selection / gather / window sums --
 // LDS-tiled fp32 FMA, coalesced along the query / pixel axis.
 #include "kernels.h"
+#include <atomic>
 
 #include <cmath>
 
@@ -305,6 +306,74 @@ __global__ void __launch_bounds__(256) mem_topk_select_kernel(const float* __res
         }
     }
     for (int j = Keff + lane; j < K; j += 64) {                     // fewer memory elements than k: the remaining slots carry no weight
+        const int64_t o = ((int64_t)b * K + j) * HW + q;
+        idx[o] = 0;
+        wgt[o] = 0.f;
+    }
+}
+
+// The same selection for longer rows (8 192 < N <= 16 384: a clip whose long-term memory has filled up): one block of four waves per query, the
+// keys in LDS instead of registers, block-wide counts per round; the compaction is done by wave 0 alone (N / 64 ballots).
+__global__ void __launch_bounds__(256) mem_topk_select_lds_kernel(const float* __restrict__ simT, int* __restrict__ idx, float* __restrict__ wgt, int N, int HW, int K) {
+    extern __shared__ unsigned keys[];                              // [N]
+    __shared__ int wcnt[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, q = blockIdx.x, b = blockIdx.y;
+    const float* row = simT + ((int64_t)b * HW + q) * N;
+    for (int n = tid; n < N; n += 256) keys[n] = f2key(row[n]);
+    __syncthreads();
+    const int Keff = K < N ? K : N;
+    unsigned thr = 0u;
+    if (N > K) {
+        for (int bit = 31; bit >= 0; --bit) {
+            const unsigned cand = thr | (1u << bit);
+            int cnt = 0;
+            for (int n = tid; n < N; n += 256) cnt += keys[n] >= cand ? 1 : 0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+            if (lane == 0) wcnt[wave] = cnt;
+            __syncthreads();
+            const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+            __syncthreads();
+            if (tot >= K) thr = cand;
+        }
+    }
+    if (wave != 0) return;
+    auto unkey = [](unsigned kb) { return __uint_as_float((kb & 0x80000000u) ? (kb ^ 0x80000000u) : ~kb); };
+    auto expv = [](float v) { return v == -INFINITY ? 0.f : expf(v); };
+    int ngt = 0;
+    float part = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        const unsigned kb = keys[n];
+        if (kb > thr) { ++ngt; part += expv(unkey(kb)); }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { ngt += __shfl_xor(ngt, o); part += __shfl_xor(part, o); }
+    const int need_eq = Keff - ngt;
+    const float e_thr = need_eq > 0 ? expv(unkey(thr)) : 0.f;
+    part += (float)need_eq * e_thr;
+    const float inv = part > 0.f ? 1.f / part : 0.f;
+    const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    int base_g = 0, base_e = 0;
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        const int n = n0 + lane;
+        const unsigned kb = n < N ? keys[n] : 0u;
+        const bool g = n < N && kb > thr, e = n < N && kb == thr;
+        const unsigned long long mg = __ballot(g), me = __ballot(e);
+        int sl = -1;
+        if (g) sl = base_g + __popcll(mg & lt);
+        else if (e) {
+            const int r = base_e + __popcll(me & lt);
+            if (r < need_eq) sl = ngt + r;
+        }
+        base_g += __popcll(mg);
+        base_e += __popcll(me);
+        if (sl >= 0) {
+            const int64_t o = ((int64_t)b * K + sl) * HW + q;
+            idx[o] = n;
+            wgt[o] = (g ? expv(unkey(kb)) : e_thr) * inv;
+        }
+    }
+    for (int j = Keff + lane; j < K; j += 64) {
         const int64_t o = ((int64_t)b * K + j) * HW + q;
         idx[o] = 0;
         wgt[o] = 0.f;
@@ -624,14 +693,23 @@ int launch_mem_similarity_t(const float* mk, const float* ms, const float* qk, c
     return (int)hipGetLastError();
 }
 
-// the wave-per-query selection holds the row in registers: up to 64 x 128 = 8 192 memory elements (beyond: the two-level kernels)
-bool mem_topk_select_supported(int N) { return N <= 64 * 128; }
+// the wave-per-query selection holds the row in registers up to 64 x 128 = 8 192 memory elements, in LDS up to 16 384 (beyond: the two-level kernels)
+bool mem_topk_select_supported(int N) { return N <= 16384; }
 
 int launch_mem_topk_select_readout(const float* simT, const float* mv, int* idx, float* wgt, float* out, int B, int CV, int N, int HW, int K, hipStream_t s) {
     if (K < 1 || K > TOPK_MAX || !mem_topk_select_supported(N)) return (int)hipErrorInvalidValue;
     dim3 grid(cdiv(HW, 4), B);
     const int nv = cdiv(N, 64);
-    if (nv <= 32) hipLaunchKernelGGL(mem_topk_select_kernel<32>, grid, dim3(256), 0, s, simT, idx, wgt, N, HW, K);
+    if (nv > 128) {
+        static std::atomic<uint64_t> optin{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!(optin.load() & (1ull << (dev & 63)))) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mem_topk_select_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+            optin.fetch_or(1ull << (dev & 63));
+        }
+        hipLaunchKernelGGL(mem_topk_select_lds_kernel, dim3(HW, B), dim3(256), (size_t)N * 4, s, simT, idx, wgt, N, HW, K);
+    } else if (nv <= 32) hipLaunchKernelGGL(mem_topk_select_kernel<32>, grid, dim3(256), 0, s, simT, idx, wgt, N, HW, K);
     else if (nv <= 64) hipLaunchKernelGGL(mem_topk_select_kernel<64>, grid, dim3(256), 0, s, simT, idx, wgt, N, HW, K);
     else if (nv <= 96) hipLaunchKernelGGL(mem_topk_select_kernel<96>, grid, dim3(256), 0, s, simT, idx, wgt, N, HW, K);
     else hipLaunchKernelGGL(mem_topk_select_kernel<128>, grid, dim3(256), 0, s, simT, idx, wgt, N, HW, K);

@@ -1977,7 +1977,7 @@ int havc_memory_read_topk_usage(havc_ctx* c, const float* mk, const float* ms, c
     const size_t lst = (size_t)B * top_k * HW, cand = lst * (mem_topk_splits(N) > 1 ? mem_topk_splits(N) : 0);
     if ((rc = ensure_scratch(c, 8, (size_t)B * N * HW * 4)) || (rc = ensure_scratch(c, 9, (lst + cand) * 4)) ||
         (rc = ensure_scratch(c, 10, (lst + cand) * 4))) return rc;
-    // wave-per-query selection on a query-major similarity (HAVC_TOPK_WAVE=0: the two-level kernels; also beyond 8 192 memory elements)
+    // wave-per-query selection on a query-major similarity (HAVC_TOPK_WAVE=0: the two-level kernels; also beyond 16 384 memory elements)
     static const bool wave_topk = [] { const char* e = getenv("HAVC_TOPK_WAVE"); return !e || atoi(e) != 0; }();
     int e;
     if (wave_topk && mem_topk_select_supported(N)) {
