@@ -149,6 +149,18 @@ enum havc_op_type {
                                      of the tile autotuner: every tile configuration produces the same bytes for a given count.  Plain convs
                                      only (no PS_BLUR / FUSE_* / W_FROM_BUF / extra-column tile)                                      */
 #define HAVC_F_SPLITK_COUNT(flags) (((flags) >> 16) & 15)
+#define HAVC_F_PRECISE 0x4000     /* fp32-class arithmetic on the fp16 MFMA path ("precise" mode; the reference computes in fp32 end to end,
+                                     deoldify/filters.py:45-68, fastai/basic_train.py:352-363).  Every activation of a precise plan is a
+                                     PAIR of fp16 tensors, hi = fp16(v) and lo = fp16((v - hi) * 2^11), in one buffer whose pixel row is
+                                     [hi: P channels | lo: P channels] (cpitch = 2 P; a view's lo plane is cpitch / 2 elements behind its
+                                     hi plane).  Conv weights are packed as three K segments [2^11 w_hi | 2^11 w_lo | w_hi] (Kc = 3 x the
+                                     plain count) and the K table walks x_hi, x_hi, x_lo: the unchanged MFMA main loop accumulates
+                                     2^11 (x_hi w_hi + x_hi w_lo + x_lo w_hi) in fp32 -- only the x_lo w_lo term (2^-22 relative) is
+                                     dropped -- and the epilogue multiplies by f3 (2^-11 x the plan's per-conv weight pre-scale), does
+                                     bias / ReLU / affine / residual in fp32 and stores a hi / lo pair.  Valid on CONV (no PS_BLUR, FUSE_*,
+                                     OUT_TRANSPOSED, W_FROM_BUF, SPLITK, GELU), MAXPOOL, BLUR_RESIZE, AFFINE, PREP_RGB8 and ATTENTION
+                                     (fp32 VALU kernels; aux1 = NHWC value buffer, Kc = its pixel pitch).  3x the MFMA work, 2x the
+                                     activation bytes.                                                                          */
 #define HAVC_F_FUSE_RGB8 0x100    /* the conv output is NOT stored: a following 1x1 conv to 3 channels (fp32 weights at
                                      scale_off [3][Npad], bias at shift_off [3]) + OUT_RGB8 maths run in the epilogue and
                                      write u8 RGB to buffer aux0 (layers.10.1 + layers.11 + layers.12 of the generator);

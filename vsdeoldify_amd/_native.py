@@ -25,6 +25,7 @@ F_RELU_PRE, F_AFFINE, F_RESIDUAL, F_RELU_POST = 0x1, 0x2, 0x4, 0x8
 F_OUT_PIXSHUF, F_OUT_TRANSPOSED, F_OUT_RGB8, F_LEAKY, F_FUSE_RGB8, F_PS_BLUR = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200
 F_GELU, F_W_FROM_BUF = 0x400, 0x800
 F_FUSE_PROJ = 0x2000
+F_PRECISE = 0x4000      # hi / lo fp16 pairs, fp32-class arithmetic (include/havc_mi355.h HAVC_F_PRECISE)
 
 
 def F_SPLITK(n):

@@ -29,9 +29,90 @@ __device__ __forceinline__ int64_t out_pixel(const ConvArgs& p, int m, int HoWo)
     return ((int64_t)(b * p.Ho * p.oss + ho * p.oss + p.ooy)) * (p.Wo * p.oss) + wo * p.oss + p.oox;
 }
 
+// ---- precise mode (HAVC_F_PRECISE): an fp32-class value travels as TWO fp16 numbers, hi = fp16(v) and lo = fp16((v - hi) * 2^11) ----
+// (v - hi) is exact in fp32 and so is the power-of-two scale: hi + lo * 2^-11 keeps 22 significand bits.  The lo plane of a tensor sits
+// half a pixel pitch behind the hi plane (a precise buffer's pixel row is [hi: P channels | lo: P channels], cpitch = 2 P).
+__device__ __forceinline__ void split_hl(float v, half_t& hi, half_t& lo) {
+    hi = (half_t)v;
+    lo = (half_t)((v - (float)hi) * 2048.f);
+}
+__device__ __forceinline__ float join_hl(half_t hi, half_t lo) { return (float)hi + (float)lo * (1.f / 2048.f); }
+
+// Precise epilogue of one accumulator fragment.  The accumulator holds 2^11 / wscale x the convolution (conv kernels: the three K
+// segments x_hi * (2^11 w_hi), x_hi * (2^11 w_lo), (2^11 x_lo) * w_hi summed by the unchanged MFMA main loop; plan.py pack_conv):
+// p.pscale brings it back, everything after that is fp32 like the reference (deoldify/filters.py:45-68), no fp16 rounding points;
+// the result is stored as a hi / lo pair.
+__device__ __forceinline__ void epilogue_frag_precise(const ConvArgs& p, const float4v acc, int m, int n, int HoWo) {
+    const bool leaky = p.flags & HAVC_F_LEAKY;
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = acc[r] * p.pscale;
+    if (p.bias) {
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    }
+    if (p.flags & HAVC_F_OUT_RGB8) {
+        if (n == 0) {
+            uint8_t* y = reinterpret_cast<uint8_t*>(p.y) + (int64_t)m * 3;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                float s = 1.f / (1.f + expf(-v[r]));
+                s = s * (p.f1 - p.f0) + p.f0;
+                s = s * p.istd[r] + p.mean[r];
+                s = fminf(fmaxf(s, 0.f), 1.f);
+                y[r] = (uint8_t)(int)(s * 255.f);
+            }
+        }
+        return;
+    }
+    if (p.flags & HAVC_F_RELU_PRE) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : (leaky ? v[r] * p.f2 : 0.f);
+    }
+    if (p.flags & HAVC_F_AFFINE) {
+        const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
+        const float4 sh = *reinterpret_cast<const float4*>(p.shift + n);
+        v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
+        v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
+    }
+    half_t* y = reinterpret_cast<half_t*>(p.y);
+    const int ylo = p.y_cpitch >> 1;
+    half4 oh, ol;
+    if (p.flags & HAVC_F_OUT_PIXSHUF) {
+        const int q = n / p.Co, c = n - q * p.Co;
+        if (q >= 4) return;
+        const int b = m / HoWo, rem = m - b * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        const int64_t pix = (int64_t)(b * 2 * p.Ho + 2 * ho + (q >> 1)) * (2 * p.Wo) + 2 * wo + (q & 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { half_t a, b; split_hl(v[r], a, b); oh[r] = a; ol[r] = b; }
+        half_t* d = y + pix * p.y_cpitch + p.y_coff + c;
+        *reinterpret_cast<half4*>(d) = oh;
+        *reinterpret_cast<half4*>(d + ylo) = ol;
+        return;
+    }
+    if (n >= p.Co) return;
+    const int64_t mo = out_pixel(p, m, HoWo);
+    if (p.flags & HAVC_F_RESIDUAL) {
+        const half_t* rp = p.res + mo * p.res_cpitch + p.res_coff + n;
+        const half4 rh = *reinterpret_cast<const half4*>(rp), rl = *reinterpret_cast<const half4*>(rp + (p.res_cpitch >> 1));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += join_hl(rh[r], rl[r]);
+    }
+    if (p.flags & HAVC_F_RELU_POST) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : (leaky ? v[r] * p.f2 : 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { half_t a, b; split_hl(v[r], a, b); oh[r] = a; ol[r] = b; }
+    half_t* d = y + mo * p.y_cpitch + p.y_coff + n;
+    *reinterpret_cast<half4*>(d) = oh;
+    *reinterpret_cast<half4*>(d + ylo) = ol;
+}
+
 // one 16x16 accumulator fragment -> fused epilogue -> store.  lane owns pixel m, channels n..n+3.
 __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v acc, int m, int n, int HoWo) {
     if (m >= p.M || n >= p.Npad) return;
+    if (p.flags & HAVC_F_PRECISE) { epilogue_frag_precise(p, acc, m, n, HoWo); return; }
     const bool leaky = p.flags & HAVC_F_LEAKY;
     float v[4];
 #pragma unroll

@@ -340,6 +340,13 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             { static const int prio = [] { const char* e = getenv("HAVC_SETPRIO"); return e ? atoi(e) != 0 : 1; }(); a.prio = prio; }
             a.splitk = HAVC_F_SPLITK_COUNT(op.flags);
             if (a.splitk == 1) a.splitk = 0;
+            a.pscale = 1.f;
+            if (op.flags & HAVC_F_PRECISE) {
+                if ((op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_FUSE_PROJ | HAVC_F_OUT_TRANSPOSED | HAVC_F_W_FROM_BUF | HAVC_F_GELU)) || a.splitk ||
+                    !(op.f3 > 0.f) || (op.src_cpitch & 15) || (!(op.flags & HAVC_F_OUT_RGB8) && (op.dst_cpitch & 15)))
+                    return fail(c, HAVC_E_INVALID, "conv op: PRECISE needs a plain conv (no fused / transposed / split-K form), f3 = accumulator scale > 0, hi|lo pixel rows");
+                a.pscale = op.f3;
+            }
             if (a.splitk) {
                 if ((op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_FUSE_PROJ | HAVC_F_W_FROM_BUF | HAVC_F_OUT_RGB8)) || (op.Kc >> 3) < 2 * a.splitk)
                     return fail(c, HAVC_E_INVALID, "conv op: SPLITK needs a plain conv with at least 2 K stages per part");
@@ -424,14 +431,30 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             break;
         }
         case HAVC_OP_MAXPOOL:
+            if (op.flags & HAVC_F_PRECISE) {
+                e = launch_maxpool3x3s2_p((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), batch, op.Hi, op.Wi, op.Ho, op.Wo, op.Ci, op.src_cpitch,
+                                          op.src_coff, op.dst_cpitch, op.dst_coff, s);
+                break;
+            }
             e = launch_maxpool3x3s2((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), batch, op.Hi, op.Wi, op.Ho,
                                     op.Wo, op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff, s);
             break;
         case HAVC_OP_BLUR_RESIZE:
+            if (op.flags & HAVC_F_PRECISE) {
+                e = launch_blur_resize_p((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), batch, op.Hi, op.Wi, op.Ho, op.Wo, op.Ci, op.src_cpitch,
+                                         op.src_coff, op.dst_cpitch, op.dst_coff, s);
+                break;
+            }
             e = launch_blur_resize((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), batch, op.Hi, op.Wi, op.Ho,
                                    op.Wo, op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff, s);
             break;
         case HAVC_OP_AFFINE:
+            if (op.flags & HAVC_F_PRECISE) {
+                e = launch_affine_p((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), wptr<float>(n, op.scale_off), wptr<float>(n, op.shift_off),
+                                    (op.flags & HAVC_F_RELU_POST) ? 1 : 0, (int64_t)batch * op.Hi * op.Wi, op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch,
+                                    op.dst_coff, s);
+                break;
+            }
             e = launch_affine((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), wptr<float>(n, op.scale_off),
                               wptr<float>(n, op.shift_off), (op.flags & HAVC_F_RELU_POST) ? 1 : 0,
                               (int64_t)batch * op.Hi * op.Wi, op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch,
@@ -442,12 +465,30 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                                op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff, s);
             break;
         case HAVC_OP_ATTENTION:
+            if (op.flags & HAVC_F_PRECISE) {
+                // aux1 = NHWC value buffer (pixel pitch Kc), kh = fp32 scratch buffer [N][2] per frame (row maximum and sum of the softmax)
+                if (op.kh < 0 || op.kh >= (int)n->bufs.size() || n->bufdesc[op.kh].elem_bytes != 4 ||
+                    (uint64_t)n->bufdesc[op.kh].elems_per_frame < (uint64_t)op.Hi * op.Wi * 2 || !attention_p_supported(op.aux0, op.Ci))
+                    return fail(c, HAVC_E_INVALID, "attention op: PRECISE needs an fp32 [N][2] scratch buffer in kh, d <= 128, C % 128 == 0");
+                e = launch_attention_p((const half_t*)bufptr(n, op.src2), op.res_cpitch, op.res_coff, op.res_coff + op.aux0, op.aux0,
+                                       n->bufdesc[op.src2].elems_per_frame, (const half_t*)bufptr(n, op.aux1), op.Kc, 0, n->bufdesc[op.aux1].elems_per_frame,
+                                       (const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, n->bufdesc[op.src].elems_per_frame,
+                                       (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff, n->bufdesc[op.dst].elems_per_frame, (float*)bufptr(n, op.kh),
+                                       batch, op.Hi * op.Wi, op.Ci, op.f0, s);
+                c->stats.launches += 1;
+                break;
+            }
             e = launch_attention((const half_t*)bufptr(n, op.src2), op.res_cpitch, op.res_coff, op.res_coff + op.aux0,
                                  op.aux0, (const half_t*)bufptr(n, op.aux1), op.Ci, op.Kc, (const half_t*)bufptr(n, op.src),
                                  op.src_cpitch, op.src_coff, (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff, batch,
                                  op.Hi * op.Wi, op.f0, s);
             break;
         case HAVC_OP_PREP_RGB8:
+            if (op.flags & HAVC_F_PRECISE) {
+                e = launch_prep_rgb8_p((const uint8_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
+                                       op.src2 >= 0 ? (half_t*)bufptr(n, op.src2) : nullptr, op.res_cpitch, op.res_coff, (int64_t)batch * op.Hi * op.Wi, s);
+                break;
+            }
             e = launch_prep_rgb8((const uint8_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
                                  op.src2 >= 0 ? (half_t*)bufptr(n, op.src2) : nullptr, op.res_cpitch, op.res_coff,
                                  (int64_t)batch * op.Hi * op.Wi, s);
@@ -939,6 +980,17 @@ int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops,
             };
             emit_seg(0, C8a);
             emit_seg(C8a, C8);
+            if (o.flags & HAVC_F_PRECISE) {
+                // precise conv: the K walk above three times -- x_hi (x 2^11 w_hi), x_hi (x 2^11 w_lo), x_lo (x w_hi; the lo plane of a pixel
+                // sits src_cpitch / 2 elements = src_cpitch BYTES behind its hi plane) -- matching plan.py pack_conv(precise=True)
+                const size_t len = host.size() - start;
+                for (int rep = 1; rep < 3; ++rep)
+                    for (size_t k = 0; k < len; ++k) {
+                        int2 e = host[start + k];
+                        if (rep == 2 && (short)(e.y & 0xffff) != HAVC_KTAB_PAD_DH) e.x += o.src_cpitch;
+                        host.push_back(e);
+                    }
+            }
             if ((int)(host.size() - start) != o.Kc) {
                 delete n;
                 return fail(c, HAVC_E_INVALID, "net_create: conv op Kc does not match its K layout (Ci, kh, kw, aux1)");

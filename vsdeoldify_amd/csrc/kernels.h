@@ -42,6 +42,7 @@ struct ConvArgs {
     int prio;              // 1: static s_setprio 1 for the younger half of an 8-wave block (HAVC_SETPRIO, default on)
     int splitk;            // > 1: the K range is cut into `splitk` parts, one block per (tile, part) stores its fp32 partial sums to `ws`
     float* ws;             //      [splitk][M][Npad]; splitk_reduce_kernel adds them in a fixed order and runs the usual epilogue
+    float pscale;          // HAVC_F_PRECISE: the accumulator is this factor away from the convolution (2^-11 x the weight pre-scale, op.f3)
 };
 #define HAVC_KTAB_PAD_DH 0x7fff
 
@@ -159,6 +160,19 @@ int launch_local_softmax(float* qk, const float* q, const float* rel_w, const fl
 int launch_local_agg(const float* attn, const float* v, float* agg, int n, int CV, int H, int W, int R, int dil, hipStream_t s);
 
 int launch_range_stats(const void* p, int elem_bytes, int64_t n, unsigned* stats, hipStream_t s);
+
+// ---- precise mode (precise.hip): the non-conv ops of the DeOldify generators on hi / lo fp16 pairs, fp32 arithmetic ----
+int launch_prep_rgb8_p(const uint8_t* rgb, half_t* y0, int y0_cpitch, int y0_coff, half_t* y1, int y1_cpitch, int y1_coff, int64_t npix, hipStream_t s);
+int launch_maxpool3x3s2_p(const half_t* x, half_t* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int x_cpitch, int x_coff, int y_cpitch, int y_coff,
+                          hipStream_t s);
+int launch_blur_resize_p(const half_t* x, half_t* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int x_cpitch, int x_coff, int y_cpitch, int y_coff,
+                         hipStream_t s);
+int launch_affine_p(const half_t* x, half_t* y, const float* scale, const float* shift, int relu, int64_t npix, int C, int x_cpitch, int x_coff, int y_cpitch,
+                    int y_coff, hipStream_t s);
+bool attention_p_supported(int d, int C);
+int launch_attention_p(const half_t* qk, int qk_cpitch, int f_coff, int g_coff, int d, int64_t qk_fs, const half_t* h, int h_cpitch, int h_coff, int64_t h_fs,
+                       const half_t* x, int x_cpitch, int x_coff, int64_t x_fs, half_t* out, int o_cpitch, int o_coff, int64_t o_fs, float* stats, int B, int N,
+                       int C, float gamma, hipStream_t s);
 
 // ---- ColorMNet network kernels (colormnet_net.hip) ----
 #ifndef HAVC_EW_SRC_BCAST          // (public values: include/havc_mi355.h)

@@ -1,0 +1,344 @@
+// "Precise" mode (HAVC_F_PRECISE, include/havc_mi355.h): the non-conv ops of the DeOldify generators on hi / lo fp16 pairs.
+//
+// The reference computes in fp32 end to end (deoldify/filters.py:45-68, fastai/basic_train.py:352-363).  The fast path of this library
+// rounds every activation to fp16; this path keeps 22 significand bits per value as two fp16 numbers (hi = fp16(v),
+// lo = fp16((v - hi) * 2^11)) so that the convolutions still run on the fp16 MFMA main loop (three K segments, conv_common.h) while
+// everything else -- the kernels below -- reads a pair as ONE fp32 value, computes in fp32 like torch and stores a pair again.
+// Layout: a precise buffer's pixel row is [hi: P channels | lo: P channels]; a view's lo plane is cpitch / 2 elements behind its hi plane.
+// All kernels are HBM-bound except the attention, which is fp32 VALU (the N x N map of fastai's SelfAttention never leaves the CU).
+#include "conv_common.h"
+
+namespace {
+
+inline int grid_for(int64_t work) {
+    int64_t b = (work + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+__device__ __forceinline__ void load8(const half_t* p, int lo, float v[8]) {
+    const half8 h = *reinterpret_cast<const half8*>(p), l = *reinterpret_cast<const half8*>(p + lo);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = join_hl(h[e], l[e]);
+}
+__device__ __forceinline__ void store8(half_t* p, int lo, const float v[8]) {
+    half8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { half_t a, b; split_hl(v[e], a, b); h[e] = a; l[e] = b; }
+    *reinterpret_cast<half8*>(p) = h;
+    *reinterpret_cast<half8*>(p + lo) = l;
+}
+
+// ---- model input (prep_rgb8_kernel of elementwise.hip in fp32): u8 RGB -> PIL 'L' -> / 255 -> imagenet normalise ----
+__global__ void prep_rgb8_p_kernel(const uint8_t* __restrict__ rgb, half_t* __restrict__ y0, int y0_cp, int y0_co, half_t* __restrict__ y1, int y1_cp,
+                                   int y1_co, int64_t npix) {
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned r = rgb[i * 3], g = rgb[i * 3 + 1], b = rgb[i * 3 + 2];
+        const unsigned L = (19595u * r + 38470u * g + 7471u * b + 0x8000u) >> 16;
+        const float f = (float)L / 255.f;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = (f - mean[c]) / stdv[c];
+        store8(y0 + i * y0_cp + y0_co, y0_cp >> 1, v);
+        if (y1) store8(y1 + i * y1_cp + y1_co, y1_cp >> 1, v);
+    }
+}
+
+// ---- MaxPool2d(3, stride 2, pad 1) ----
+__global__ void maxpool_p_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int B, int Hi, int Wi, int Ho, int Wo, int C8, int x_cp, int x_co,
+                                 int y_cp, int y_co) {
+    const int64_t total = (int64_t)B * Ho * Wo * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        int64_t pix = i / C8;
+        const int wo = (int)(pix % Wo);
+        pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = -3.0e38f;
+        for (int dy = 0; dy < 3; ++dy) {
+            const int hi = ho * 2 - 1 + dy;
+            if ((unsigned)hi >= (unsigned)Hi) continue;
+            for (int dx = 0; dx < 3; ++dx) {
+                const int wi = wo * 2 - 1 + dx;
+                if ((unsigned)wi >= (unsigned)Wi) continue;
+                float v[8];
+                load8(x + ((int64_t)(b * Hi + hi) * Wi + wi) * x_cp + x_co + c8 * 8, x_cp >> 1, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        }
+        store8(y + ((int64_t)(b * Ho + ho) * Wo + wo) * y_cp + y_co + c8 * 8, y_cp >> 1, m);
+    }
+}
+
+// ---- ReplicationPad2d((1,0,1,0)) + AvgPool2d(2, stride 1) [+ nearest resize]: blur_resize_kernel of elementwise.hip in fp32 ----
+// torch's avg_pool2d sums the window row by row and divides by the window size: ((v00 + v01) + v10) + v11, then / 4.
+__global__ void blur_resize_p_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, int B, int Hi, int Wi, int Ho, int Wo, int C8, int x_cp, int x_co,
+                                     int y_cp, int y_co, float sh, float sw) {
+    const int64_t total = (int64_t)B * Ho * Wo * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        int64_t pix = i / C8;
+        const int wo = (int)(pix % Wo);
+        pix /= Wo;
+        const int ho = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        int sy = ho, sx = wo;
+        if (Ho != Hi) sy = min((int)floorf(ho * sh), Hi - 1);
+        if (Wo != Wi) sx = min((int)floorf(wo * sw), Wi - 1);
+        const int y0 = max(sy - 1, 0), x0 = max(sx - 1, 0);
+        const half_t* base = x + (int64_t)b * Hi * Wi * x_cp + x_co + c8 * 8;
+        const int lo = x_cp >> 1;
+        float v00[8], v01[8], v10[8], v11[8], o[8];
+        load8(base + ((int64_t)y0 * Wi + x0) * x_cp, lo, v00);
+        load8(base + ((int64_t)y0 * Wi + sx) * x_cp, lo, v01);
+        load8(base + ((int64_t)sy * Wi + x0) * x_cp, lo, v10);
+        load8(base + ((int64_t)sy * Wi + sx) * x_cp, lo, v11);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (v00[e] + v01[e] + v10[e] + v11[e]) * 0.25f;
+        store8(y + ((int64_t)(b * Ho + ho) * Wo + wo) * y_cp + y_co + c8 * 8, y_cp >> 1, o);
+    }
+}
+
+// ---- y = [relu](x * scale + shift) ----
+__global__ void affine_p_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, int relu,
+                                int64_t npix, int C8, int x_cp, int x_co, int y_cp, int y_co) {
+    const int64_t total = npix * C8;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);
+        const int64_t pix = i / C8;
+        float v[8];
+        load8(x + pix * x_cp + x_co + c8 * 8, x_cp >> 1, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (scale) v[e] = v[e] * scale[c8 * 8 + e] + shift[c8 * 8 + e];
+            if (relu) v[e] = fmaxf(v[e], 0.f);
+        }
+        store8(y + pix * y_cp + y_co + c8 * 8, y_cp >> 1, v);
+    }
+}
+
+// ---- fastai SelfAttention in fp32 (fastai/layers.py:81-96): beta = softmax_i(f_i . g_j), o_j = gamma * sum_i beta_ij h_i + x_j ----
+// Two passes over the keys, both with the N x N map kept on the CU:
+//   pattn_stats_kernel: per query j the row maximum m_j and l_j = sum_i exp(s_ij - m_j)  (torch's softmax: exp(x - max) / sum)
+//   pattn_apply_kernel: s_ij again, p = exp(s_ij - m_j) / l_j, o_j += p h_i for a chunk of CC channels, epilogue gamma o + x.
+// Block = 64 queries x 256 threads; key tiles of 32.  S role: thread (query t & 63, key group t >> 6) = 8 keys; PV role: thread
+// (channel lane t & 31, query group t >> 5) = 8 queries x NV float4 of channels (cg * 4 + k * 128: consecutive lanes read consecutive
+// 16-byte LDS slots, the p values are wave-uniform broadcasts).  Sums run in a fixed order (d, then keys ascending): deterministic.
+struct PAttnArgs {
+    const half_t* qk; const half_t* h; const half_t* x; half_t* out; float* stats;
+    int qk_cp, f_co, g_co, d, h_cp, h_co, x_cp, x_co, o_cp, o_co, B, N, C;
+    int64_t qk_fs, h_fs, x_fs, o_fs;     // frame strides (elements)
+    float gamma;
+};
+constexpr int PA_TJ = 64, PA_TI = 32;
+
+__device__ __forceinline__ void pa_load_rows(const half_t* base, int cp, int co, int row0, int rows, int N, int nch8, float* dst, int dpitch, int t) {
+    // rows x nch8 chunks of 8 channels (hi + lo) -> fp32 LDS rows of pitch dpitch; rows beyond N are zeros
+    for (int q = t; q < rows * nch8; q += 256) {
+        const int r = q / nch8, ch = q - r * nch8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+        if (row0 + r < N) load8(base + (int64_t)(row0 + r) * cp + co + ch * 8, cp >> 1, v);
+        float4* o = reinterpret_cast<float4*>(dst + r * dpitch + ch * 8);
+        o[0] = make_float4(v[0], v[1], v[2], v[3]);
+        o[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+
+__device__ __forceinline__ void pa_scores(const float* Gs, const float* Fs, int DP, int d, int sj, int ig, float s[8]) {
+#pragma unroll
+    for (int ii = 0; ii < 8; ++ii) s[ii] = 0.f;
+    for (int dd = 0; dd < d; dd += 4) {
+        const float4 g = *reinterpret_cast<const float4*>(Gs + sj * DP + dd);
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            const float4 f = *reinterpret_cast<const float4*>(Fs + (ig * 8 + ii) * DP + dd);
+            s[ii] += f.x * g.x; s[ii] += f.y * g.y; s[ii] += f.z * g.z; s[ii] += f.w * g.w;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) pattn_stats_kernel(const PAttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int DP = a.d + 4;
+    float* Gs = sm;
+    float* Fs = Gs + PA_TJ * DP;
+    float* red = Fs + PA_TI * DP;                 // [4][64][2]
+    const int j0 = blockIdx.x * PA_TJ, b = blockIdx.y, t = threadIdx.x, sj = t & 63, ig = t >> 6;
+    const half_t* qk = a.qk + (int64_t)b * a.qk_fs;
+    pa_load_rows(qk, a.qk_cp, a.g_co, j0, PA_TJ, a.N, a.d / 8, Gs, DP, t);
+    float m = -3.0e38f, l = 0.f;
+    for (int i0 = 0; i0 < a.N; i0 += PA_TI) {
+        __syncthreads();
+        pa_load_rows(qk, a.qk_cp, a.f_co, i0, PA_TI, a.N, a.d / 8, Fs, DP, t);
+        __syncthreads();
+        float s[8];
+        pa_scores(Gs, Fs, DP, a.d, sj, ig, s);
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) {
+            if (i0 + ig * 8 + ii >= a.N) continue;
+            if (s[ii] > m) { l = l * expf(m - s[ii]) + 1.f; m = s[ii]; }
+            else l += expf(s[ii] - m);
+        }
+    }
+    red[(ig * 64 + sj) * 2] = m;
+    red[(ig * 64 + sj) * 2 + 1] = l;
+    __syncthreads();
+    if (t < 64 && j0 + t < a.N) {
+        float M = red[t * 2];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) M = fmaxf(M, red[(k * 64 + t) * 2]);
+        float L = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) L += red[(k * 64 + t) * 2 + 1] * expf(red[(k * 64 + t) * 2] - M);
+        float* st = a.stats + ((int64_t)b * a.N + j0 + t) * 2;
+        st[0] = M;
+        st[1] = L;
+    }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) pattn_apply_kernel(const PAttnArgs a) {
+    constexpr int CC = NV * 128;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int DP = a.d + 4;
+    float* Gs = sm;
+    float* Fs = Gs + PA_TJ * DP;
+    float* Ps = Fs + PA_TI * DP;                  // [TI][TJ]
+    float* Hs = Ps + PA_TI * PA_TJ;               // [TI][CC]
+    const int j0 = blockIdx.x * PA_TJ, b = blockIdx.y, c0 = blockIdx.z * CC, t = threadIdx.x;
+    const int sj = t & 63, ig = t >> 6, cg = t & 31, jg = t >> 5;
+    const half_t* qk = a.qk + (int64_t)b * a.qk_fs;
+    const half_t* hb = a.h + (int64_t)b * a.h_fs;
+    pa_load_rows(qk, a.qk_cp, a.g_co, j0, PA_TJ, a.N, a.d / 8, Gs, DP, t);
+    float m = 0.f, l = 1.f;
+    if (j0 + sj < a.N) {
+        const float* st = a.stats + ((int64_t)b * a.N + j0 + sj) * 2;
+        m = st[0];
+        l = st[1];
+    }
+    float4 acc[8][NV];
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) acc[jj][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i0 = 0; i0 < a.N; i0 += PA_TI) {
+        __syncthreads();
+        pa_load_rows(qk, a.qk_cp, a.f_co, i0, PA_TI, a.N, a.d / 8, Fs, DP, t);
+        pa_load_rows(hb, a.h_cp, a.h_co + c0, i0, PA_TI, a.N, CC / 8, Hs, CC, t);
+        __syncthreads();
+        float s[8];
+        pa_scores(Gs, Fs, DP, a.d, sj, ig, s);
+#pragma unroll
+        for (int ii = 0; ii < 8; ++ii) Ps[(ig * 8 + ii) * PA_TJ + sj] = (i0 + ig * 8 + ii < a.N) ? expf(s[ii] - m) / l : 0.f;
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < PA_TI; ++i) {
+            const float4 p0 = *reinterpret_cast<const float4*>(Ps + i * PA_TJ + jg * 8), p1 = *reinterpret_cast<const float4*>(Ps + i * PA_TJ + jg * 8 + 4);
+            const float pj[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const float4 hv = *reinterpret_cast<const float4*>(Hs + i * CC + k * 128 + cg * 4);
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    acc[jj][k].x += pj[jj] * hv.x; acc[jj][k].y += pj[jj] * hv.y;
+                    acc[jj][k].z += pj[jj] * hv.z; acc[jj][k].w += pj[jj] * hv.w;
+                }
+            }
+        }
+    }
+    // epilogue: out = gamma * o + x, as a hi / lo pair (4 consecutive channels per store)
+    const half_t* xb = a.x + (int64_t)b * a.x_fs;
+    half_t* ob = a.out + (int64_t)b * a.o_fs;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+        const int j = j0 + jg * 8 + jj;
+        if (j >= a.N) continue;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = c0 + k * 128 + cg * 4;
+            const half_t* xp = xb + (int64_t)j * a.x_cp + a.x_co + c;
+            const half4 xh = *reinterpret_cast<const half4*>(xp), xl = *reinterpret_cast<const half4*>(xp + (a.x_cp >> 1));
+            const float o4[4] = {acc[jj][k].x, acc[jj][k].y, acc[jj][k].z, acc[jj][k].w};
+            half4 oh, ol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = a.gamma * o4[r] + join_hl(xh[r], xl[r]);
+                half_t hh, ll;
+                split_hl(v, hh, ll);
+                oh[r] = hh; ol[r] = ll;
+            }
+            half_t* op = ob + (int64_t)j * a.o_cp + a.o_co + c;
+            *reinterpret_cast<half4*>(op) = oh;
+            *reinterpret_cast<half4*>(op + (a.o_cp >> 1)) = ol;
+        }
+    }
+}
+
+template <auto Kernel>
+void lds_optin(int bytes) {
+    // per device and harmless when repeated (conv_igemm_pipe.hip ensure_lds_optin keeps the same rule)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+}  // namespace
+
+int launch_prep_rgb8_p(const uint8_t* rgb, half_t* y0, int y0_cpitch, int y0_coff, half_t* y1, int y1_cpitch, int y1_coff, int64_t npix, hipStream_t s) {
+    hipLaunchKernelGGL(prep_rgb8_p_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, y0, y0_cpitch, y0_coff, y1, y1_cpitch, y1_coff, npix);
+    return (int)hipGetLastError();
+}
+
+int launch_maxpool3x3s2_p(const half_t* x, half_t* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int x_cpitch, int x_coff, int y_cpitch, int y_coff,
+                          hipStream_t s) {
+    const int C8 = C / 8;
+    hipLaunchKernelGGL(maxpool_p_kernel, dim3(grid_for((int64_t)B * Ho * Wo * C8)), dim3(256), 0, s, x, y, B, Hi, Wi, Ho, Wo, C8, x_cpitch, x_coff, y_cpitch, y_coff);
+    return (int)hipGetLastError();
+}
+
+int launch_blur_resize_p(const half_t* x, half_t* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int x_cpitch, int x_coff, int y_cpitch, int y_coff,
+                         hipStream_t s) {
+    const int C8 = C / 8;
+    hipLaunchKernelGGL(blur_resize_p_kernel, dim3(grid_for((int64_t)B * Ho * Wo * C8)), dim3(256), 0, s, x, y, B, Hi, Wi, Ho, Wo, C8, x_cpitch, x_coff, y_cpitch,
+                       y_coff, (float)Hi / (float)Ho, (float)Wi / (float)Wo);
+    return (int)hipGetLastError();
+}
+
+int launch_affine_p(const half_t* x, half_t* y, const float* scale, const float* shift, int relu, int64_t npix, int C, int x_cpitch, int x_coff, int y_cpitch,
+                    int y_coff, hipStream_t s) {
+    const int C8 = C / 8;
+    hipLaunchKernelGGL(affine_p_kernel, dim3(grid_for(npix * C8)), dim3(256), 0, s, x, y, scale, shift, relu, npix, C8, x_cpitch, x_coff, y_cpitch, y_coff);
+    return (int)hipGetLastError();
+}
+
+bool attention_p_supported(int d, int C) { return d >= 8 && d <= 128 && (d & 7) == 0 && C >= 128 && (C & 127) == 0; }
+
+// qk: view holding f at f_coff and g at g_coff (d channels each); h: value view (C channels); x / out: C channels; stats: fp32 [B][N][2] scratch
+int launch_attention_p(const half_t* qk, int qk_cpitch, int f_coff, int g_coff, int d, int64_t qk_fs, const half_t* h, int h_cpitch, int h_coff, int64_t h_fs,
+                       const half_t* x, int x_cpitch, int x_coff, int64_t x_fs, half_t* out, int o_cpitch, int o_coff, int64_t o_fs, float* stats, int B, int N,
+                       int C, float gamma, hipStream_t s) {
+    if (!attention_p_supported(d, C)) return (int)hipErrorInvalidValue;
+    PAttnArgs a{};
+    a.qk = qk; a.h = h; a.x = x; a.out = out; a.stats = stats;
+    a.qk_cp = qk_cpitch; a.f_co = f_coff; a.g_co = g_coff; a.d = d; a.h_cp = h_cpitch; a.h_co = h_coff; a.x_cp = x_cpitch; a.x_co = x_coff;
+    a.o_cp = o_cpitch; a.o_co = o_coff; a.B = B; a.N = N; a.C = C; a.qk_fs = qk_fs; a.h_fs = h_fs; a.x_fs = x_fs; a.o_fs = o_fs; a.gamma = gamma;
+    const int DP = d + 4, NJ = (N + PA_TJ - 1) / PA_TJ;
+    const int lds_a = (PA_TJ * DP + PA_TI * DP + 4 * 64 * 2) * 4;
+    lds_optin<pattn_stats_kernel>(lds_a);
+    hipLaunchKernelGGL(pattn_stats_kernel, dim3(NJ, B), dim3(256), lds_a, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    const int CC = (C % 512 == 0) ? 512 : ((C % 256 == 0) ? 256 : 128);
+    const int lds_b = (PA_TJ * DP + PA_TI * DP + PA_TI * PA_TJ + PA_TI * CC) * 4;
+    const dim3 grid(NJ, B, C / CC);
+    if (CC == 512) { lds_optin<pattn_apply_kernel<4>>(lds_b); hipLaunchKernelGGL(pattn_apply_kernel<4>, grid, dim3(256), lds_b, s, a); }
+    else if (CC == 256) { lds_optin<pattn_apply_kernel<2>>(lds_b); hipLaunchKernelGGL(pattn_apply_kernel<2>, grid, dim3(256), lds_b, s, a); }
+    else { lds_optin<pattn_apply_kernel<1>>(lds_b); hipLaunchKernelGGL(pattn_apply_kernel<1>, grid, dim3(256), lds_b, s, a); }
+    return (int)hipGetLastError();
+}

@@ -23,8 +23,14 @@ def conv_out(n, k, s, p, d=1):
 class DeoldifyGenerator:
     """Packs a reference state dict once; emits a plan per render size S = render_factor * 16."""
 
-    def __init__(self, state_dict, arch="wide", fuse_final=True, fuse_blur=True):
-        assert arch in RESNET
+    def __init__(self, state_dict, arch="wide", fuse_final=True, fuse_blur=True, precision="fast"):
+        """precision: "fast" = fp16 activations / fp16 MFMA operands / fp32 accumulate; "precise" = fp32-class arithmetic
+        like the reference's (deoldify/filters.py:45-68): hi / lo fp16 pairs, three-segment convs, fp32 attention (HAVC_F_PRECISE), the
+        op-by-op plan (no fused shuffle+blur / RGB8 epilogues)."""
+        assert arch in RESNET and precision in ("fast", "precise")
+        self.precise = precision == "precise"
+        if self.precise:
+            fuse_final = fuse_blur = False
         self.sd, self.arch, self.fuse_final, self.fuse_blur = to_np(state_dict), arch, fuse_final, fuse_blur
         self.pack, self._pc, self._vec = WeightPack(), {}, {}
         self._frozen = False
@@ -42,6 +48,7 @@ class DeoldifyGenerator:
         import json
         from dataclasses import asdict
         meta = {"format": self.FORMAT, "arch": self.arch, "fuse_final": self.fuse_final, "fuse_blur": self.fuse_blur,
+                "precision": "precise" if self.precise else "fast",
                 "convs": {k: asdict(v) for k, v in self._pc.items()}, "vecs": {k: list(v) for k, v in self._vec.items()},
                 "shapes": {k: list(v.shape) for k, v in self.sd.items()},
                 "scalars": {k: float(v.reshape(-1)[0]) for k, v in self.sd.items() if k.endswith(".gamma")}}
@@ -59,6 +66,7 @@ class DeoldifyGenerator:
             raise ValueError(f"{path}: not a {cls.FORMAT} file")
         g = cls.__new__(cls)
         g.arch, g.fuse_final, g.fuse_blur = meta["arch"], meta["fuse_final"], meta["fuse_blur"]
+        g.precise = meta.get("precision", "fast") == "precise"
         g.sd = {k: np.broadcast_to(np.float32(meta["scalars"].get(k, 0.0)), tuple(shp)) for k, shp in meta["shapes"].items()}
         g._pc = {k: PackedConv(**v) for k, v in meta["convs"].items()}
         g._vec = {k: tuple(v) for k, v in meta["vecs"].items()}
@@ -102,14 +110,14 @@ class DeoldifyGenerator:
         def make():
             W = self.sd[wkey + ".weight"].astype(np.float32)
             s, sh = bn_scale_shift(self.sd, bnkey)
-            return pack_conv(self.pack, W * s[:, None, None, None], x.cmap, x.span, bias=sh)
+            return pack_conv(self.pack, W * s[:, None, None, None], x.cmap, x.span, bias=sh, precise=self.precise)
         return self._conv(wkey, make)
 
     def _dec_conv(self, b, p, x, ks=3):
         """custom_conv_layer(norm=Spectral, extra_bn): conv -> ReLU -> BN  (deoldify/layers.py:28-45)."""
         def make():
             s, sh = bn_scale_shift(self.sd, p + ".2")
-            return pack_conv(self.pack, conv_weight(self.sd, p + ".0"), x.cmap, x.span, scale=s, shift=sh)
+            return pack_conv(self.pack, conv_weight(self.sd, p + ".0"), x.cmap, x.span, scale=s, shift=sh, precise=self.precise)
         pc = self._conv(p, make)
         y = b.tensor(x.H, x.W, pc.Cout)
         b.conv(p, pc, x, y, pad=ks // 2, flags=nat.F_RELU_PRE | nat.F_AFFINE)
@@ -121,12 +129,18 @@ class DeoldifyGenerator:
         d = C // 8
         pc_qk = self._conv(p + ".qk", lambda: pack_conv(
             self.pack, np.concatenate([fold_spectral(sd, p + ".query"), fold_spectral(sd, p + ".key")])[..., None],
-            x.cmap, x.span))
+            x.cmap, x.span, precise=self.precise))
         pc_v = self._conv(p + ".value", lambda: pack_conv(self.pack, fold_spectral(sd, p + ".value")[..., None],
-                                                          x.cmap, x.span))
+                                                          x.cmap, x.span, precise=self.precise))
         qk = b.tensor(x.H, x.W, 2 * d)
         b.conv(p + ".qk", pc_qk, x, qk)
         N = x.H * x.W
+        if self.precise:                       # fp32 attention kernels read the value map as an ordinary NHWC hi / lo tensor
+            hv = b.tensor(x.H, x.W, C)
+            b.conv(p + ".value", pc_v, x, hv)
+            y = b.tensor(x.H, x.W, C)
+            b.attention(p, x, qk, d, hv.buf, hv.cpitch, y, float(sd[p + ".gamma"].reshape(-1)[0]))
+            return y
         npitch = pad_to(N, 64)
         vT = b.buf(C * npitch, 2, zero_init=True)
         b.conv(p + ".value", pc_v, x, vT, flags=nat.F_OUT_TRANSPOSED, Co=C, aux0=npitch)
@@ -139,13 +153,14 @@ class DeoldifyGenerator:
         assert S % 16 == 0 and S >= 32, "render size must be render_factor*16"
         sd, deep = self.sd, self.arch == "deep"
         kind, nblk = RESNET[self.arch]
-        b = PlanBuilder()
+        b = PlanBuilder(precise=self.precise)
+        pm = b.pm
         in_buf, out_buf = b.buf(S * S * 3, 1), b.buf(S * S * 3, 1)
 
         c8 = sd["layers.8.conv.0.weight_v"].shape[0] // 4          # channels after the last pixel shuffle
         c8s = pad_to(c8, 8)
         tail_span = c8s + 8
-        tail_pitch = pitch_for(tail_span)                          # 264 -> 320: 128-byte aligned pixel rows
+        tail_pitch = pitch_for(tail_span) * pm                     # 264 -> 320: 128-byte aligned pixel rows (precise: hi | lo)
         tail_buf = b.buf(S * S * tail_pitch, 2, zero_init=c8s != c8)
         tail_cmap = np.concatenate([np.arange(c8), c8s + np.arange(3)])
         x0 = b.tensor(S, S, 3, zero_init=False)
@@ -208,12 +223,12 @@ class DeoldifyGenerator:
             def make_shuf(order, p=p, x=x):
                 s, sh = bn_scale_shift(sd, p + ".shuf.conv.1")      # conv -> BN, no activation between: fold
                 W = conv_weight(sd, p + ".shuf.conv.0")
-                return pack_conv(self.pack, W * s[:, None, None, None], x.cmap, x.span, bias=sh, pixshuf=order)
+                return pack_conv(self.pack, W * s[:, None, None, None], x.cmap, x.span, bias=sh, pixshuf=order, precise=self.precise)
             pc = self._shuf_conv(p + ".shuf", make_shuf, fuse)
             up_c = pc.Cout // 4
             ups, sks = pad_to(up_c, 8), pad_to(skip.C, 8)
             cat_span = ups + sks
-            cat_pitch = pitch_for(cat_span)
+            cat_pitch = pitch_for(cat_span) * pm
             cat_buf = b.buf(skip.H * skip.W * cat_pitch, 2, zero_init=(ups != up_c or sks != skip.C))
             if fuse:
                 # 1x1 conv + BN + ReLU + PixelShuffle(2) + blur in ONE kernel (HAVC_F_PS_BLUR): the shuffled tensor never
@@ -242,7 +257,7 @@ class DeoldifyGenerator:
         # ---- layers.8 PixelShuffle_ICNR (weight norm, bias, no BN) -> blur -> layers.9 dense merge ----
         fuse8 = self._fuse_blur(x, c8, S)
         pc = self._shuf_conv("layers.8", lambda order, x=x: pack_conv(self.pack, conv_weight(sd, "layers.8.conv.0"), x.cmap, x.span,
-                                                                       bias=sd["layers.8.conv.0.bias"], pixshuf=order), fuse8)
+                                                                       bias=sd["layers.8.conv.0.bias"], pixshuf=order, precise=self.precise), fuse8)
         assert 2 * x.H == S
         if fuse8:
             b.conv("layers.8+blur", pc, x, View(tail_buf, 0, tail_pitch, S, S, c8, c8s),
@@ -256,7 +271,7 @@ class DeoldifyGenerator:
         # ---- layers.10 res_block: 2 x (spectral conv3x3 + bias -> ReLU), + input; layers.11/12 ----
         def res_pc(key):
             return self._conv(key, lambda: pack_conv(self.pack, conv_weight(sd, key), tail_cmap, tail_span,
-                                                     bias=sd[key + ".bias"], omap=tail_cmap, ospan=tail_span))
+                                                     bias=sd[key + ".bias"], omap=tail_cmap, ospan=tail_span, precise=self.precise))
         r1 = View(b.buf(S * S * tail_pitch), 0, tail_pitch, S, S, c8 + 3, tail_span, tail_cmap)
         b.conv("layers.10.layers.0.0", res_pc("layers.10.layers.0.0"), cat, r1, pad=1, flags=nat.F_RELU_PRE,
                tag=TAG_TAIL_RES)
@@ -280,7 +295,7 @@ class DeoldifyGenerator:
             b.conv("layers.10.layers.1.0", pc2, r1, r2, pad=1,
                    flags=nat.F_RELU_PRE | nat.F_RESIDUAL, res=cat, tag=TAG_TAIL_RES)
             pc = self._conv("layers.11.0", lambda: pack_conv(self.pack, conv_weight(sd, "layers.11.0"), tail_cmap, tail_span,
-                                                             bias=sd["layers.11.0.bias"]))
+                                                             bias=sd["layers.11.0.bias"], precise=self.precise))
             b.conv("layers.11.0", pc, r2, out_buf, flags=nat.F_OUT_RGB8, f=(Y_RANGE[0], Y_RANGE[1], 0, 0), Co=3)
         ops, bufs = b.finish()
         return ops, bufs, in_buf, out_buf, b.names

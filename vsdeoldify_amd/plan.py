@@ -109,6 +109,7 @@ class PackedConv:
     kh: int
     kw: int
     C8a: int = 0                 # chunks per tap in the main K segment (== Ci/8 when K is not split)
+    pscale: float = 0.0          # precise packing: the factor between the MFMA accumulator and the convolution (op.f3); 0 = plain fp16 packing
 
 
 def pitch_for(span):
@@ -117,10 +118,30 @@ def pitch_for(span):
     return span if span <= 64 else pad_to(span, 64)
 
 
-def pack_conv(pack, W, cmap, Ci, bias=None, scale=None, shift=None, pixshuf=False, omap=None, ospan=None):
+def split_weights(flat):
+    """precise packing of a [Npad][K] fp32 weight matrix: three K segments for the unchanged fp16 MFMA main loop,
+        [2^11 w_hi | 2^11 w_lo | w_hi]   with  w_hi = fp16(w / 2^s), w_lo = w / 2^s - w_hi,
+    walked by the K table as x_hi, x_hi, x_lo' (x_lo' = 2^11 (x - x_hi), the activation's lo plane): the accumulator holds
+    2^(11-s) x (x_hi w_hi + x_hi w_lo + x_lo w_hi) -- the convolution up to the 2^-22 x_lo w_lo term.  s >= 0 keeps 2^11 w_hi inside
+    fp16 (|w| < 32 needs none; BN-folded encoder weights of a real checkpoint may).  Returns (fp16 [Npad][3K], accumulator scale 2^(s-11))."""
+    flat = np.asarray(flat, np.float32)
+    amax = float(np.abs(flat).max()) if flat.size else 0.0
+    s = 0
+    while amax / 2.0 ** s >= 31.0:
+        s += 1
+    w = flat / np.float32(2.0 ** s)
+    with np.errstate(over="raise"):
+        hi = w.astype(np.float16)
+        lo = ((w - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+        hi_up = (hi.astype(np.float32) * np.float32(2048.0)).astype(np.float16)
+    return np.concatenate([hi_up, lo, hi], axis=1), float(2.0 ** (s - 11))
+
+
+def pack_conv(pack, W, cmap, Ci, bias=None, scale=None, shift=None, pixshuf=False, omap=None, ospan=None, precise=False):
     """W [Cout, Cin, KH, KW] fp32 -> fp16 [Npad][KH*KW][Ci/8][8] (+ fp32 bias/scale/shift [Npad]).
     cmap: position of every logical input channel inside the Ci-wide input span;
-    omap/ospan: position of every logical output channel inside the ospan-wide output span."""
+    omap/ospan: position of every logical output channel inside the ospan-wide output span.
+    precise: the three-segment hi / lo packing of split_weights (HAVC_F_PRECISE convs; Kc is then 3 x the plain count)."""
     Cout, Cin, KH, KW = W.shape
     assert len(cmap) == Cin and Ci % 8 == 0
     if omap is None:
@@ -182,15 +203,23 @@ def pack_conv(pack, W, cmap, Ci, bias=None, scale=None, shift=None, pixshuf=Fals
             seg = seg.reshape(Npad, -1)
             padk = (-seg.shape[1]) % 64
             segs.append(np.pad(seg, ((0, 0), (0, padk))))
-    flat = np.concatenate(segs, axis=1).astype(np.float16)
+    flat = np.concatenate(segs, axis=1)
+    pscale = 0.0
+    if precise:
+        assert not pixshuf or pixshuf is True, "precise convs use the plain pixel-shuffle row order"
+        flat, pscale = split_weights(flat)
+    flat = flat.astype(np.float16)
     Kc = flat.shape[1] // 8
     return PackedConv(pack.add(flat), -1 if bias is None else pack.add(bias), -1 if scale is None else pack.add(scale),
-                      -1 if shift is None else pack.add(shift), Kc, Npad, Ci, Cout, Cin, KH, KW, C8a)
+                      -1 if shift is None else pack.add(shift), Kc, Npad, Ci, Cout, Cin, KH, KW, C8a, pscale)
 
 
 class PlanBuilder:
-    def __init__(self):
-        self.ops, self.bufs, self.names = [], [], []
+    def __init__(self, precise=False):
+        """precise: every tensor is a hi / lo pair of fp16 planes in one buffer (pixel row = [hi: P | lo: P], View.cpitch = 2 P) and every
+        op carries HAVC_F_PRECISE (include/havc_mi355.h); only the op types of the DeOldify generators exist in that form."""
+        self.ops, self.bufs, self.names, self.precise = [], [], [], precise
+        self.pm = 2 if precise else 1          # pitch multiplier
 
     def buf(self, elems_per_frame, elem_bytes=2, zero_init=False):
         self.bufs.append((int(elems_per_frame), elem_bytes, 1 if zero_init else 0))
@@ -199,7 +228,7 @@ class PlanBuilder:
     def tensor(self, H, W, C, zero_init=True):
         """fresh buffer holding one logical tensor; zero_init keeps pad channels 0 forever."""
         span = pad_to(C, 8)
-        pitch = pitch_for(span)
+        pitch = pitch_for(span) * self.pm
         return View(self.buf(H * W * pitch, 2, zero_init and span != C), 0, pitch, H, W, C, span)
 
     def _op(self, name, tag=None, **kw):
@@ -209,6 +238,9 @@ class PlanBuilder:
             op[f] = -1
         for k, v in kw.items():
             op[k] = v
+        if self.precise:
+            assert int(op["type"]) in (nat.OP_CONV, nat.OP_MAXPOOL, nat.OP_BLUR_RESIZE, nat.OP_AFFINE, nat.OP_ATTENTION, nat.OP_PREP_RGB8), name
+            op["flags"] |= nat.F_PRECISE
         if tag is None:
             tag = TAG_FIRST_FREE + len(self.names)
         op["tag"] = tag
@@ -222,6 +254,9 @@ class PlanBuilder:
         out_step=2 scatters output pixel (ho, wo) to (2*ho + out_oy, 2*wo + out_ox) of y (ConvTranspose parity convs,
         which also use dil=-1, asymmetric pad (pad_w) and an explicit out_hw)."""
         assert x.span == pc.Ci, (name, x.span, pc.Ci)
+        assert bool(pc.pscale) == self.precise, name
+        if self.precise:
+            f = (f[0], f[1], f[2], pc.pscale)
         if out_hw is not None:
             Ho, Wo = out_hw
         else:
@@ -271,8 +306,10 @@ class PlanBuilder:
                         Ci=x.span, Ho=y.H, Wo=y.W, Co=y.span, scale_off=scale_off, shift_off=shift_off)
 
     def attention(self, name, x, qk, d, vT_buf, npitch, y, gamma):
+        """fast plans: vT_buf = transposed value buffer [C][npitch]; precise plans: vT_buf = the NHWC value buffer, npitch = its pixel pitch"""
         N = x.H * x.W
-        return self._op(name, type=nat.OP_ATTENTION, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf,
+        extra = dict(kh=self.buf(N * 2, 4)) if self.precise else {}          # precise: fp32 [N][2] softmax statistics per frame
+        return self._op(name, type=nat.OP_ATTENTION, **extra, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf,
                         dst_coff=y.coff, dst_cpitch=y.cpitch, src2=qk.buf, res_coff=qk.coff, res_cpitch=qk.cpitch,
                         Hi=x.H, Wi=x.W, Ci=x.C, Ho=x.H, Wo=x.W, Co=x.C, aux0=d, aux1=vT_buf, Kc=npitch, f0=gamma,
                         flops=2 * N * N * d + 2 * N * N * x.C)

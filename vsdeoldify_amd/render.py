@@ -58,14 +58,15 @@ def _load_pth(path):
 class GeneratorRuntime:
     """Packed weights on one GPU + a cache of nets keyed by (render size, max_batch)."""
 
-    def __init__(self, ctx, state_dict, arch, fuse_final=True, fuse_blur=True, generator=None, share_key=None):
+    def __init__(self, ctx, state_dict, arch, fuse_final=True, fuse_blur=True, generator=None, share_key=None, precision="fast"):
         self.ctx, self.arch = ctx, arch
         if share_key is not None:              # worker contexts of one device: one packed blob for all of them
-            self.gen, self.weights = _shared_weights(ctx, (arch, fuse_final, fuse_blur) + tuple(share_key), lambda: generator or DeoldifyGenerator(
-                state_dict, arch, fuse_final=fuse_final, fuse_blur=fuse_blur))
+            self.gen, self.weights = _shared_weights(ctx, (arch, fuse_final, fuse_blur) + tuple(share_key) + ((precision,) if precision != "fast" else ()),
+                                                     lambda: generator or DeoldifyGenerator(state_dict, arch, fuse_final=fuse_final, fuse_blur=fuse_blur,
+                                                                                            precision=precision))
             self._owns_weights = False
         else:
-            self.gen = generator or DeoldifyGenerator(state_dict, arch, fuse_final=fuse_final, fuse_blur=fuse_blur)
+            self.gen = generator or DeoldifyGenerator(state_dict, arch, fuse_final=fuse_final, fuse_blur=fuse_blur, precision=precision)
             self.weights = nat.Weights(ctx, self.gen.blob)
             self._owns_weights = True
         self.nets = {}
@@ -96,8 +97,11 @@ class ModelImageRender:
     """Drop-in for vsdeoldify.deoldify.visualize.ModelImageRender."""
 
     def __init__(self, package_dir=None, modelname="video", render_factor=24, video_weight=0, device_index=0,
-                 state_dicts=None, max_batch=1, worker=0, coalesce=0):
-        """`worker`: index of the per-thread context on this GPU (get_context): renders built with different worker indices run
+                 state_dicts=None, max_batch=1, worker=0, coalesce=0, precision=None):
+        """`precision`: "fast" (default: fp16 activations and MFMA operands, fp32 accumulation: CIEDE2000 against the reference's fp32 path small
+        in the mean but p99 1.2 - 2.3 on the final image) or "precise" (fp32-class arithmetic like the reference,
+        deoldify/filters.py:45-68: hi / lo fp16 pairs on the same MFMA kernels, 3x the matrix work); None reads HAVC_PRECISION.
+        `worker`: index of the per-thread context on this GPU (get_context): renders built with different worker indices run
         concurrently from different threads and share the packed weights.
         `coalesce` = N > 0: ONE render shared by N caller threads (the reference's per-frame call shape under VapourSynth's thread pool):
         their concurrent get_transformed_image calls for frames already at the render size are merged into batches of up to
@@ -110,6 +114,9 @@ class ModelImageRender:
         self._worker = worker
         self._coalesce = coalesce
         self._batchers = {}
+        self._precision = precision or os.environ.get("HAVC_PRECISION", "fast")
+        if self._precision not in ("fast", "precise"):
+            raise ValueError(f"precision must be 'fast' or 'precise', not {self._precision!r}")
         self.ctx = get_context(device_index, worker)
         second = None if modelname == "video" else ("stable" if modelname == "stable" else "artistic")
         self._video = self._runtime("video", state_dicts)
@@ -120,10 +127,14 @@ class ModelImageRender:
         if state_dicts is not None and which in state_dicts:
             sd = state_dicts[which]
             if self._worker or os.environ.get("HAVC_SHARE_WEIGHTS", "0") != "0":
-                return GeneratorRuntime(self.ctx, sd, arch, share_key=("sd", id(sd)))
+                return GeneratorRuntime(self.ctx, sd, arch, share_key=("sd", id(sd)), precision=self._precision)
         else:
             path = os.path.join(str(self.package_dir), "models", name + ".pth")      # Learner.load path
             packed = os.path.splitext(path)[0] + ".havc"                             # tools/convert_weights.py output, if newer
+            if self._precision != "fast":                                            # the packed files hold the fast layout: precise packs from the .pth
+                if not os.path.isfile(path) or os.path.getsize(path) == 0:
+                    raise FileNotFoundError(f"DeOldify weights not found: {path}")
+                return GeneratorRuntime(self.ctx, _load_pth(path), arch, share_key=("file", path, os.path.getmtime(path)), precision=self._precision)
             if os.path.isfile(packed) and (not os.path.isfile(path) or os.path.getmtime(packed) >= os.path.getmtime(path)):
                 key = ("file", packed, os.path.getmtime(packed))
                 if (self.ctx.device_id, arch, True, True) + key in _weights_cache:
@@ -135,7 +146,7 @@ class ModelImageRender:
             if (self.ctx.device_id, arch, True, True) + key in _weights_cache:
                 return GeneratorRuntime(self.ctx, None, arch, share_key=key)
             return GeneratorRuntime(self.ctx, _load_pth(path), arch, share_key=key)
-        return GeneratorRuntime(self.ctx, sd, arch)
+        return GeneratorRuntime(self.ctx, sd, arch, precision=self._precision)
 
     # -- raw batched entry (frames already S x S, uint8 [n,S,S,3]) ------------------------------
     def render_square_batch(self, frames, post_process=True):
