@@ -54,44 +54,106 @@ def _stats(de, d):
             "bytes_within_1lsb": round(float((d <= 1).mean()), 5), "bytes_within_2lsb": round(float((d <= 2).mean()), 5)}
 
 
-def cpu_baseline_and_parity(cc_main, frames, threads, device_index):
+def cpu_baseline_and_parity(cc_main, frames, threads, device_index, cc_precise=None):
     """Time the CPU oracle (fp32 PyTorch restatement + numpy tail) on frames of the same workload and use its outputs as the parity
     reference for the GPU results of those frames: 8 frames of the clip over 3 seeded weight sets (the bench weights + two more),
-    per-frame statistics pooled, the worst frame named."""
+    per-frame statistics pooled, the worst frame named.  With cc_precise (the bench weights in precise mode) the SAME reference frames
+    also judge the precise path (a second parity object)."""
     import gc
     import torch
     from oracle import imaging, pipeline
     from vsdeoldify_amd.clip import ClipColorizer
     from vsdeoldify_amd.synth import synth_state_dict
     torch.set_num_threads(threads)
-    per, des, ds, cpu_s, cpu_n = [], [], [], 0.0, 0
+    modes = ["fast"] + (["precise"] if cc_precise is not None else [])
+    per, des, ds = {m: [] for m in modes}, {m: [] for m in modes}, {m: [] for m in modes}
+    cpu_s, cpu_n = 0.0, 0
     for (sv, ss), nfr in zip(PARITY_SEEDS, PARITY_FRAMES):
         sds = {"video": synth_state_dict("wide", sv), "stable": synth_state_dict("wide", ss)}
-        cc = cc_main if (sv, ss) == PARITY_SEEDS[0] else ClipColorizer("stable", RENDER_FACTOR, 0.5, device_index=device_index, state_dicts=sds, max_batch=2)
         idx = [(i * 7) % len(frames) for i in range(nfr)]
-        got = np.concatenate([cc.colorize(frames[i:i + 1]) for i in idx])
+        got = {}
+        for m in modes:
+            main = cc_main if m == "fast" else cc_precise
+            cc = main if (sv, ss) == PARITY_SEEDS[0] else ClipColorizer("stable", RENDER_FACTOR, 0.5, device_index=device_index, state_dicts=sds, max_batch=2,
+                                                                        precision=m)
+            got[m] = np.concatenate([cc.colorize(frames[i:i + 1]) for i in idx])
+            if cc is not main:
+                for r in (cc.render._video, cc.render._second):
+                    r.close()
+                del cc
+                gc.collect()
         for k, i in enumerate(idx):
             t0 = time.time()
             ref = pipeline.colorize_frame_fullsize(sds, "stable", frames[i], RENDER_FACTOR, 0.5)
             cpu_s += time.time() - t0
             cpu_n += 1
-            de = imaging.delta_e00_images(got[k], ref)
-            d = np.abs(got[k].astype(np.int32) - ref.astype(np.int32))
-            des.append(de.reshape(-1)); ds.append(d.reshape(-1))
-            per.append({"weights_seed": [sv, ss], "frame": int(i), "mean": round(float(de.mean()), 4), "p99": round(float(np.percentile(de, 99)), 4),
-                        "max": round(float(de.max()), 3)})
-        if cc is not cc_main:
-            for r in (cc.render._video, cc.render._second):
-                r.close()
-            del cc
-            gc.collect()
-    parity = _stats(np.concatenate(des), np.concatenate(ds))
-    worst = max(per, key=lambda r: r["p99"])
-    parity.update({"frames_checked": len(per), "weight_sets": len(PARITY_SEEDS), "worst_frame": worst, "per_frame": per, "against": "oracle (CPU fp32 port)",
-                   "note": "fp16 MFMA operands; floor / decomposition in profiles/r2_precision_study.txt"})
+            for m in modes:
+                de = imaging.delta_e00_images(got[m][k], ref)
+                d = np.abs(got[m][k].astype(np.int32) - ref.astype(np.int32))
+                des[m].append(de.reshape(-1)); ds[m].append(d.reshape(-1))
+                per[m].append({"weights_seed": [sv, ss], "frame": int(i), "mean": round(float(de.mean()), 4), "p99": round(float(np.percentile(de, 99)), 4),
+                               "max": round(float(de.max()), 3), "pixels_with_dE_below_1": round(float((de < 1.0).mean()), 5)})
+    out = {}
+    for m in modes:
+        parity = _stats(np.concatenate(des[m]), np.concatenate(ds[m]))
+        worst = max(per[m], key=lambda r: r["p99"])
+        parity.update({"frames_checked": len(per[m]), "weight_sets": len(PARITY_SEEDS), "worst_frame": worst, "per_frame": per[m], "against": "oracle (CPU fp32 port)",
+                       "note": "fp16 MFMA operands; floor / decomposition in profiles/r2_precision_study.txt" if m == "fast" else
+                               "hi / lo fp16 pairs, three-segment convs, fp32 epilogues and attention (HAVC_F_PRECISE): what is left is the fp32 summation-order floor"})
+        out[m] = parity
     base = {"value": round(cpu_n / cpu_s, 5), "unit": "frames/s", "cores": threads, "kind": "port",
             "sample": f"{cpu_n} frames of the 1080p clip (2 U-Net passes at 560x560 fp32 + Spline64/YUV tail each), {cpu_s:.1f} s"}
-    return base, parity
+    return base, out["fast"], out.get("precise")
+
+
+def precise_leg(args, sds, device_index, frames, fbytes):
+    """The mode that meets the CIEDE2000 < 1.0 contract per pixel: the same step on the same clip with
+    ModelImageRender(precision="precise") -- hi / lo fp16 activation pairs, three K segments per conv on the same MFMA kernels (3x the matrix
+    work), fp32 epilogues and attention.  16 frames per step (activations are twice as large).  Returns (leg dict, ClipColorizer)."""
+    from vsdeoldify_amd import _native as nat
+    from vsdeoldify_amd.clip import ClipColorizer
+    batch = min(16, args.batch)
+    cc = ClipColorizer("stable", RENDER_FACTOR, 0.5, device_index=device_index, state_dicts=sds, max_batch=batch, precision="precise")
+    ctx = cc.ctx
+    n = len(frames) // batch * batch
+    d_src, d_dst = ctx.dev_alloc(n * fbytes), ctx.dev_alloc(n * fbytes)
+    try:
+        ctx.dev_upload(d_src, frames[:n])
+
+        def step(i):
+            f0 = (i % (n // batch)) * batch
+            cc.colorize_device(off(d_src, f0 * fbytes), off(d_dst, f0 * fbytes), batch, WIDTH, HEIGHT)
+        step(0)
+        ctx.synchronize()
+        ctx.reset_stats()
+        nat.check(ctx.lib.havc_tag_timing_enable(ctx.h, TAG_TAIL_RES, 1), ctx.h)
+        steps = max(2, min(args.steps, 4))
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            step(1 + i)
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        avg_ms, launches = ctypes.c_double(), ctypes.c_int64()
+        nat.check(ctx.lib.havc_tag_timing_read(ctx.h, ctypes.byref(avg_ms), ctypes.byref(launches)), ctx.h)
+        nat.check(ctx.lib.havc_tag_timing_enable(ctx.h, TAG_TAIL_RES, 0), ctx.h)
+    finally:
+        ctx.dev_free(d_src)
+        ctx.dev_free(d_dst)
+    S, c = RENDER_FACTOR * 16, 259
+    fpl = steps * batch * 4 / max(int(launches.value), 1)
+    alg = 2.0 * fpl * S * S * c * c * 9
+    ach = alg / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
+    fps = steps * batch / dt
+    leg = {"value": round(fps, 2), "unit": "frames/s", "frames_per_step": batch, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2), "dtype": "f16x2 (hi / lo pairs, fp32 accumulate)",
+           "whole_path_tflops": round(fps * 2759.32e9 / 1e12, 2), "whole_path_frac": round(fps * 2759.32e9 / 1e12 / PEAK_F16_TFLOPS, 4),
+           "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4),
+                        "mfma_executed_frac": round(3 * ach / PEAK_F16_TFLOPS, 4), "launches_timed": int(launches.value), "frames_per_launch": round(fpl, 2),
+                        "avg_launch_ms": round(avg_ms.value, 4), "flops_per_launch": alg,
+                        "kernel": "conv_pipe_kernel<2,4,8,1> on the three-segment K walk (layers.10 res-block 3x3 259->259 @560x560): `achieved` counts the "
+                                  "ALGORITHMIC flops of the conv, the kernel executes 3x that on the MFMA pipe (mfma_executed_frac)"},
+           "how": "havc_colorize_clip with nets built by ModelImageRender(precision='precise') / HAVC_PRECISION=precise"}
+    return leg, cc
 
 
 def off(p, nbytes):
@@ -110,6 +172,7 @@ def main():
                          "c5 = configs[4] (ColorMNet exemplar path, 1 reference frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sustained / PCIe-inclusive / batch-1 legs")
+    ap.add_argument("--no-precise", action="store_true", help="skip the precise-mode leg (ModelImageRender(precision='precise'))")
     ap.add_argument("--sustain-seconds", type=float, default=30.0)
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads for the CPU-oracle baseline leg")
     args = ap.parse_args()
@@ -235,10 +298,18 @@ def main():
         out["multi_gpu"] = multi
     if rank == 0 and world == 1 and not args.no_extras:
         out.update(extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds))
+    cc_precise = None
+    if rank == 0 and world == 1 and not args.no_precise:
+        try:
+            out["precise"], cc_precise = precise_leg(args, sds, local_rank, frames, fbytes)
+        except Exception as e:                          # never lose the headline line to the second mode
+            out["precise"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, parity = cpu_baseline_and_parity(cc, frames, min(os.cpu_count() or 1, args.cpu_threads), local_rank)
+        base, parity, parity_p = cpu_baseline_and_parity(cc, frames, min(os.cpu_count() or 1, args.cpu_threads), local_rank, cc_precise)
         out["cpu_baseline"] = base
         out["parity"] = parity
+        if parity_p is not None:
+            out["precise"]["parity"] = parity_p
     if dist is not None:
         try:
             sg = sharded_clip_leg(cc, dist, rank, world, local_rank, torch)

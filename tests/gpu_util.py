@@ -54,3 +54,55 @@ def conv_op(ctx, x, W, bias=None, scale=None, shift=None, stride=1, pad=0, dil=1
     out = run_plan(ctx, pack, b, ups, {yv.buf: ((B, yv.H, yv.W, yv.cpitch), np.float16)}, B, cfg)[yv.buf]
     out = out[..., :yv.span]
     return out.astype(np.float32)[..., :yv.C].transpose(0, 3, 1, 2), out
+
+
+# ---- precise mode (HAVC_F_PRECISE): tensors are hi / lo fp16 pairs, pixel row = [hi: P | lo: P] ----
+def hl_split(x):
+    """fp32 array -> (hi, lo) fp16 arrays with hi + lo / 2048 == x up to 2^-22 relative (csrc/conv_common.h split_hl)"""
+    x = np.asarray(x, np.float32)
+    hi = x.astype(np.float16)
+    lo = ((x - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    return hi, lo
+
+
+def hl_pack(x_nchw, cpitch):
+    """float NCHW -> precise NHWC buffer image [n, h, w, cpitch] (cpitch = 2 P: hi plane, then lo plane)"""
+    n, c, h, w = x_nchw.shape
+    P = cpitch // 2
+    out = np.zeros((n, h, w, cpitch), np.float16)
+    hi, lo = hl_split(np.transpose(x_nchw, (0, 2, 3, 1)))
+    out[..., :c] = hi
+    out[..., P:P + c] = lo
+    return out
+
+
+def hl_unpack(buf, C):
+    """precise NHWC buffer image [n, h, w, 2 P] -> float32 NCHW of the first C channels"""
+    P = buf.shape[-1] // 2
+    v = buf[..., :C].astype(np.float32) + buf[..., P:P + C].astype(np.float32) / np.float32(2048.0)
+    return v.transpose(0, 3, 1, 2)
+
+
+def conv_op_precise(ctx, x, W, bias=None, scale=None, shift=None, stride=1, pad=0, dil=1, flags=0, res=None, pixshuf=False, cfg=0):
+    """conv_op in precise mode: fp32 in, fp32 out (both travel as hi / lo pairs), returns (float32 NCHW, raw buffer image)"""
+    B, Cin, H, Wd = x.shape
+    pack, b = WeightPack(), PlanBuilder(precise=True)
+    xv = b.tensor(H, Wd, Cin)
+    pc = pack_conv(pack, W.astype(np.float32), xv.cmap, xv.span, bias=bias, scale=scale, shift=shift, pixshuf=pixshuf, precise=True)
+    kh, kw = W.shape[2:]
+    Ho = (H + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    Wo = (Wd + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    if pixshuf:
+        flags |= nat.F_OUT_PIXSHUF
+        yv = b.tensor(2 * Ho, 2 * Wo, W.shape[0] // 4)
+    else:
+        yv = b.tensor(Ho, Wo, W.shape[0])
+    ups = {xv.buf: hl_pack(x, xv.cpitch)}
+    rv = None
+    if res is not None:
+        rv = b.tensor(Ho, Wo, W.shape[0])
+        ups[rv.buf] = hl_pack(res, rv.cpitch)
+        flags |= nat.F_RESIDUAL
+    b.conv("t", pc, xv, yv, stride=stride, pad=pad, dil=dil, flags=flags, res=rv)
+    raw = run_plan(ctx, pack, b, ups, {yv.buf: ((B, yv.H, yv.W, yv.cpitch), np.float16)}, B, cfg)[yv.buf]
+    return hl_unpack(raw, yv.C), raw

@@ -1,0 +1,199 @@
+"""-m gpu: the precise mode (HAVC_F_PRECISE; ModelImageRender(precision="precise") / HAVC_PRECISION=precise) against the fp32 CPU oracle.
+
+The reference computes in fp32 end to end (deoldify/filters.py:45-68, fastai/basic_train.py:352-363) and BASELINE.json's north_star asks for
+outputs "within CIEDE2000 < 1.0" of it.  The fast path (fp16 activations) meets that in the mean only (p99 1.2 - 2.3 on the final image
+depending on the weights).  The precise path keeps 22 significand bits per activation (hi / lo fp16 pairs), runs every
+conv as three K segments on the same MFMA kernels and everything else in fp32.  Stated tolerance, written here:
+
+  * a precise conv / attention / element-wise op vs torch fp32 on the same fp32 inputs: |diff| <= 2e-6 * max|ref| + 1e-6 (fp32-class:
+    the plain fp16 path needs 2e-3);
+  * raw colour of a generator (u8, before the YUV merge): >= 99.9 % of the bytes EQUAL to the oracle's, no byte off by more than 1
+    (uint8(x * 255) truncates: two fp32 evaluations that differ only in summation order already flip 0.01 - 0.03 % of the bytes);
+  * final 1080p image of BASELINE configs[1] over 8 frames x 3 seeded weight sets: CIEDE2000 p99 < 1.0 AND >= 99 % of the pixels below 1.0
+    (VERDICT r3 item 1), pooled and per frame.
+The fast path rides along in the 1080p test on the same frames and reference images, with thresholds that hold on all three weight sets.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import imaging, pipeline
+from tests import gpu_util as gu
+from tests.test_gpu_deoldify import make_frame, raw_gpu
+from vsdeoldify_amd import _native as nat
+from vsdeoldify_amd.plan import PlanBuilder, WeightPack
+from vsdeoldify_amd.render import GeneratorRuntime, ModelImageRender
+from vsdeoldify_amd.synth import synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+PRECISE_RAW = dict(equal=0.999, max_lsb=1)
+PRECISE_CLIP = dict(p99=1.0, frac_lt1=0.99)                 # the contract (BASELINE.json north_star)
+FAST_CLIP = dict(mean=0.35, p99=2.6, frac_lt1=0.84)         # fp16 path on ANY of the three weight sets (bench seeds: 0.12 / 1.25 / 0.97; seeds 11, 12: 0.24 / 2.27 / 0.87)
+
+
+def close32(got, ref, what, rtol=2e-6, atol=1e-6):
+    ref = np.asarray(ref, np.float32)
+    err = np.abs(got - ref).max()
+    lim = rtol * np.abs(ref).max() + atol
+    assert np.isfinite(got).all() and err <= lim, f"{what}: max|diff| {err:.4g} > {lim:.4g} (max|ref| {np.abs(ref).max():.4g})"
+
+
+PCONV = [   # (cfg, B, Cin, Cout, k, stride, pad, H, W)
+    (0, 1, 3, 64, 7, 2, 3, 48, 48), (0, 2, 64, 64, 1, 1, 0, 20, 20), (0, 1, 128, 128, 3, 2, 1, 17, 17), (0, 3, 96, 40, 3, 1, 1, 9, 11),
+    (0, 1, 259, 259, 3, 1, 1, 32, 32), (61, 2, 264, 259, 3, 1, 1, 21, 13), (60, 1, 320, 256, 3, 1, 1, 24, 24), (70, 2, 64, 128, 1, 1, 0, 19, 21),
+    (72, 1, 1024, 256, 1, 1, 0, 35, 35), (96, 1, 512, 256, 3, 1, 1, 18, 18), (99, 1, 64, 64, 3, 1, 1, 30, 30), (1, 1, 256, 256, 3, 1, 1, 12, 12),
+    (0, 1, 2048, 512, 1, 1, 0, 5, 5),
+]
+
+
+@pytest.mark.parametrize("case", PCONV, ids=[str(c) for c in PCONV])
+def test_precise_conv_matches_torch_fp32(ctx, case):
+    """fp32 inputs and weights (NOT pre-rounded to fp16), ReLU + residual epilogue: the three-segment conv is fp32-class"""
+    cfg, B, Cin, Cout, k, s, p, H, W = case
+    r = np.random.default_rng(hash(case) % 2**31)
+    x = r.standard_normal((B, Cin, H, W)).astype(np.float32) * 3
+    Wt = (r.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    bias = r.standard_normal(Cout).astype(np.float32)
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    res = r.standard_normal((B, Cout, Ho, Wo)).astype(np.float32)
+    got, raw = gu.conv_op_precise(ctx, x, Wt, bias=bias, stride=s, pad=p, flags=nat.F_RELU_PRE, res=res, cfg=cfg)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(Wt).double(), torch.from_numpy(bias).double(), s, p)) + torch.from_numpy(res).double()
+    close32(got, ref.float().numpy(), f"precise conv {case}")
+    P = raw.shape[-1] // 2
+    assert (raw[..., Cout:P] == 0).all() and (raw[..., P + Cout:] == 0).all(), "pad channels must stay zero in both planes"
+
+
+def test_precise_conv_affine_pixshuf_and_large_weights(ctx):
+    """ReLU -> affine epilogue, the pixel-shuffle scatter, and a weight pre-scale (|w| >= 31 does not fit 2^11 w_hi in fp16)"""
+    r = np.random.default_rng(3)
+    x = r.standard_normal((2, 64, 10, 12)).astype(np.float32)
+    Wt = (r.standard_normal((128, 64, 1, 1)) / 8).astype(np.float32)
+    Wt[5, 7, 0, 0] = 70.0
+    sc, sh = r.standard_normal(128).astype(np.float32), r.standard_normal(128).astype(np.float32)
+    got, _ = gu.conv_op_precise(ctx, x, Wt, scale=sc, shift=sh, flags=nat.F_RELU_PRE | nat.F_AFFINE)
+    ref = F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(Wt).double())) * torch.from_numpy(sc).double()[None, :, None, None] + \
+        torch.from_numpy(sh).double()[None, :, None, None]
+    close32(got, ref.float().numpy(), "precise conv + affine, pre-scaled weights", rtol=4e-6)
+    got, _ = gu.conv_op_precise(ctx, x, Wt, flags=nat.F_RELU_PRE, pixshuf=True)
+    ref = F.pixel_shuffle(F.relu(F.conv2d(torch.from_numpy(x).double(), torch.from_numpy(Wt).double())), 2)
+    close32(got, ref.float().numpy(), "precise conv + pixel shuffle", rtol=4e-6)
+
+
+@pytest.mark.parametrize("C,hw", [(512, (35, 35)), (256, (9, 13)), (128, (8, 8))])
+def test_precise_elementwise_and_attention_ops(ctx, C, hw):
+    """max pool, blur (+ nearest resize), BN affine + ReLU and fastai's SelfAttention (fastai/layers.py:81-96) in precise form vs torch fp32.
+    N = 1225 / 117 / 64 keys: not multiples of the 64-query / 32-key tiles."""
+    H, W = hw
+    r = np.random.default_rng(C)
+    B, d = 2, C // 8
+    x = r.standard_normal((B, C, H, W)).astype(np.float32)
+    pack, b = WeightPack(), PlanBuilder(precise=True)
+    xv = b.tensor(H, W, C)
+    # attention inputs: qk (f | g) and h come from convs in the net; here they are uploaded
+    qk, hv, av = b.tensor(H, W, 2 * d), b.tensor(H, W, C), b.tensor(H, W, C)
+    f = (r.standard_normal((B, d, H, W)) / 3).astype(np.float32)
+    g = (r.standard_normal((B, d, H, W)) / 3).astype(np.float32)
+    h = r.standard_normal((B, C, H, W)).astype(np.float32)
+    b.attention("attn", xv, qk, d, hv.buf, hv.cpitch, av, 0.37)
+    Hm, Wm = (H + 1) // 2, (W + 1) // 2
+    mv = b.tensor(Hm, Wm, C)
+    b.maxpool("pool", xv, mv)
+    bv = b.tensor(H - 1, W - 1, C)                       # blur + nearest resize to a smaller map (the 36 -> 35 case of rf = 35)
+    b.blur_resize("blur", xv, bv)
+    sc, sh = r.standard_normal(C).astype(np.float32), r.standard_normal(C).astype(np.float32)
+    fv = b.tensor(H, W, C)
+    b.affine("bn", xv, fv, pack.add(sc), pack.add(sh), relu=True)
+    shp = lambda v: ((B, v.H, v.W, v.cpitch), np.float16)
+    out = gu.run_plan(ctx, pack, b, {xv.buf: gu.hl_pack(x, xv.cpitch), qk.buf: gu.hl_pack(np.concatenate([f, g], 1), qk.cpitch), hv.buf: gu.hl_pack(h, hv.cpitch)},
+                      {v.buf: shp(v) for v in (av, mv, bv, fv)}, B)
+    xt = torch.from_numpy(x)
+    close32(gu.hl_unpack(out[mv.buf], C), F.max_pool2d(xt, 3, 2, 1).numpy(), "max pool", rtol=0, atol=1e-6)
+    blur = F.avg_pool2d(F.pad(xt, (1, 0, 1, 0), mode="replicate"), 2, stride=1)
+    close32(gu.hl_unpack(out[bv.buf], C), F.interpolate(blur, (H - 1, W - 1), mode="nearest").numpy(), "blur + nearest resize")
+    close32(gu.hl_unpack(out[fv.buf], C), F.relu(xt * torch.from_numpy(sc)[None, :, None, None] + torch.from_numpy(sh)[None, :, None, None]).numpy(), "affine + relu")
+    ft, gt, ht = (torch.from_numpy(a).double().reshape(B, a.shape[1], -1) for a in (f, g, h))
+    beta = F.softmax(torch.bmm(ft.permute(0, 2, 1), gt), dim=1)
+    ref = 0.37 * torch.bmm(ht, beta) + xt.double().reshape(B, C, -1)
+    close32(gu.hl_unpack(out[av.buf], C), ref.float().reshape(B, C, H, W).numpy(), "self attention", rtol=4e-6)
+
+
+@pytest.mark.parametrize("arch,which,seed", [("wide", "video", 1), ("deep", "artistic", 3), ("wide", "stable", 12)])
+@pytest.mark.parametrize("S", [64, 80])
+def test_precise_generator_raw_color_equals_the_oracle(ctx, arch, which, seed, S):
+    sd = synth_state_dict(arch, seed)
+    rt = GeneratorRuntime(ctx, sd, arch, precision="precise")
+    try:
+        frames = np.stack([make_frame(S, 10 + S), make_frame(S, 11 + S)])
+        got = raw_gpu(ctx, rt, frames)
+        ref = np.stack([pipeline.raw_color_square(sd, arch, f) for f in frames])
+        d = np.abs(got.astype(int) - ref.astype(int))
+        assert (d == 0).mean() >= PRECISE_RAW["equal"] and d.max() <= PRECISE_RAW["max_lsb"], (float((d == 0).mean()), int(d.max()))
+        # batch independence holds in precise mode too
+        assert np.array_equal(raw_gpu(ctx, rt, frames[1:]), got[1:])
+    finally:
+        rt.close()
+
+
+def test_model_image_render_precision_argument_and_environment(ctx):
+    from PIL import Image
+    sds = {"video": synth_state_dict("wide", 1), "stable": synth_state_dict("wide", 2)}
+    rf, img = 5, make_frame(80, 42)
+    ref = pipeline.model_image_render(sds, "stable", img, rf, 0.5)
+    outs = {}
+    for how in ("argument", "environment"):
+        if how == "environment":
+            os.environ["HAVC_PRECISION"] = "precise"
+        try:
+            r = ModelImageRender(None, "stable", rf, 0.5, state_dicts=sds, precision="precise" if how == "argument" else None)
+        finally:
+            os.environ.pop("HAVC_PRECISION", None)
+        assert r._video.gen.precise and r._second.gen.precise
+        outs[how] = np.asarray(r.get_transformed_image(Image.fromarray(img)))
+        for rt in (r._video, r._second):
+            rt.close()
+    assert np.array_equal(outs["argument"], outs["environment"])
+    de = imaging.delta_e00_images(outs["argument"], ref)
+    assert np.percentile(de, 99) < PRECISE_CLIP["p99"] and (de < 1.0).mean() >= PRECISE_CLIP["frac_lt1"], (float(np.percentile(de, 99)), float((de < 1).mean()))
+    with pytest.raises(ValueError):
+        ModelImageRender(None, "video", rf, 0.5, state_dicts=sds, precision="double")
+
+
+def test_colorize_clip_1080p_8_frames_3_weight_sets_precise_meets_the_contract(ctx):
+    """BASELINE configs[1] (stable, rf = 35, 1080p, two generators + blend + Spline64 + luma): 8 frames x 3 seeded weight sets against
+    oracle.pipeline.colorize_frame_fullsize.  precise: CIEDE2000 p99 < 1.0 and >= 99 % of the pixels below 1.0, per frame and pooled;
+    fast: the fp16 contract on the same frames, with thresholds that hold for every weight set (not only the bench's)."""
+    import gc
+    from vsdeoldify_amd.clip import ClipColorizer, synthetic_gray_frame
+    seeds, nfr = ((1, 2), (11, 12), (21, 22)), (4, 2, 2)
+    pooled = {"fast": [], "precise": []}
+    for (sv, ss), n in zip(seeds, nfr):
+        sds = {"video": synth_state_dict("wide", sv), "stable": synth_state_dict("wide", ss)}
+        idx = [(i * 7) % 32 for i in range(n)]
+        frames = np.stack([synthetic_gray_frame(i, 1920, 1080) for i in idx])
+        got = {}
+        for mode in ("fast", "precise"):
+            cc = ClipColorizer("stable", 35, 0.5, device_index=0, state_dicts=sds, max_batch=2, precision=mode)
+            got[mode] = np.concatenate([cc.colorize(frames[k:k + 2]) for k in range(0, n, 2)])
+            for rt in (cc.render._video, cc.render._second):
+                rt.close()
+            del cc
+            gc.collect()
+        for k in range(n):
+            ref = pipeline.colorize_frame_fullsize(sds, "stable", frames[k], 35, 0.5)
+            for mode in ("fast", "precise"):
+                de = imaging.delta_e00_images(got[mode][k], ref)
+                pooled[mode].append(de.reshape(-1))
+                p99, frac = float(np.percentile(de, 99)), float((de < 1.0).mean())
+                print(f"seeds {sv},{ss} frame {idx[k]} {mode:8s}: mean dE00 {de.mean():.4f} p99 {p99:.3f} max {de.max():.2f} dE<1 {frac:.5f}")
+                if mode == "precise":
+                    assert p99 < PRECISE_CLIP["p99"] and frac >= PRECISE_CLIP["frac_lt1"], (sv, ss, idx[k], p99, frac)
+                else:
+                    assert de.mean() < FAST_CLIP["mean"] and p99 < FAST_CLIP["p99"] and frac >= FAST_CLIP["frac_lt1"], (sv, ss, idx[k], float(de.mean()), p99, frac)
+    for mode, lim in (("precise", PRECISE_CLIP), ("fast", FAST_CLIP)):
+        de = np.concatenate(pooled[mode])
+        print(f"pooled {mode}: mean {de.mean():.4f} p99 {np.percentile(de, 99):.3f} dE<1 {float((de < 1).mean()):.5f}")
+        assert np.percentile(de, 99) < lim["p99"] and (de < 1.0).mean() >= lim["frac_lt1"]

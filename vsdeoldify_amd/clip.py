@@ -33,9 +33,9 @@ def synthetic_gray_frame(idx, width=1920, height=1080, base_seed=20240229):
 
 class ClipColorizer:
     def __init__(self, modelname="stable", render_factor=35, video_weight=0.5, device_index=0, state_dicts=None,
-                 package_dir=None, max_batch=8):
+                 package_dir=None, max_batch=8, precision=None):
         self.render = ModelImageRender(package_dir, modelname, render_factor, video_weight, device_index, state_dicts,
-                                       max_batch)
+                                       max_batch, precision=precision)
         self.ctx = self.render.ctx
         self.S = render_factor * RENDER_BASE
         self.max_batch = max_batch

@@ -110,9 +110,12 @@ __device__ __forceinline__ void epilogue_frag_precise(const ConvArgs& p, const f
 }
 
 // one 16x16 accumulator fragment -> fused epilogue -> store.  lane owns pixel m, channels n..n+3.
+// PRECISE is a COMPILE-TIME switch: the precise epilogue lives in kernel instantiations of its own, the fast kernels carry none of its
+// code (a run-time branch here cost the dominant fast kernel 60 % -- register allocation of the whole kernel changed).
+template <bool PRECISE = false>
 __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v acc, int m, int n, int HoWo) {
     if (m >= p.M || n >= p.Npad) return;
-    if (p.flags & HAVC_F_PRECISE) { epilogue_frag_precise(p, acc, m, n, HoWo); return; }
+    if (PRECISE) { epilogue_frag_precise(p, acc, m, n, HoWo); return; }
     const bool leaky = p.flags & HAVC_F_LEAKY;
     float v[4];
 #pragma unroll

@@ -15,7 +15,7 @@
 
 __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool PRECISE = false>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     constexpr int FM = BM / WM / 16;  // 16-pixel fragments per wave
     constexpr int FN = BN / WN / 16;  // 16-channel fragments per wave
@@ -141,14 +141,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     for (int mi = 0; mi < FM; ++mi) {
         const int m = m0 + wm * (BM / WM) + mi * 16 + lr;
 #pragma unroll
-        for (int ni = 0; ni < FN; ++ni) epilogue_frag(p, acc[ni][mi], m, n0 + wn * (BN / WN) + ni * 16 + lg * 4, HoWo);
+        for (int ni = 0; ni < FN; ++ni) epilogue_frag<PRECISE>(p, acc[ni][mi], m, n0 + wn * (BN / WN) + ni * 16 + lg * 4, HoWo);
     }
 }
 
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const ConvArgs& a, hipStream_t s) {
     const int MT = (a.M + BM - 1) / BM, NT = (a.Npad + BN - 1) / BN;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(MT * NT), dim3(256), 0, s, a);
+    if (a.flags & HAVC_F_PRECISE) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, true>), dim3(MT * NT), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(MT * NT), dim3(256), 0, s, a);
     return (int)hipGetLastError();
 }
 

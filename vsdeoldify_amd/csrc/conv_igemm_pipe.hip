@@ -57,7 +57,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 
 }  // namespace
 
-// ABL (profiling only, wrong results): 1 = no DMA inside the loop, 4 = no MFMA, 5 = no epilogue
+// ABL (profiling only, wrong results): 1 = no DMA inside the loop, 4 = no MFMA, 5 = no epilogue; ABL 30 (a product path): the precise epilogue
 // (Tried and dropped: staggering the DMA slots of the two waves sharing a SIMD -- 3-12 % slower, profiles/r1_conv_ablation.txt.)
 template <int WM, int WN, int FM, int EXTRA, int ABL = 0>
 __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p) {
@@ -577,6 +577,20 @@ bool conv_pipe_supported(const ConvArgs& a, int extra) {
 }
 
 int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
+    if (a.flags & HAVC_F_PRECISE) {                            // precise mode: the same main loops with the fp32 hi / lo epilogue (ABL 30)
+        switch (cfg) {
+            case 60: return launch_pipe<2, 4, 8, 0, 30>(a, s);
+            case 61: return launch_pipe<2, 4, 8, 1, 30>(a, s);
+            case 70: return launch_pipe<2, 2, 4, 0, 30>(a, s);
+            case 71: return launch_pipe<1, 4, 8, 0, 30>(a, s);
+            case 72: return launch_pipe<1, 2, 4, 0, 30>(a, s);
+            case 96: return launch_pipe<2, 4, 4, 0, 30>(a, s);
+            case 98: return launch_pipe<4, 2, 4, 0, 30>(a, s);
+            case 99: return launch_pipe<4, 1, 4, 0, 30>(a, s);
+            case 92: return launch_pipe<2, 1, 4, 0, 30>(a, s);
+        }
+        return (int)hipErrorInvalidValue;
+    }
     switch (cfg) {
         case 60: return launch_pipe<2, 4, 8, 0>(a, s);        // 256 x 256
         case 61: return launch_pipe<2, 4, 8, 1>(a, s);        // 256 x (256 + 16)

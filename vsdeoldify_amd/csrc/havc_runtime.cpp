@@ -1147,6 +1147,14 @@ static std::vector<int> tune_candidates(const havc_op& op) {
     }
     std::vector<int> cand = {0};
     if (op.Npad <= 16) return cand;                                        // thin N: the 128x16 kernel only
+    if (op.flags & HAVC_F_PRECISE) {                                       // precise convs: the tile geometries instantiated with the precise epilogue
+        if (op.Npad % 256 == 0 || op.Npad % 256 >= 192) { for (int k : {60, 71, 96}) cand.push_back(k); }
+        if (op.Npad % 256 == 16) cand.push_back(61);
+        if (op.Npad % 128 == 0 || op.Npad % 128 >= 96 || op.Npad > 256) { for (int k : {70, 72, 98}) cand.push_back(k); }
+        if (op.Npad % 64 == 0 && op.Npad <= 192) { cand.push_back(99); cand.push_back(92); }
+        for (int k : {1, 2, 3, 7}) cand.push_back(k);
+        return cand;
+    }
     // column tiles of 256 / 128 channels: also when the last tile is >= 75 % full (ConvNeXt pwconv2 at stage 0, 768 -> 192: the
     // 256 x 256 tile beats every narrower one by 30 %)
     if (op.Npad % 256 == 0 || op.Npad % 256 >= 192) { for (int k : {60, 71, 90, 91, 96, 97}) cand.push_back(k); }

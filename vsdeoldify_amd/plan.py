@@ -124,17 +124,24 @@ def split_weights(flat):
     walked by the K table as x_hi, x_hi, x_lo' (x_lo' = 2^11 (x - x_hi), the activation's lo plane): the accumulator holds
     2^(11-s) x (x_hi w_hi + x_hi w_lo + x_lo w_hi) -- the convolution up to the 2^-22 x_lo w_lo term.  s >= 0 keeps 2^11 w_hi inside
     fp16 (|w| < 32 needs none; BN-folded encoder weights of a real checkpoint may).  Returns (fp16 [Npad][3K], accumulator scale 2^(s-11))."""
-    flat = np.asarray(flat, np.float32)
-    amax = float(np.abs(flat).max()) if flat.size else 0.0
+    w = np.array(flat, np.float32)          # private copy: the arithmetic below runs in place (these matrices are hundreds of MB)
+    amax = float(np.abs(w).max()) if w.size else 0.0
     s = 0
     while amax / 2.0 ** s >= 31.0:
         s += 1
-    w = flat / np.float32(2.0 ** s)
-    with np.errstate(over="raise"):
-        hi = w.astype(np.float16)
-        lo = ((w - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
-        hi_up = (hi.astype(np.float32) * np.float32(2048.0)).astype(np.float16)
-    return np.concatenate([hi_up, lo, hi], axis=1), float(2.0 ** (s - 11))
+    if s:
+        w /= np.float32(2.0 ** s)
+    K = w.shape[1]
+    out = np.empty((w.shape[0], 3 * K), np.float16)
+    hi = w.astype(np.float16)
+    out[:, 2 * K:] = hi
+    hf = hi.astype(np.float32)
+    w -= hf                                 # exact in fp32
+    w *= np.float32(2048.0)
+    out[:, K:2 * K] = w                     # rounds to fp16 on assignment
+    hf *= np.float32(2048.0)
+    out[:, :K] = hf                         # exact (|w| < 31)
+    return out, float(2.0 ** (s - 11))
 
 
 def pack_conv(pack, W, cmap, Ci, bias=None, scale=None, shift=None, pixshuf=False, omap=None, ospan=None, precise=False):
