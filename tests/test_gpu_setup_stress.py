@@ -1,0 +1,29 @@
+"""-m gpu: concurrent model set-up from several host threads.  The reference's glue builds models from whichever VapourSynth
+worker thread asks first (vsslib/vsmodels.py:196-233); the library serialises set-up work behind one process-wide mutex and loads code objects /
+opts in to big LDS / sizes the queues' scratch eagerly at havc_create (csrc/havc_runtime.cpp).  The stress runs in a CHILD process under a
+timeout (a GPU hang must fail the test, not take the session with it): tools/setup_stress.py."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_concurrent_setup_of_three_model_kinds_from_four_threads():
+    """4 threads x {DeOldify, DDColor, ColorMNet} on fresh contexts, constructed, autotuned and first-called at the same time, 20 rounds
+    (80 concurrent set-ups; tools/setup_stress.py --reps 50 is the 200-set-up run recorded in profiles/): no hang, no error, and every
+    result byte-identical to the single-threaded baseline."""
+    env = dict(os.environ, HAVC_TUNE_CACHE="0")
+    env.pop("HAVC_SETUP_MUTEX", None)
+    env.pop("HAVC_EAGER_SETUP", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "setup_stress.py"), "--reps", "20", "--threads", "4"], env=env, cwd=ROOT,
+                       capture_output=True, text=True, timeout=900)
+    tail = (p.stdout + p.stderr)[-3000:]
+    assert p.returncode == 0, tail
+    res = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["setups"] == 80 and not res["errors"], res

@@ -358,3 +358,8 @@ int launch_attention(const half_t* qk, int qk_pitch, int f_coff, int g_coff, int
         return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }
+
+// Eager module load (havc_create, under the library's set-up mutex): the HIP runtime loads a translation unit's code object on the first use
+// of one of its kernels; querying one here moves that -- and the big-LDS opt-ins below -- out of the first launch, which may come from
+// several host threads at once ("set-up is serialised").
+void preload_attention() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(self_attention_kernel2<64>)); (void)hipGetLastError(); }

@@ -404,3 +404,8 @@ int launch_color_temporal_stabilizer(const uint8_t* const* frames, const double*
     hipLaunchKernelGGL(color_temporal_stabilizer_kernel, dim3(grid_for(npix)), dim3(256), 0, s, fl, out, npix);
     return (int)hipGetLastError();
 }
+
+// Eager module load (havc_create, under the library's set-up mutex): the HIP runtime loads a translation unit's code object on the first use
+// of one of its kernels; querying one here moves that -- and the big-LDS opt-ins below -- out of the first launch, which may come from
+// several host threads at once ("set-up is serialised").
+void preload_colorfilters() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(resize_h_kernel)); (void)hipGetLastError(); }

@@ -693,6 +693,21 @@ int launch_mem_similarity_t(const float* mk, const float* ms, const float* qk, c
     return (int)hipGetLastError();
 }
 
+// > 64 KiB of dynamic LDS needs an opt-in per kernel and DEVICE: done once per device, eagerly from havc_create (preload_colormnet) and -- for a
+// caller that reaches a launcher first -- lazily here; never on every launch.
+static void colormnet_lds_optin() {
+    static std::atomic<uint64_t> done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mem_topk_select_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(local_agg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipGetLastError();
+    done.fetch_or(bit, std::memory_order_release);
+}
+void preload_colormnet() { colormnet_lds_optin(); }
+
 // the wave-per-query selection holds the row in registers up to 64 x 128 = 8 192 memory elements, in LDS up to 16 384 (beyond: the two-level kernels)
 bool mem_topk_select_supported(int N) { return N <= 16384; }
 
@@ -701,13 +716,7 @@ int launch_mem_topk_select_readout(const float* simT, const float* mv, int* idx,
     dim3 grid(cdiv(HW, 4), B);
     const int nv = cdiv(N, 64);
     if (nv > 128) {
-        static std::atomic<uint64_t> optin{0};
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (!(optin.load() & (1ull << (dev & 63)))) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mem_topk_select_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-            optin.fetch_or(1ull << (dev & 63));
-        }
+        colormnet_lds_optin();
         hipLaunchKernelGGL(mem_topk_select_lds_kernel, dim3(HW, B), dim3(256), (size_t)N * 4, s, simT, idx, wgt, N, HW, K);
     } else if (nv <= 32) hipLaunchKernelGGL(mem_topk_select_kernel<32>, grid, dim3(256), 0, s, simT, idx, wgt, N, HW, K);
     else if (nv <= 64) hipLaunchKernelGGL(mem_topk_select_kernel<64>, grid, dim3(256), 0, s, simT, idx, wgt, N, HW, K);
@@ -763,7 +772,7 @@ int launch_local_agg(const float* attn, const float* v, float* agg, int n, int C
     const int ws = 2 * R + 1, HT = LC_T + 2 * R * dil;
     const size_t lds = (size_t)(LA_CC * HT * (HT + 1) + ws * ws * 64) * sizeof(float);
     if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(local_agg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    colormnet_lds_optin();
     hipLaunchKernelGGL(local_agg_kernel, dim3(cdiv(W, LC_T) * cdiv(H, LC_T), cdiv(CV, LA_CC), n), dim3(256), lds, s, attn, v, agg, CV, H, W, R, dil, n);
     return (int)hipGetLastError();
 }

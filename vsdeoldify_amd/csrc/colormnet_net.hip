@@ -634,3 +634,8 @@ int launch_planar_out(const half_t* x, int cp, int co, int64_t fs, float* y, int
     hipLaunchKernelGGL(planar_out_kernel, dim3(grid_for((int64_t)B * ((C + 7) / 8) * P)), dim3(256), 0, s, x, cp, co, fs, y, y_fs, B, P, C, act);
     return (int)hipGetLastError();
 }
+
+// Eager module load (havc_create, under the library's set-up mutex): the HIP runtime loads a translation unit's code object on the first use
+// of one of its kernels; querying one here moves that -- and the big-LDS opt-ins below -- out of the first launch, which may come from
+// several host threads at once ("set-up is serialised").
+void preload_colormnet_net() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(chan_gram_kernel)); (void)hipGetLastError(); }

@@ -226,3 +226,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     }
     return (int)hipErrorInvalidValue;
 }
+
+// Eager module load (havc_create, under the library's set-up mutex): the HIP runtime loads a translation unit's code object on the first use
+// of one of its kernels; querying one here moves that -- and the big-LDS opt-ins below -- out of the first launch, which may come from
+// several host threads at once ("set-up is serialised").
+void preload_conv_igemm() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(conv_igemm_kernel<128, 128, 2, 2>)); (void)hipGetLastError(); }

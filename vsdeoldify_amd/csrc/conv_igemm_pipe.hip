@@ -567,6 +567,21 @@ static int launch_pipe(const ConvArgs& a, hipStream_t s) {
     return (int)hipGetLastError();
 }
 
+// Every PRODUCT instantiation (the heuristic's and the autotuner's tile configurations, the halo conv, the precise epilogues): LDS opt-in + module
+// load, eagerly from havc_create under the library's set-up mutex, so that no first launch -- possibly from several host threads -- does either.
+void preload_conv_pipe() {
+#define PL(WM, WN, FM, EX, ABL) ensure_lds_optin<conv_pipe_kernel<WM, WN, FM, EX, ABL>>(Geo<WM, WN, FM, EX>::LDS_BYTES)
+    PL(2, 4, 8, 0, 0); PL(2, 4, 8, 1, 0); PL(2, 2, 4, 0, 0); PL(1, 4, 8, 0, 0); PL(1, 2, 4, 0, 0);
+    PL(1, 4, 6, 0, 0); PL(1, 4, 4, 0, 0); PL(2, 2, 6, 0, 0); PL(1, 2, 6, 0, 0); PL(2, 4, 4, 0, 0); PL(2, 4, 6, 0, 0); PL(4, 2, 4, 0, 0);
+    PL(4, 1, 4, 0, 0); PL(2, 1, 4, 0, 0);
+    PL(2, 4, 8, 0, 30); PL(2, 4, 8, 1, 30); PL(2, 2, 4, 0, 30); PL(1, 4, 8, 0, 30); PL(1, 2, 4, 0, 30); PL(2, 4, 4, 0, 30); PL(4, 2, 4, 0, 30);
+    PL(4, 1, 4, 0, 30); PL(2, 1, 4, 0, 30);
+#undef PL
+    ensure_lds_optin<conv_halo_kernel<0, 0>>(2 * 46 * 1024 + 2 * 256 * 128);
+    ensure_lds_optin<conv_halo_kernel<1, 0>>(2 * 46 * 1024 + 2 * 272 * 128);
+    (void)hipGetLastError();
+}
+
 bool conv_splitk_cfg_ok(int cfg) {
     switch (cfg) { case 60: case 70: case 71: case 72: case 90: case 91: case 92: case 93: case 95: case 96: case 97: case 98: case 99: return true; }
     return false;

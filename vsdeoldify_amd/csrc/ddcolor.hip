@@ -386,6 +386,26 @@ __global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __res
 bool dwconv7_ln_supported(int C) { return C == 64 || C == 192 || C == 384 || C == 768 || C == 1536; }
 
 template <int C4, bool WF32, int THREADS, bool PAIR>
+static void dwln_optin() {                                  // > 64 KiB of dynamic LDS: once per kernel instantiation and device
+    static std::atomic<uint64_t> optin{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (optin.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv7_ln_kernel<C4, WF32, THREADS, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    optin.fetch_or(bit, std::memory_order_release);
+}
+// every instantiation launch_dwconv7_ln may pick: opted in eagerly from havc_create (see preload_elementwise)
+void preload_ddcolor() {
+    dwln_optin<16, true, 768, false>();
+    dwln_optin<48, true, 512, true>(); dwln_optin<48, true, 768, false>();
+    dwln_optin<96, true, 512, true>(); dwln_optin<96, true, 768, false>();
+    dwln_optin<192, true, 512, true>(); dwln_optin<192, true, 768, false>();
+    dwln_optin<384, false, 768, false>(); dwln_optin<384, false, 512, true>();
+    (void)hipGetLastError();
+}
+
+template <int C4, bool WF32, int THREADS, bool PAIR>
 static int launch_dwln(const half_t* x, const half_t* w, const float* bias, const float* gamma, const float* beta, float eps, half_t* y, int B, int H,
                        int W, unsigned x_bytes, int x_cpitch, int x_coff, int y_cpitch, int y_coff, int w_pitch, hipStream_t s) {
     constexpr int S = THREADS / C4;
@@ -393,15 +413,7 @@ static int launch_dwln(const half_t* x, const half_t* w, const float* bias, cons
     const int64_t total = (int64_t)B * ((H + DWLN_T - 1) / DWLN_T) * ((W + DWLN_R - 1) / DWLN_R);
     const int64_t need = (total + S - 1) / S;
     const int grid = (int)(need < 256 ? need : 256);
-    static std::atomic<uint64_t> optin{0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const uint64_t bit = 1ull << (dev & 63);
-    if (!(optin.load(std::memory_order_acquire) & bit)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv7_ln_kernel<C4, WF32, THREADS, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024);
-        optin.fetch_or(bit, std::memory_order_release);
-    }
+    dwln_optin<C4, WF32, THREADS, PAIR>();
     hipLaunchKernelGGL((dwconv7_ln_kernel<C4, WF32, THREADS, PAIR>), dim3(grid), dim3(THREADS), lds, s, x, w, bias, gamma, beta, eps, y, B, H, W, x_bytes,
                        x_cpitch, x_coff, y_cpitch, y_coff, w_pitch);
     return (int)hipGetLastError();

@@ -341,3 +341,8 @@ int launch_range_stats(const void* p, int elem_bytes, int64_t n, unsigned* stats
     else return 0;
     return (int)hipGetLastError();
 }
+
+// Eager module load (havc_create, under the library's set-up mutex): the HIP runtime loads a translation unit's code object on the first use
+// of one of its kernels; querying one here moves that -- and the big-LDS opt-ins below -- out of the first launch, which may come from
+// several host threads at once ("set-up is serialised").
+void preload_elementwise() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(maxpool3x3s2_kernel)); (void)hipGetLastError(); }

@@ -16,6 +16,37 @@
 #include <string>
 #include <vector>
 
+// ---- set-up is serialised process-wide -------------------------------------------------------------------------------------------------
+// The reference's glue builds its models from whichever VapourSynth worker thread asks first (vsslib/vsmodels.py:196-233), so contexts,
+// weights and nets of SEVERAL models can be created -- and autotuned -- from several host threads at once.  Everything that is set-up rather
+// than steady-state work takes this one mutex (after the context's own): context creation (streams, eager code-object load, big-LDS opt-ins,
+// the per-queue scratch warm-up below), weight upload, net creation / destruction (hipMalloc / hipFree of the activation arenas), the
+// autotuner's trial launches, scratch regrowth and the device / pinned allocators.  Steady-state launches never take it.  History: before
+// round 4 concurrent set-up of two models from two threads preceded a "HW Exception: GPU Hang" (1 in ~15 runs).
+static std::recursive_mutex g_setup_mu;      // recursive: the autotuner's trial launches may regrow the split-K workspace (ensure_scratch)
+// HAVC_SETUP_MUTEX=0 turns the lock into a no-op (tools/setup_stress.py bisects with it; never a production setting)
+struct SetupLock {
+    bool on;
+    SetupLock() {
+        static const bool enabled = [] { const char* e = getenv("HAVC_SETUP_MUTEX"); return e ? atoi(e) != 0 : true; }();
+        on = enabled;
+        if (on) g_setup_mu.lock();
+    }
+    ~SetupLock() { if (on) g_setup_mu.unlock(); }
+    SetupLock(const SetupLock&) = delete;
+    SetupLock& operator=(const SetupLock&) = delete;
+};
+
+// Kernels that spill use per-queue scratch memory which the HIP runtime sizes on the FIRST launch that needs it (and re-sizes when a later
+// kernel needs more).  The largest private segment of any kernel of this library is 624 bytes per lane (conv_igemm_kernel<128,304>): this
+// kernel declares more than that and does nothing, so launching it once on each stream of a new context -- under the set-up mutex -- gives
+// every hardware queue its final scratch size before any product launch.
+__global__ void scratch_warm_kernel(int* out, int n) {
+    volatile int a[192];
+    for (int i = 0; i < n; ++i) a[i % 192] = i;
+    if (n == 12345) out[0] = a[n % 192];
+}
+
 namespace {
 
 thread_local std::string g_create_error;
@@ -113,8 +144,10 @@ int ensure_scratch(havc_ctx* c, int slot, size_t nbytes) {
     if (c->scratch_sz[slot] >= nbytes) return HAVC_OK;
     // a regrow costs a device synchronisation (hipFree / hipMalloc): grow by at least half, so that a request that creeps up call after call
     // (ColorMNet's memory read: the memory gains a frame every fifth frame) stalls the stream a handful of times, not every time
+    const size_t exact = (nbytes + 4095) & ~(size_t)4095;
     if (c->scratch[slot]) nbytes = std::max(nbytes, c->scratch_sz[slot] + c->scratch_sz[slot] / 2);
     nbytes = (nbytes + 4095) & ~(size_t)4095;
+    SetupLock setup;
     if (c->scratch[slot]) {
         HIP_TRY(c, sync_streams(c));
         (void)hipFree(c->scratch[slot]);
@@ -122,7 +155,13 @@ int ensure_scratch(havc_ctx* c, int slot, size_t nbytes) {
         c->scratch[slot] = nullptr;
         c->scratch_sz[slot] = 0;
     }
-    HIP_TRY(c, hipMalloc(&c->scratch[slot], nbytes));
+    hipError_t e = hipMalloc(&c->scratch[slot], nbytes);
+    if (e == hipErrorOutOfMemory && nbytes > exact) {      // the head-room is a convenience: near the memory limit fall back to the exact size
+        (void)hipGetLastError();
+        nbytes = exact;
+        e = hipMalloc(&c->scratch[slot], nbytes);
+    }
+    if (e != hipSuccess) { c->scratch[slot] = nullptr; return hip_fail(c, e, "workspace allocation"); }
     c->scratch_sz[slot] = nbytes;
     c->stats.bytes_resident += (int64_t)nbytes;
     return HAVC_OK;
@@ -159,6 +198,7 @@ int get_resize_table(havc_ctx* c, int src, int dst, ResizeTable** out) {
     }
     ResizeTable tb;
     tb.taps = taps;
+    SetupLock setup;
     HIP_TRY(c, hipMalloc((void**)&tb.d_start, dst * sizeof(int)));
     HIP_TRY(c, hipMalloc((void**)&tb.d_w, w.size() * sizeof(float)));
     HIP_TRY(c, hipMemcpy(tb.d_start, start.data(), dst * sizeof(int), hipMemcpyHostToDevice));
@@ -221,6 +261,7 @@ int build_pil_table(havc_ctx* c, int in_size, int out_size, int resample, PilTab
         bounds[xx * 2] = xmin; bounds[xx * 2 + 1] = xmax;
     }
     tb->ksize = ksize;
+    SetupLock setup;
     HIP_TRY(c, hipMalloc((void**)&tb->d_bounds, bounds.size() * sizeof(int)));
     HIP_TRY(c, hipMalloc((void**)&tb->d_kk, kk.size() * sizeof(int)));
     HIP_TRY(c, hipMemcpy(tb->d_bounds, bounds.data(), bounds.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -804,15 +845,29 @@ extern "C" {
 
 const char* havc_version(void) { return "havc_mi355 0.1.0 (gfx950)"; }
 
+static void havc_destroy_unlocked(havc_ctx* c);
+
 int havc_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
 
+static void preload_device_locked(int dev) {
+    static uint64_t done = 0;                              // guarded by g_setup_mu
+    if (done & (1ull << (dev & 63))) return;
+    preload_conv_pipe(); preload_conv_igemm(); preload_elementwise(); preload_zhang(); preload_attention(); preload_colorfilters();
+    preload_tweaks(); preload_ddcolor(); preload_colormnet(); preload_colormnet_net(); preload_precise();
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(scratch_warm_kernel));
+    (void)hipGetLastError();
+    done |= 1ull << (dev & 63);
+}
+
 int havc_create(havc_ctx** out, int device_id) {
     if (!out) return fail(nullptr, HAVC_E_INVALID, "out is NULL");
     *out = nullptr;
+    SetupLock setup;
     int n = havc_device_count();
     if (n <= 0) return fail(nullptr, HAVC_E_NODEVICE, "no HIP device visible (libhavc_mi355 needs an MI355X / gfx950 GPU)");
     if (device_id < 0 || device_id >= n) return fail(nullptr, HAVC_E_INVALID, "device_id out of range");
@@ -838,12 +893,27 @@ int havc_create(havc_ctx** out, int device_id) {
         delete c;
         return fail(nullptr, HAVC_E_HIP, "failed to create stream/events");
     }
+    static const bool eager = [] { const char* e = getenv("HAVC_EAGER_SETUP"); return e ? atoi(e) != 0 : true; }();
+    if (eager) {
+        preload_device_locked(device_id);
+        for (hipStream_t st : {c->stream, c->stream2}) hipLaunchKernelGGL(scratch_warm_kernel, dim3(1), dim3(64), 0, st, (int*)nullptr, 0);
+        if (hipGetLastError() != hipSuccess || sync_streams(c) != hipSuccess) {
+            (void)hipGetLastError();
+            havc_destroy_unlocked(c);
+            return fail(nullptr, HAVC_E_HIP, "scratch warm-up launch failed");
+        }
+    }
     *out = c;
     return HAVC_OK;
 }
 
 void havc_destroy(havc_ctx* c) {
     if (!c) return;
+    SetupLock setup;
+    havc_destroy_unlocked(c);
+}
+
+static void havc_destroy_unlocked(havc_ctx* c) {
     (void)hipSetDevice(c->dev);
     (void)hipStreamSynchronize(c->stream);
     if (c->stream_h2d) {
@@ -899,6 +969,7 @@ int havc_reset_stats(havc_ctx* c) {
 int havc_weights_load(havc_ctx* c, const void* blob, size_t nbytes, havc_weights** out) {
     if (!c || !blob || !out || nbytes == 0) return fail(c, HAVC_E_INVALID, "weights_load: bad args");
     std::lock_guard<std::mutex> lk(c->mu);
+    SetupLock setup;
     HIP_TRY(c, hipSetDevice(c->dev));
     uint8_t* d = nullptr;
     HIP_TRY(c, hipMalloc((void**)&d, nbytes));
@@ -912,6 +983,7 @@ int havc_weights_load(havc_ctx* c, const void* blob, size_t nbytes, havc_weights
 void havc_weights_free(havc_weights* w) {
     if (!w) return;
     std::lock_guard<std::mutex> lk(w->ctx->mu);
+    SetupLock setup;
     (void)sync_streams(w->ctx);
     (void)hipFree(w->d_blob);
     w->ctx->stats.bytes_resident -= (int64_t)w->nbytes;
@@ -924,6 +996,7 @@ int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops,
         return fail(c, HAVC_E_INVALID, "net_create: bad args");
     if (in_buf < 0 || in_buf >= n_bufs || out_buf < 0 || out_buf >= n_bufs) return fail(c, HAVC_E_INVALID, "net_create: in/out buffer id");
     std::lock_guard<std::mutex> lk(c->mu);
+    SetupLock setup;
     HIP_TRY(c, hipSetDevice(c->dev));
     for (int i = 0; i < n_ops; ++i) {
         const havc_op& o = ops[i];
@@ -1040,6 +1113,7 @@ int havc_net_create(havc_ctx* c, havc_weights* w, const havc_op* ops, int n_ops,
 void havc_net_free(havc_net* n) {
     if (!n) return;
     std::lock_guard<std::mutex> lk(n->ctx->mu);
+    SetupLock setup;
     (void)sync_streams(n->ctx);
     if (n->d_ktab) {
         (void)hipFree(n->d_ktab);
@@ -1181,6 +1255,7 @@ int havc_net_autotune(havc_net* n, int batch, int* n_changed) {
     if (!n) return HAVC_E_INVALID;
     havc_ctx* c = n->ctx;
     std::lock_guard<std::mutex> lk(c->mu);
+    SetupLock setup;                                       // trial launches of every tile geometry: the first launch of most kernel instantiations
     HIP_TRY(c, hipSetDevice(c->dev));
     if (batch < 1 || batch > n->max_batch) return fail(c, HAVC_E_INVALID, "autotune: batch out of range");
     HIP_TRY(c, sync_streams(c));
@@ -1867,6 +1942,7 @@ int havc_host_alloc(havc_ctx* c, size_t nbytes, void** out) {
     if (!c || !out) return HAVC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(c, hipSetDevice(c->dev));
+    SetupLock setup;
     HIP_TRY(c, hipHostMalloc(out, nbytes, hipHostMallocDefault));
     return HAVC_OK;
 }
@@ -1876,6 +1952,7 @@ int havc_host_free(havc_ctx* c, void* p) {
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(c, hipSetDevice(c->dev));
     HIP_TRY(c, sync_streams(c));
+    SetupLock setup;
     HIP_TRY(c, hipHostFree(p));
     return HAVC_OK;
 }
@@ -1977,6 +2054,7 @@ int havc_dev_alloc(havc_ctx* c, size_t nbytes, void** out) {
     if (!c || !out) return HAVC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(c, hipSetDevice(c->dev));
+    SetupLock setup;
     HIP_TRY(c, hipMalloc(out, nbytes));
     return HAVC_OK;
 }
@@ -1985,6 +2063,7 @@ int havc_dev_free(havc_ctx* c, void* p) {
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(c, hipSetDevice(c->dev));
     HIP_TRY(c, sync_streams(c));
+    SetupLock setup;
     HIP_TRY(c, hipFree(p));
     return HAVC_OK;
 }

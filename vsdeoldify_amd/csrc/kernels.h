@@ -161,6 +161,19 @@ int launch_local_agg(const float* attn, const float* v, float* agg, int n, int C
 
 int launch_range_stats(const void* p, int elem_bytes, int64_t n, unsigned* stats, hipStream_t s);
 
+// ---- eager module load + big-LDS opt-ins, one function per translation unit (called once per device from havc_create) ----
+void preload_conv_pipe();
+void preload_conv_igemm();
+void preload_elementwise();
+void preload_zhang();
+void preload_attention();
+void preload_colorfilters();
+void preload_tweaks();
+void preload_ddcolor();
+void preload_colormnet();
+void preload_colormnet_net();
+void preload_precise();
+
 // ---- precise mode (precise.hip): the non-conv ops of the DeOldify generators on hi / lo fp16 pairs, fp32 arithmetic ----
 int launch_prep_rgb8_p(const uint8_t* rgb, half_t* y0, int y0_cpitch, int y0_coff, half_t* y1, int y1_cpitch, int y1_coff, int64_t npix, hipStream_t s);
 int launch_maxpool3x3s2_p(const half_t* x, half_t* y, int B, int Hi, int Wi, int Ho, int Wo, int C, int x_cpitch, int x_coff, int y_cpitch, int y_coff,

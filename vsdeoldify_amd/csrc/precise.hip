@@ -7,6 +7,7 @@
 // Layout: a precise buffer's pixel row is [hi: P channels | lo: P channels]; a view's lo plane is cpitch / 2 elements behind its hi plane.
 // All kernels are HBM-bound except the attention, which is fp32 VALU (the N x N map of fastai's SelfAttention never leaves the CU).
 #include "conv_common.h"
+#include <atomic>
 
 namespace {
 
@@ -283,12 +284,22 @@ __global__ void __launch_bounds__(256) pattn_apply_kernel(const PAttnArgs a) {
 }
 
 template <auto Kernel>
-void lds_optin(int bytes) {
-    // per device and harmless when repeated (conv_igemm_pipe.hip ensure_lds_optin keeps the same rule)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+void lds_optin() {                                         // > 64 KiB of dynamic LDS: once per kernel and device (eagerly: preload_precise)
+    static std::atomic<uint64_t> done{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    done.fetch_or(bit, std::memory_order_release);
 }
 
 }  // namespace
+
+void preload_precise() {
+    lds_optin<pattn_stats_kernel>(); lds_optin<pattn_apply_kernel<4>>(); lds_optin<pattn_apply_kernel<2>>(); lds_optin<pattn_apply_kernel<1>>();
+    (void)hipGetLastError();
+}
 
 int launch_prep_rgb8_p(const uint8_t* rgb, half_t* y0, int y0_cpitch, int y0_coff, half_t* y1, int y1_cpitch, int y1_coff, int64_t npix, hipStream_t s) {
     hipLaunchKernelGGL(prep_rgb8_p_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, y0, y0_cpitch, y0_coff, y1, y1_cpitch, y1_coff, npix);
@@ -330,15 +341,15 @@ int launch_attention_p(const half_t* qk, int qk_cpitch, int f_coff, int g_coff, 
     a.o_cp = o_cpitch; a.o_co = o_coff; a.B = B; a.N = N; a.C = C; a.qk_fs = qk_fs; a.h_fs = h_fs; a.x_fs = x_fs; a.o_fs = o_fs; a.gamma = gamma;
     const int DP = d + 4, NJ = (N + PA_TJ - 1) / PA_TJ;
     const int lds_a = (PA_TJ * DP + PA_TI * DP + 4 * 64 * 2) * 4;
-    lds_optin<pattn_stats_kernel>(lds_a);
+    lds_optin<pattn_stats_kernel>();
     hipLaunchKernelGGL(pattn_stats_kernel, dim3(NJ, B), dim3(256), lds_a, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     const int CC = (C % 512 == 0) ? 512 : ((C % 256 == 0) ? 256 : 128);
     const int lds_b = (PA_TJ * DP + PA_TI * DP + PA_TI * PA_TJ + PA_TI * CC) * 4;
     const dim3 grid(NJ, B, C / CC);
-    if (CC == 512) { lds_optin<pattn_apply_kernel<4>>(lds_b); hipLaunchKernelGGL(pattn_apply_kernel<4>, grid, dim3(256), lds_b, s, a); }
-    else if (CC == 256) { lds_optin<pattn_apply_kernel<2>>(lds_b); hipLaunchKernelGGL(pattn_apply_kernel<2>, grid, dim3(256), lds_b, s, a); }
-    else { lds_optin<pattn_apply_kernel<1>>(lds_b); hipLaunchKernelGGL(pattn_apply_kernel<1>, grid, dim3(256), lds_b, s, a); }
+    if (CC == 512) { lds_optin<pattn_apply_kernel<4>>(); hipLaunchKernelGGL(pattn_apply_kernel<4>, grid, dim3(256), lds_b, s, a); }
+    else if (CC == 256) { lds_optin<pattn_apply_kernel<2>>(); hipLaunchKernelGGL(pattn_apply_kernel<2>, grid, dim3(256), lds_b, s, a); }
+    else { lds_optin<pattn_apply_kernel<1>>(); hipLaunchKernelGGL(pattn_apply_kernel<1>, grid, dim3(256), lds_b, s, a); }
     return (int)hipGetLastError();
 }

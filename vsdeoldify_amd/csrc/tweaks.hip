@@ -280,3 +280,8 @@ int launch_chroma_tweak(const uint8_t* img, uint8_t* out, int64_t npix, const Ch
     hipLaunchKernelGGL(chroma_tweak_kernel, dim3(grid_for_px(npix)), dim3(256), 0, s, img, out, npix, a);
     return (int)hipGetLastError();
 }
+
+// Eager module load (havc_create, under the library's set-up mutex): the HIP runtime loads a translation unit's code object on the first use
+// of one of its kernels; querying one here moves that -- and the big-LDS opt-ins below -- out of the first launch, which may come from
+// several host threads at once ("set-up is serialised").
+void preload_tweaks() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(chroma_tweak_kernel)); (void)hipGetLastError(); }

@@ -307,3 +307,8 @@ int launch_cmn_lab_to_rgb(const float* l_plane, const float* ab, uint8_t* rgb, i
     hipLaunchKernelGGL(cmn_lab_to_rgb_kernel, dim3(grid_for(npix)), dim3(256), 0, s, l_plane, ab, rgb, npix);
     return (int)hipGetLastError();
 }
+
+// Eager module load (havc_create, under the library's set-up mutex): the HIP runtime loads a translation unit's code object on the first use
+// of one of its kernels; querying one here moves that -- and the big-LDS opt-ins below -- out of the first launch, which may come from
+// several host threads at once ("set-up is serialised").
+void preload_zhang() { hipFuncAttributes a; (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(cmn_lab_to_rgb_kernel)); (void)hipGetLastError(); }

@@ -93,7 +93,7 @@ class HAVCFrameColorizer:
         # thread, while DeOldify runs on this one -- two independent chains of launches fill the chip better than one after the other
         # (HAVC_OVERLAP_MODELS=0: one after the other on one stream).  Same bytes either way.
         self.overlap_models = os.environ.get("HAVC_OVERLAP_MODELS", "1") != "0"
-        self._pool, self._warmed = None, set()
+        self._pool = None
 
     def _read_ddtweak(self, flags, tweaks):
         """vs_sc_ddcolor's tweak handling WITHOUT scene detection (vsslib/vsmodels.py:304-344,365-374; scenechange = False because
@@ -214,8 +214,10 @@ class HAVCFrameColorizer:
         sq = dclip if (w, h) == (fs, fs) else self._spline64(dclip, fs, fs)
         a = b = None
         dd_size = math.trunc(dd_rf / 2) * 32                                                      # vsmodels.py:302
-        shape_key = (tuple(sq.shape), dd_size)
-        if self._side_by_side() and is_device(sq) and shape_key in self._warmed:
+        if self._side_by_side() and is_device(sq):
+            # The two models side by side on two contexts, DDColor driven from a second thread -- from the first clip on: building the models,
+            # their nets and the tile autotuning from two host threads at once is serialised INSIDE the library (the set-up mutex of
+            # csrc/havc_runtime.cpp; the reference's glue builds models from whichever worker thread asks first, vsslib/vsmodels.py:196-233).
             import concurrent.futures
             if self._pool is None:
                 self._pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
@@ -223,25 +225,27 @@ class HAVCFrameColorizer:
 
             def branch():
                 bctx = self._ddcolor_model(dd_size).rt.ctx
-                out = self._ddcolor_branch(sq, dd_size, bctx)
-                bctx.synchronize()                                                                # (only enqueued: this context must not run ahead of it)
-                return out
+                try:
+                    return self._ddcolor_branch(sq, dd_size, bctx)
+                finally:
+                    bctx.synchronize()                                                            # (only enqueued: this context must not run ahead of it)
             fut = self._pool.submit(branch)
-            a = self._deoldify_clip(sq)
-            b = fut.result()
+            err = None
+            try:
+                a = self._deoldify_clip(sq)
+            except BaseException as e:                                                            # noqa: BLE001 -- re-raised below, after the branch has drained
+                err = e
+            try:
+                b = fut.result()          # ALWAYS waited for: the branch's stream reads `sq`, whose buffer returns to this context's pool when we leave
+            except BaseException as e:                                                            # noqa: BLE001
+                err = err or e
+            if err is not None:
+                raise err
         else:
-            # (also the FIRST clip of a shape: building the two models, their nets and the tile autotuning -- allocations, trial launches, first
-            #  loads of every kernel -- happens one model after the other; only warmed-up launch chains run side by side)
             if self.method != 1:
                 a = self._deoldify_clip(sq)
             if self.method != 0:
-                bctx = self._ddcolor_model(dd_size).rt.ctx if self._side_by_side() else None
-                if bctx is not None:
-                    self.ctx.synchronize()
-                b = self._ddcolor_branch(sq, dd_size, bctx)
-                if bctx is not None:
-                    bctx.synchronize()
-            self._warmed.add(shape_key)
+                b = self._ddcolor_branch(sq, dd_size, None)
         col = self._combine(a, b)
         out = self._spline64(col, w, h, luma_from=dclip)
         if host_in:
