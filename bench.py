@@ -73,6 +73,9 @@ def cpu_baseline_and_parity(cc_main, frames, threads, device_index, cc_precise=N
         idx = [(i * 7) % len(frames) for i in range(nfr)]
         got = {}
         for m in modes:
+            if m == "precise" and (sv, ss) != PARITY_SEEDS[0]:
+                continue            # (packing a precise generator pair takes a minute of host time: the bench checks the precise path on its own
+                                    #  weights; all three weight sets are the -m gpu test's job, tests/test_gpu_precise.py)
             main = cc_main if m == "fast" else cc_precise
             cc = main if (sv, ss) == PARITY_SEEDS[0] else ClipColorizer("stable", RENDER_FACTOR, 0.5, device_index=device_index, state_dicts=sds, max_batch=2,
                                                                         precision=m)
@@ -87,7 +90,7 @@ def cpu_baseline_and_parity(cc_main, frames, threads, device_index, cc_precise=N
             ref = pipeline.colorize_frame_fullsize(sds, "stable", frames[i], RENDER_FACTOR, 0.5)
             cpu_s += time.time() - t0
             cpu_n += 1
-            for m in modes:
+            for m in got:
                 de = imaging.delta_e00_images(got[m][k], ref)
                 d = np.abs(got[m][k].astype(np.int32) - ref.astype(np.int32))
                 des[m].append(de.reshape(-1)); ds[m].append(d.reshape(-1))
@@ -97,7 +100,7 @@ def cpu_baseline_and_parity(cc_main, frames, threads, device_index, cc_precise=N
     for m in modes:
         parity = _stats(np.concatenate(des[m]), np.concatenate(ds[m]))
         worst = max(per[m], key=lambda r: r["p99"])
-        parity.update({"frames_checked": len(per[m]), "weight_sets": len(PARITY_SEEDS), "worst_frame": worst, "per_frame": per[m], "against": "oracle (CPU fp32 port)",
+        parity.update({"frames_checked": len(per[m]), "weight_sets": len({tuple(r_["weights_seed"]) for r_ in per[m]}), "worst_frame": worst, "per_frame": per[m], "against": "oracle (CPU fp32 port)",
                        "note": "fp16 MFMA operands; floor / decomposition in profiles/r2_precision_study.txt" if m == "fast" else
                                "hi / lo fp16 pairs, three-segment convs, fp32 epilogues and attention (HAVC_F_PRECISE): what is left is the fp32 summation-order floor"})
         out[m] = parity
@@ -172,6 +175,7 @@ def main():
                          "c5 = configs[4] (ColorMNet exemplar path, 1 reference frame)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the sustained / PCIe-inclusive / batch-1 legs")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short c3 / c4 / c5 legs of the default run")
     ap.add_argument("--no-precise", action="store_true", help="skip the precise-mode leg (ModelImageRender(precision='precise'))")
     ap.add_argument("--sustain-seconds", type=float, default=30.0)
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads for the CPU-oracle baseline leg")
@@ -188,6 +192,13 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", os.environ.get("MASTER_PORT", "29533"), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
+
+    # ---- the other BASELINE configs as short legs of the DEFAULT run (the driver only runs `bench.py --gpus 1`) ----
+    # Fresh child processes, one after the other, BEFORE this process touches the GPU; each prints its own JSON line (the same code as
+    # `bench.py --config cX`), of which the headline fields are embedded under "other_configs".  --no-extras / --no-other-configs skip them.
+    other = None
+    if args.config == "c2" and world == 1 and rank == 0 and not args.no_extras and not args.no_other_configs:
+        other = other_configs_leg(args)
 
     import torch
     dist = None
@@ -310,6 +321,8 @@ def main():
         out["parity"] = parity
         if parity_p is not None:
             out["precise"]["parity"] = parity_p
+    if other is not None:
+        out["other_configs"] = other
     if dist is not None:
         try:
             sg = sharded_clip_leg(cc, dist, rank, world, local_rank, torch)
@@ -322,6 +335,34 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def other_configs_leg(args):
+    """c3 / c4 / c5 (BASELINE configs[2..4]) in child processes: {value, ms_per_step, whole_path_tflops, roofline frac, parity} per config"""
+    import subprocess
+    res = {}
+    for cfg in ("c3", "c4", "c5"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "3", "--warmup", "1", "--no-extras", "--cpu-threads", str(args.cpu_threads)]
+        if args.no_cpu_baseline:
+            cmd.append("--no-cpu-baseline")
+        t0 = time.time()
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+            lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not lines:
+                raise RuntimeError(f"rc {p.returncode}: {(p.stderr or p.stdout)[-300:]}")
+            o = json.loads(lines[-1])
+            par = o.get("parity") or {}
+            res[cfg] = {"metric": o["metric"], "value": o["value"], "unit": "frames/s", "ms_per_step": o["ms_per_step"],
+                        "frames_per_step": o["config"].get("frames_per_step_per_gpu"), "steps": o["steps"],
+                        "whole_path_tflops": o.get("whole_path_tflops"), "whole_path_frac": round((o.get("whole_path_tflops") or 0.0) / PEAK_F16_TFLOPS, 4),
+                        "roofline": {k: o["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "frames_per_launch")},
+                        "parity": {k: par.get(k) for k in ("ciede2000_mean", "ciede2000_p99", "pixels_with_dE_below_1", "frames_checked")} if par else None,
+                        "cpu_baseline": (o.get("cpu_baseline") or {}).get("value"), "workload": o["config"]["workload"],
+                        "leg_seconds": round(time.time() - t0, 1)}
+        except Exception as e:                                  # noqa: BLE001 -- a leg never costs the headline line
+            res[cfg] = {"error": f"{type(e).__name__}: {e}", "leg_seconds": round(time.time() - t0, 1)}
+    return res
 
 
 def sharded_clip_leg(cc, dist, rank, world, local_rank, torch):

@@ -61,7 +61,9 @@ def test_gpu_memory_read_matches_reference_vectors(ctx, gm, tag, has_ms, has_qe)
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,CK,CV,N,HW,k", [(1, 64, 512, 2000, 600, 30), (2, 32, 40, 77, 130, 30), (1, 64, 8, 20, 50, 30), (1, 16, 16, 300, 64, 5),
-                                            (1, 64, 16, 6100, 97, 30), (2, 64, 8, 12345, 70, 30), (1, 64, 8, 17000, 40, 30)])     # register / LDS radix select, two-level beyond 16 384
+                                            (1, 64, 16, 6100, 97, 30), (2, 64, 8, 12345, 70, 30), (1, 64, 8, 17000, 40, 30),      # register / LDS radix select, two-level beyond 16 384
+                                            (1, 64, 8, 16384, 40, 30), (1, 64, 8, 16381, 33, 30),     # the LDS select at its limit: N * 4 bytes of dynamic LDS + 16 static (> 64 KiB: opt-in)
+                                            (1, 64, 8, 20000, 24, 64)])                                # two-level merge at K = 64, 128 slices: exactly 64 KiB of dynamic LDS
 def test_gpu_memory_read_matches_oracle(ctx, B, CK, CV, N, HW, k):
     """bigger / ragged shapes, k > N, several batches; near-ties in the top-k may pick another element of (almost) equal weight:
     the readout is compared, not the index set"""

@@ -4,10 +4,11 @@
                   step_AnyExemplar (:119-230, a reference image of any content arrives with a frame), as colormnet_render.py:250-261
                   drives them; pad_divide_by / unpad of colormnet/util/tensor_util.py:18-51.
 
-The network stays the caller's object (the reference's torch ColorMNet on ROCm, with `short_term_attn` swapped for
-colormnet_torch.LocalGatedPropagation): this class only sequences its four entry points (encode_key, encode_value, segment,
-short_term_attn) around the memory, which is colormnet_memory.MemoryManager on the MI355X kernels.  Sequential in time by nature
-(every frame reads what the previous ones wrote): one clip per GPU, replicas only.
+The network is the caller's object with the reference's four entry points (encode_key, encode_value, segment, short_term_attn;
+model/network.py:52-145) -- in production vsdeoldify_amd.colormnet_net.ColorMNetNetwork, the whole network as one HIP plan; in the CPU
+tests a stub or the oracle network.  This class only sequences those entry points around the memory, which is
+colormnet_memory.MemoryManager on the MI355X kernels.  Sequential in time by nature (every frame reads what the previous ones
+wrote): one clip per GPU, replicas only.
 """
 import torch.nn.functional as F
 

@@ -278,6 +278,13 @@ class DeepExColorMNet:
             return
         net = self.render.network                                            # frames announced ahead are squashed on the look-ahead context's stream
         la_ctx = net.lookahead_context() if hasattr(net, "lookahead_context") else None
+        if la_ctx is not None:
+            # A device frame may still be being WRITTEN on its own context's stream (the output of another model handed straight to deepex):
+            # the look-ahead stream must not read it unordered (device.py's rule: a buffer crosses contexts behind a synchronize() of its
+            # producer).  Once per window and producer context, not per frame.
+            from .device import is_device
+            for pctx in {id(f.ctx): f.ctx for f in new if is_device(f) and f.ctx is not la_ctx}.values():
+                pctx.synchronize()
         smalls = [self._small(f, la_ctx) for f in new]
         self.render.prefetch([s for s, _ in smalls])
         for f, sm in zip(new, smalls):
@@ -289,6 +296,10 @@ class DeepExColorMNet:
         AHEAD, so that the key-encoder pass of the next window runs (on its own stream) while the memory step walks this window frame by frame.
         upcoming: the frame objects the NEXT call will start with (a streaming caller knows them): announced during the last window of this call."""
         frames, out, L = list(frames), [], max(1, self.render.lookahead)
+        if self._announced:                                                  # frames announced as `upcoming` that the caller did not come back with:
+            live = {id(f) for f in frames}                                   # their squashed copies and look-ahead entries are dropped, not kept forever
+            for k in [k for k in self._announced if k not in live]:          # (the render's own FIFO forgets an abandoned order by itself)
+                del self._announced[k]
         for i0 in range(0, len(frames), L):
             if i0 == 0:
                 self._announce(frames[:L])

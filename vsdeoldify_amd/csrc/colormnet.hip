@@ -703,6 +703,8 @@ static void colormnet_lds_optin() {
     if (done.load(std::memory_order_acquire) & bit) return;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mem_topk_select_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(local_agg_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    // the two-level merge holds S * K candidates (value + index): 128 slices x K = 64 is exactly 64 KiB of dynamic LDS on top of 512 static bytes
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(mem_topk_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipGetLastError();
     done.fetch_or(bit, std::memory_order_release);
 }
@@ -744,6 +746,7 @@ int launch_mem_topk_readout(const float* sim, const float* mv, int* idx, float* 
         const int len = (N + S - 1) / S;
         hipLaunchKernelGGL((mem_topk_kernel<false, false>), dim3(cdiv(HW, TOPK_THREADS), S, B), dim3(TOPK_THREADS), lds, s, sim, nullptr, cand_idx, cand_val, N,
                            HW, K, len);
+        colormnet_lds_optin();
         hipLaunchKernelGGL(mem_topk_merge_kernel, dim3(HW, B), dim3(64), (size_t)S * K * 8, s, cand_val, cand_idx, idx, wgt, S * K, HW, K);
     }
     hipError_t e = hipGetLastError();
