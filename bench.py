@@ -455,6 +455,16 @@ def extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds):
     dt = time.perf_counter() - t0
     res["batch1"] = {"value": round(k / dt, 2), "unit": "frames/s", "ms_per_call": round(dt / k * 1e3, 3),
                      "how": "ModelImageRender('stable', rf=35).get_transformed_image(PIL 560x560), one blocking call per frame (H2D + 2 passes + D2H)"}
+    # ---- the same single caller with the low-latency nets (split-K convs for one frame per launch; fp32 summation order differs) ----
+    r2 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1, low_latency=True)
+    for _ in range(3):
+        r2.get_transformed_image(img)
+    t0 = time.perf_counter()
+    for _ in range(k):
+        r2.get_transformed_image(img)
+    dt = time.perf_counter() - t0
+    res["batch1_low_latency"] = {"value": round(k / dt, 2), "unit": "frames/s", "ms_per_call": round(dt / k * 1e3, 3),
+                                 "how": "the same call on ModelImageRender(..., low_latency=True) / HAVC_LOW_LATENCY=1: nets for one frame per launch with split-K convs"}
     # ---- the same per-frame call from 16 threads (VapourSynth's worker pool) through ONE coalescing render: havc_batcher ----
     import threading
     T, K = 16, 6

@@ -453,6 +453,37 @@ int havc_local_attention(havc_ctx* ctx, const float* q, const float* k, const fl
 int havc_colormnet_rgb_to_lab(havc_ctx* ctx, const uint8_t* rgb, float* lab, int width, int height);
 int havc_colormnet_lab_to_rgb(havc_ctx* ctx, const float* l_plane, const float* ab, uint8_t* rgb, int width, int height);
 
+/* ---- ColorMNet fast step (round 4): the frame loop without tensor bookkeeping between the kernels ------------------------------------------
+ * The reference's InferenceCore / MemoryManager (colormnet/inference/inference_core.py:119-230, memory_manager.py:58-246, kv_memory_store.py:36-170)
+ * glue their kernels with torch.cat / F.pad / repeat / stack / add / topk on every frame.  These entry points let the host-side drop-in
+ * (vsdeoldify_amd/colormnet_fast.py) run a steady-state frame as a handful of enqueue-only calls on PRE-SIZED device buffers:
+ *   havc_cmn_frame_in     u8 RGB (host or device) -> normalised Lab planes [3][h][w] (get_image, colormnet_render.py:285-301) and, with img != NULL,
+ *                         the network input: the L plane three times, zero-padded to [3][padded_h][padded_w] (pad_divide_by 112)
+ *   havc_cmn_frame_out    L plane [h][w] + the PADDED ab planes [2][padded_h][padded_w] the decoder wrote -> u8 RGB (host or device), the unpad folded in
+ *   havc_memory_read_banked   havc_memory_read_topk_usage for B = 1 on memory BANKS: mk / mv rows have a pitch (elements) >= N, so the working and
+ *                         long-term memories live side by side in one pre-sized buffer and are read without a concatenation; the usage update
+ *                         (use_count += usage, life_count += 1 for elements [usage_from, N), kv_memory_store.py:93-101) happens in place
+ *   havc_cmn_short_term   LocalGatedPropagation on the last memory frame (havc_local_attention) + the plan's `short` slice (depthwise 5x5 + Linear) on the
+ *                         ctx's SECOND stream, forked behind the main stream: the memory read runs next to it.  agg [H*W][2 CV], attn [225][H*W],
+ *                         short_out [2 CV][H*W]: caller-owned device scratch / output; agg_buf / short_buf: the plan's buffer ids they are bound to
+ *   havc_cmn_join_add     main stream waits for that, then readout += short_out (inference_core.py `_read`)
+ *   havc_cmn_value_in     encode_value's input [2][5][pixels] from the padded image [3][pixels] and the ab planes [2][pixels] (network.py:87-101)
+ *   havc_dev_copy_2d      device -> device rows with pitches (appending a frame's key / value columns to the banks), enqueued on the ctx stream
+ *   havc_net_bind_many / havc_net_enqueue_slices   several havc_net_bind / havc_net_enqueue_ops in one call */
+int havc_cmn_frame_in(havc_ctx* ctx, const uint8_t* rgb, float* lab, float* img, int width, int height, int padded_w, int padded_h, int pad_left,
+                      int pad_top);
+int havc_cmn_frame_out(havc_ctx* ctx, const float* l_plane, const float* ab_padded, uint8_t* rgb, int width, int height, int padded_w, int padded_h,
+                       int pad_left, int pad_top);
+int havc_memory_read_banked(havc_ctx* ctx, const float* mk, const float* ms, const float* qk, const float* qe, const float* mv, float* out,
+                            float* use_count, float* life_count, int usage_from, int CK, int CV, int N, int64_t pitch, int HW, int top_k);
+int havc_cmn_short_term(havc_ctx* ctx, havc_net* net, int first_op, int n_ops, int agg_buf, int short_buf, const float* q, const float* k, const float* v,
+                        const float* rel_w, const float* rel_b, float* agg, float* attn, float* short_out, int C, int CV, int H, int W, int max_dis);
+int havc_cmn_join_add(havc_ctx* ctx, float* readout, const float* short_out, int64_t n);
+int havc_cmn_value_in(havc_ctx* ctx, const float* image, const float* planes, float* value_in, int64_t pixels);
+int havc_dev_copy_2d(havc_ctx* ctx, void* d_dst, size_t dst_pitch, const void* d_src, size_t src_pitch, size_t width_bytes, size_t rows);
+int havc_net_bind_many(havc_net* net, int count, const int32_t* bufs, void* const* device_ptrs);
+int havc_net_enqueue_slices(havc_net* net, int count, const int32_t* first_op, const int32_t* n_ops, const int32_t* batch);
+
 /* timing of the dominant kernel for bench.py's roofline object: average duration (ms) and launch count
  * of HAVC_OP_CONV ops with the given tag over the launches since havc_reset_stats (HIP events on the
  * ctx stream are recorded around those launches only while enabled). */

@@ -102,6 +102,34 @@ def test_deepex_colormnet_data_path_with_borders(ctx):
         assert got[t].shape == clip[t].shape and mean < 0.3 and p99 < 2.0, (t, mean, p99)
 
 
+def test_deepex_lookahead_reads_device_frames_behind_their_producer(ctx):
+    """DeepExColorMNet squashes announced frames on the LOOK-AHEAD context's stream.  Frames that are still being written
+    on the main context's stream when colorize_frames is called (the output of another model handed straight to deepex: here a Spline64 chain
+    enqueued right before the call, on buffers that held other content) must be read behind their producer: same bytes as with host frames."""
+    from vsdeoldify_amd.colormnet_net import ColorMNetNetwork
+    from vsdeoldify_amd.colormnet_render import DeepExColorMNet
+    from vsdeoldify_amd.device import DeviceImage
+    from vsdeoldify_amd.havc import spline64
+    from vsdeoldify_amd.synth import synth_colormnet_state_dict
+    net = ColorMNetNetwork(synth_colormnet_state_dict(1))
+    n, H, W = 6, 540, 960
+    big = np.stack([synthetic_gray_frame(40 + i, 1920, 1080) for i in range(n)])
+    host = [resample.resize_rgb8(f, W, H) for f in big]                                    # what the device chain below produces (checked)
+    ref = np.clip(host[0].astype(np.float32) * [1.05, 0.9, 0.75] + [10, 0, 12], 0, 255).astype(np.uint8)
+    base = [np.asarray(o) for o in DeepExColorMNet(vid_length=100, render_speed="fast", render_vivid=False, network=net).colorize_frames(host, {0: ref})]
+    for rep in range(3):
+        dbig = DeviceImage.from_numpy(net.ctx, big)
+        junk = [DeviceImage.from_numpy(net.ctx, np.full((H, W, 3), 255 - 40 * rep, np.uint8)) for _ in range(n)]
+        del junk                                                                           # their buffers return to the pool, holding stale content
+        dx = DeepExColorMNet(vid_length=100, render_speed="fast", render_vivid=False, network=net)
+        frames = [spline64(net.ctx, dbig.frame(i), W, H) for i in range(n)]              # only ENQUEUED on the main context's stream
+        got = [o.numpy() for o in dx.colorize_frames(frames, {0: ref})]
+        for t in range(n):
+            assert np.array_equal(frames[t].numpy(), host[t]) or np.abs(frames[t].numpy().astype(int) - host[t]).max() <= 1
+            d = np.abs(got[t].astype(int) - base[t].astype(int))
+            assert (d <= 2).mean() > 0.999, (rep, t, float((d <= 2).mean()), int(d.max()))
+
+
 def test_colormnet_at_the_slow_deepex_size(ctx):
     """HAVC_deepex render_speed 'slow': 512 x 288 (deepex/__init__.py:64-65) -> padded to 560 x 336 inside the step: odd 1/16 grid (21 x 35), DINOv2 grid
     24 x 40 interpolated to it, pads on both axes; exemplar + one propagated frame vs the oracle loop"""

@@ -145,6 +145,15 @@ SYMBOLS = [
     ("havc_batcher_submit", _I, [_P, _P, _P]),
     ("havc_batcher_stats", _I, [_P, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     ("havc_batcher_free", None, [_P]),
+    ("havc_cmn_frame_in", _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
+    ("havc_cmn_frame_out", _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
+    ("havc_memory_read_banked", _I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_int64, _I, _I]),
+    ("havc_cmn_short_term", _I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
+    ("havc_cmn_join_add", _I, [_P, _P, _P, C.c_int64]),
+    ("havc_cmn_value_in", _I, [_P, _P, _P, _P, C.c_int64]),
+    ("havc_dev_copy_2d", _I, [_P, _P, _SZ, _P, _SZ, _SZ, _SZ]),
+    ("havc_net_bind_many", _I, [_P, _I, _P, _P]),
+    ("havc_net_enqueue_slices", _I, [_P, _I, _P, _P, _P]),
     ("havc_tag_timing_enable", _I, [_P, _I, _I]),
     ("havc_tag_timing_read", _I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 ]

@@ -20,11 +20,13 @@ inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // TRANSPOSED: the result goes out query-major, simT[b][q][n] (the wave-per-query top-k below reads one contiguous row per query)
 template <bool HAS_QE, bool TRANSPOSED = false>
 __global__ void __launch_bounds__(256) mem_similarity_kernel(const float* __restrict__ mk, const float* __restrict__ ms, const float* __restrict__ qk,
-                                                             const float* __restrict__ qe, float* __restrict__ sim, int CK, int N, int HW, float sqrt_ck) {
+                                                             const float* __restrict__ qe, float* __restrict__ sim, int CK, int N, int HW, float sqrt_ck,
+                                                             int64_t mpitch) {
+    // mpitch: row pitch of mk in elements (N for the reference's contiguous [CK][N] tensors; larger when the memory lives in a pre-sized bank)
     __shared__ float Ms[16][64 + 1], Qs[16][64 + 1], Es[16][64 + 1];
     const int b = blockIdx.z, n0 = blockIdx.y * 64, q0 = blockIdx.x * 64;
     const int tid = threadIdx.x, tq = tid & 15, tn = tid >> 4;
-    const float* mkb = mk + (int64_t)b * CK * N;
+    const float* mkb = mk + (int64_t)b * CK * mpitch;
     const float* qkb = qk + (int64_t)b * CK * HW;
     const float* qeb = HAS_QE ? qe + (int64_t)b * CK * HW : nullptr;
     float a_sq[4][4], two_ab[4][4], b_sq[4];
@@ -39,7 +41,7 @@ __global__ void __launch_bounds__(256) mem_similarity_kernel(const float* __rest
         for (int i = tid; i < 16 * 64; i += 256) {
             const int c = i >> 6, x = i & 63;
             const bool cok = c0 + c < CK;
-            Ms[c][x] = (cok && n0 + x < N) ? mkb[(int64_t)(c0 + c) * N + n0 + x] : 0.f;
+            Ms[c][x] = (cok && n0 + x < N) ? mkb[(int64_t)(c0 + c) * mpitch + n0 + x] : 0.f;
             Qs[c][x] = (cok && q0 + x < HW) ? qkb[(int64_t)(c0 + c) * HW + q0 + x] : 0.f;
             if (HAS_QE) Es[c][x] = (cok && q0 + x < HW) ? qeb[(int64_t)(c0 + c) * HW + q0 + x] : 0.f;
         }
@@ -382,7 +384,7 @@ __global__ void __launch_bounds__(256) mem_topk_select_lds_kernel(const float* _
 
 // ---- readout: out[cv][q] = sum_j w[j][q] mv[cv][idx[j][q]]   (memory_manager._readout on the sparse affinity) ----
 __global__ void __launch_bounds__(256) mem_readout_kernel(const float* __restrict__ mv, const int* __restrict__ idx, const float* __restrict__ wgt,
-                                                          float* __restrict__ out, int CV, int N, int HW, int K) {
+                                                          float* __restrict__ out, int CV, int64_t N, int HW, int K) {      // N: row pitch of mv
     __shared__ int si[TOPK_MAX][64];
     __shared__ float sw[TOPK_MAX][64];
     const int b = blockIdx.z, q0 = blockIdx.x * 64, cv0 = blockIdx.y * 64;
@@ -419,7 +421,39 @@ __global__ void mem_usage_final_kernel(const unsigned long long* __restrict__ ac
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (i < total) usage[i] = (float)((double)acc[i] * (1.0 / 1099511627776.0));
 }
+// KeyValueMemoryStore.update_usage in place (kv_memory_store.py:93-101): use_count += usage, life_count += 1, for the elements [from, N)
+__global__ void mem_usage_update_kernel(const unsigned long long* __restrict__ acc, float* __restrict__ use, float* __restrict__ life, int from, int N) {
+    const int i = from + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) { use[i] = use[i] + (float)((double)acc[i] * (1.0 / 1099511627776.0)); life[i] = life[i] + 1.f; }
+}
+// encode_value's input (network.py:87-101 as colormnet_net.encode_value assembles it): per object i the image (3 planes), its own ab plane and the
+// other object's: vin[i] = [img0, img1, img2, m_i, m_(1-i)]
+__global__ void cmn_value_in_kernel(const float* __restrict__ img, const float* __restrict__ m, float* __restrict__ vin, int64_t P) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float a = img[i], b = img[P + i], c = img[2 * P + i], m0 = m[i], m1 = m[P + i];
+        vin[i] = a; vin[P + i] = b; vin[2 * P + i] = c; vin[3 * P + i] = m0; vin[4 * P + i] = m1;
+        vin[5 * P + i] = a; vin[6 * P + i] = b; vin[7 * P + i] = c; vin[8 * P + i] = m1; vin[9 * P + i] = m0;
+    }
+}
+__global__ void vec_add_kernel(float* __restrict__ y, const float* __restrict__ x, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = y[i] + x[i];
+}
 }  // namespace
+int launch_mem_usage_update(const int* idx, const float* wgt, unsigned long long* acc, float* use, float* life, int from, int N, int HW, int K, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(acc, 0, (size_t)N * 8, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(mem_usage_accum_kernel, dim3(cdiv((int64_t)K * HW, 256), 1), dim3(256), 0, s, idx, wgt, acc, N, HW, K);
+    if (N > from) hipLaunchKernelGGL(mem_usage_update_kernel, dim3(cdiv(N - from, 256)), dim3(256), 0, s, acc, use, life, from, N);
+    return (int)hipGetLastError();
+}
+int launch_cmn_value_in(const float* img, const float* planes, float* vin, int64_t P, hipStream_t s) {
+    hipLaunchKernelGGL(cmn_value_in_kernel, dim3(cdiv(P, 256) > 2048 ? 2048 : cdiv(P, 256)), dim3(256), 0, s, img, planes, vin, P);
+    return (int)hipGetLastError();
+}
+int launch_vec_add(float* y, const float* x, int64_t n, hipStream_t s) {
+    hipLaunchKernelGGL(vec_add_kernel, dim3(cdiv(n, 256) > 2048 ? 2048 : cdiv(n, 256)), dim3(256), 0, s, y, x, n);
+    return (int)hipGetLastError();
+}
 int launch_mem_usage(const int* idx, const float* wgt, unsigned long long* acc, float* usage, int B, int N, int HW, int K, hipStream_t s) {
     hipError_t e = hipMemsetAsync(acc, 0, (size_t)B * N * 8, s);
     if (e != hipSuccess) return (int)e;
@@ -677,19 +711,23 @@ __global__ void __launch_bounds__(256) local_agg_kernel(const float* __restrict_
 
 }  // namespace
 
-int launch_mem_similarity(const float* mk, const float* ms, const float* qk, const float* qe, float* sim, int B, int CK, int N, int HW, hipStream_t s) {
+int launch_mem_similarity(const float* mk, const float* ms, const float* qk, const float* qe, float* sim, int B, int CK, int N, int HW, hipStream_t s,
+                          int64_t mpitch) {
     dim3 grid(cdiv(HW, 64), cdiv(N, 64), B);
     const float sq = sqrtf((float)CK);
-    if (qe) hipLaunchKernelGGL(mem_similarity_kernel<true>, grid, dim3(256), 0, s, mk, ms, qk, qe, sim, CK, N, HW, sq);
-    else hipLaunchKernelGGL(mem_similarity_kernel<false>, grid, dim3(256), 0, s, mk, ms, qk, qe, sim, CK, N, HW, sq);
+    if (mpitch <= 0) mpitch = N;
+    if (qe) hipLaunchKernelGGL(mem_similarity_kernel<true>, grid, dim3(256), 0, s, mk, ms, qk, qe, sim, CK, N, HW, sq, mpitch);
+    else hipLaunchKernelGGL(mem_similarity_kernel<false>, grid, dim3(256), 0, s, mk, ms, qk, qe, sim, CK, N, HW, sq, mpitch);
     return (int)hipGetLastError();
 }
 
-int launch_mem_similarity_t(const float* mk, const float* ms, const float* qk, const float* qe, float* simT, int B, int CK, int N, int HW, hipStream_t s) {
+int launch_mem_similarity_t(const float* mk, const float* ms, const float* qk, const float* qe, float* simT, int B, int CK, int N, int HW, hipStream_t s,
+                            int64_t mpitch) {
     dim3 grid(cdiv(HW, 64), cdiv(N, 64), B);
     const float sq = sqrtf((float)CK);
-    if (qe) hipLaunchKernelGGL((mem_similarity_kernel<true, true>), grid, dim3(256), 0, s, mk, ms, qk, qe, simT, CK, N, HW, sq);
-    else hipLaunchKernelGGL((mem_similarity_kernel<false, true>), grid, dim3(256), 0, s, mk, ms, qk, qe, simT, CK, N, HW, sq);
+    if (mpitch <= 0) mpitch = N;
+    if (qe) hipLaunchKernelGGL((mem_similarity_kernel<true, true>), grid, dim3(256), 0, s, mk, ms, qk, qe, simT, CK, N, HW, sq, mpitch);
+    else hipLaunchKernelGGL((mem_similarity_kernel<false, true>), grid, dim3(256), 0, s, mk, ms, qk, qe, simT, CK, N, HW, sq, mpitch);
     return (int)hipGetLastError();
 }
 
@@ -713,7 +751,8 @@ void preload_colormnet() { colormnet_lds_optin(); }
 // the wave-per-query selection holds the row in registers up to 64 x 128 = 8 192 memory elements, in LDS up to 16 384 (beyond: the two-level kernels)
 bool mem_topk_select_supported(int N) { return N <= 16384; }
 
-int launch_mem_topk_select_readout(const float* simT, const float* mv, int* idx, float* wgt, float* out, int B, int CV, int N, int HW, int K, hipStream_t s) {
+int launch_mem_topk_select_readout(const float* simT, const float* mv, int* idx, float* wgt, float* out, int B, int CV, int N, int HW, int K, hipStream_t s,
+                                   int64_t vpitch) {
     if (K < 1 || K > TOPK_MAX || !mem_topk_select_supported(N)) return (int)hipErrorInvalidValue;
     dim3 grid(cdiv(HW, 4), B);
     const int nv = cdiv(N, 64);
@@ -726,7 +765,7 @@ int launch_mem_topk_select_readout(const float* simT, const float* mv, int* idx,
     else hipLaunchKernelGGL(mem_topk_select_kernel<128>, grid, dim3(256), 0, s, simT, idx, wgt, N, HW, K);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(mem_readout_kernel, dim3(cdiv(HW, 64), cdiv(CV, 64), B), dim3(256), 0, s, mv, idx, wgt, out, CV, N, HW, K);
+    hipLaunchKernelGGL(mem_readout_kernel, dim3(cdiv(HW, 64), cdiv(CV, 64), B), dim3(256), 0, s, mv, idx, wgt, out, CV, vpitch > 0 ? vpitch : (int64_t)N, HW, K);
     return (int)hipGetLastError();
 }
 
@@ -736,7 +775,7 @@ int mem_topk_splits(int N) {                                  // slices of the m
 }
 // cand_val / cand_idx: workspace of B * S * K * HW floats / ints each (S = mem_topk_splits(N)); unused when S == 1
 int launch_mem_topk_readout(const float* sim, const float* mv, int* idx, float* wgt, float* cand_val, int* cand_idx, float* out, int B, int CV, int N,
-                            int HW, int K, hipStream_t s) {
+                            int HW, int K, hipStream_t s, int64_t vpitch) {
     if (K < 1 || K > TOPK_MAX) return (int)hipErrorInvalidValue;
     const int S = mem_topk_splits(N);
     const size_t lds = (size_t)K * TOPK_THREADS * 8;
@@ -751,7 +790,7 @@ int launch_mem_topk_readout(const float* sim, const float* mv, int* idx, float* 
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(mem_readout_kernel, dim3(cdiv(HW, 64), cdiv(CV, 64), B), dim3(256), 0, s, mv, idx, wgt, out, CV, N, HW, K);
+    hipLaunchKernelGGL(mem_readout_kernel, dim3(cdiv(HW, 64), cdiv(CV, 64), B), dim3(256), 0, s, mv, idx, wgt, out, CV, vpitch > 0 ? vpitch : (int64_t)N, HW, K);
     return (int)hipGetLastError();
 }
 

@@ -75,8 +75,8 @@ struct havc_ctx {
     havc_stats stats{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // grow-only scratch (u8 staging + float resample rows): allocated once, reused every call
-    void* scratch[13] = {nullptr};         // 0-3 staging / model i-o, 4-5 plane staging, 6 small, 7 resample rows, 8-11 pipelined host clip,
-    size_t scratch_sz[13] = {0};           // 12 split-K partial sums
+    void* scratch[14] = {nullptr};         // 0-3 staging / model i-o, 4-5 plane staging, 6 small, 7 resample rows, 8-11 pipelined host clip,
+    size_t scratch_sz[14] = {0};           // 12 / 13 split-K partial sums of the launches on stream / stream2
     hipStream_t stream_h2d = nullptr, stream_d2h = nullptr;      // copy streams of havc_colorize_clip_host (created on first use)
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
     std::map<std::pair<int, int>, ResizeTable> resize_tables;
@@ -391,10 +391,11 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             if (a.splitk) {
                 if ((op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_FUSE_PROJ | HAVC_F_W_FROM_BUF | HAVC_F_OUT_RGB8)) || (op.Kc >> 3) < 2 * a.splitk)
                     return fail(c, HAVC_E_INVALID, "conv op: SPLITK needs a plain conv with at least 2 K stages per part");
-                if (s != c->stream) return fail(c, HAVC_E_INVALID, "conv op: SPLITK ops run on the main stream only (one scratch buffer per ctx)");
+                if (s != c->stream && s != c->stream2) return fail(c, HAVC_E_INVALID, "conv op: SPLITK ops run on the ctx's own streams (one workspace per stream)");
+                const int slot = s == c->stream ? 12 : 13;         // the two generators of a stable / artistic render run side by side on the two streams
                 const size_t need = (size_t)a.splitk * batch * op.Ho * op.Wo * op.Npad * 4;
-                if (int rc2 = ensure_scratch(c, 12, need)) return rc2;
-                a.ws = (float*)c->scratch[12];
+                if (int rc2 = ensure_scratch(c, slot, need)) return rc2;
+                a.ws = (float*)c->scratch[slot];
             }
             {
                 const int oi = (int)(&op - n->ops.data());
@@ -923,7 +924,7 @@ static void havc_destroy_unlocked(havc_ctx* c) {
         (void)hipStreamDestroy(c->stream_h2d);
         (void)hipStreamDestroy(c->stream_d2h);
     }
-    for (int i = 0; i < 12; ++i)
+    for (int i = 0; i < 14; ++i)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     for (auto& kv : c->resize_tables) { (void)hipFree(kv.second.d_start); (void)hipFree(kv.second.d_w); }
     for (auto& p : c->tag_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
@@ -2262,6 +2263,147 @@ int havc_colormnet_lab_to_rgb(havc_ctx* c, const float* l_plane, const float* ab
     c->stats.launches++;
     if (e) return hip_fail(c, (hipError_t)e, "colormnet_lab_to_rgb");
     return stage_out(c, rgb, d_out, npix * 3, host);
+}
+
+// ---- ColorMNet: the per-frame step without tensor bookkeeping between the kernels (include/havc_mi355.h, "fast step") -----------------------
+int havc_cmn_frame_in(havc_ctx* c, const uint8_t* rgb, float* lab, float* img, int width, int height, int padded_w, int padded_h, int pad_left, int pad_top) {
+    if (!c || !rgb || !lab || width < 1 || height < 1 || padded_w < width + pad_left || padded_h < height + pad_top || pad_left < 0 || pad_top < 0 ||
+        is_device_ptr(lab) == false || (img && !is_device_ptr(img)))
+        return fail(c, HAVC_E_INVALID, "cmn_frame_in: bad args (lab / img are device buffers)");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const uint8_t* d_in;
+    int rc;
+    if ((rc = stage_in(c, 0, rgb, (size_t)width * height * 3, &d_in))) return rc;
+    int e = launch_cmn_frame_in(d_in, lab, img, width, height, img ? padded_w : width, img ? padded_h : height, img ? pad_left : 0, img ? pad_top : 0, c->stream);
+    c->stats.launches++;
+    if (e) return hip_fail(c, (hipError_t)e, "cmn_frame_in");
+    return HAVC_OK;
+}
+
+int havc_cmn_frame_out(havc_ctx* c, const float* l_plane, const float* ab_padded, uint8_t* rgb, int width, int height, int padded_w, int padded_h,
+                       int pad_left, int pad_top) {
+    if (!c || !l_plane || !ab_padded || !rgb || width < 1 || height < 1 || padded_w < width + pad_left || padded_h < height + pad_top || pad_left < 0 || pad_top < 0 ||
+        !is_device_ptr(l_plane) || !is_device_ptr(ab_padded))
+        return fail(c, HAVC_E_INVALID, "cmn_frame_out: bad args (the Lab planes are device buffers)");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    const size_t nb = (size_t)width * height * 3;
+    uint8_t* d_out;
+    bool host;
+    int rc;
+    if ((rc = stage_out_ptr(c, 2, rgb, nb, &d_out, &host))) return rc;
+    int e = launch_cmn_frame_out(l_plane, ab_padded, d_out, width, height, padded_w, padded_h, pad_left, pad_top, c->stream);
+    c->stats.launches++;
+    if (e) return hip_fail(c, (hipError_t)e, "cmn_frame_out");
+    return stage_out(c, rgb, d_out, nb, host);
+}
+
+int havc_memory_read_banked(havc_ctx* c, const float* mk, const float* ms, const float* qk, const float* qe, const float* mv, float* out, float* use_count,
+                            float* life_count, int usage_from, int CK, int CV, int N, int64_t pitch, int HW, int top_k) {
+    if (!c || !mk || !qk || !mv || !out || CK < 1 || CV < 1 || N < 1 || HW < 1 || pitch < N || top_k < 1 || top_k > 64 || usage_from < 0 ||
+        (use_count && !life_count))
+        return fail(c, HAVC_E_INVALID, "memory_read_banked: bad args (top_k 1..64, pitch >= N)");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    int rc;
+    const size_t lst = (size_t)top_k * HW, cand = lst * (mem_topk_splits(N) > 1 ? mem_topk_splits(N) : 0);
+    if ((rc = ensure_scratch(c, 8, (size_t)N * HW * 4)) || (rc = ensure_scratch(c, 9, (lst + cand) * 4)) || (rc = ensure_scratch(c, 10, (lst + cand) * 4))) return rc;
+    static const bool wave_topk = [] { const char* e = getenv("HAVC_TOPK_WAVE"); return !e || atoi(e) != 0; }();
+    int e;
+    if (wave_topk && mem_topk_select_supported(N)) {
+        e = launch_mem_similarity_t(mk, ms, qk, qe, (float*)c->scratch[8], 1, CK, N, HW, c->stream, pitch);
+        if (!e) e = launch_mem_topk_select_readout((const float*)c->scratch[8], mv, (int*)c->scratch[9], (float*)c->scratch[10], out, 1, CV, N, HW, top_k, c->stream, pitch);
+    } else {
+        e = launch_mem_similarity(mk, ms, qk, qe, (float*)c->scratch[8], 1, CK, N, HW, c->stream, pitch);
+        if (!e) e = launch_mem_topk_readout((const float*)c->scratch[8], mv, (int*)c->scratch[9], (float*)c->scratch[10], (float*)c->scratch[10] + lst,
+                                            (int*)c->scratch[9] + lst, out, 1, CV, N, HW, top_k, c->stream, pitch);
+    }
+    c->stats.launches += 3;
+    if (!e && use_count) {
+        if ((rc = ensure_scratch(c, 11, (size_t)N * 8))) return rc;
+        e = launch_mem_usage_update((const int*)c->scratch[9], (const float*)c->scratch[10], (unsigned long long*)c->scratch[11], use_count, life_count,
+                                    usage_from, N, HW, top_k, c->stream);
+        c->stats.launches += 2;
+    }
+    if (e) return hip_fail(c, (hipError_t)e, "memory_read_banked");
+    return HAVC_OK;
+}
+
+int havc_cmn_short_term(havc_ctx* c, havc_net* net, int first_op, int n_ops, int agg_buf, int short_buf, const float* q, const float* k, const float* v,
+                        const float* rel_w, const float* rel_b, float* agg, float* attn, float* short_out, int C, int CV, int H, int W, int max_dis) {
+    if (!c || !net || net->ctx != c || !q || !k || !v || !rel_w || !rel_b || !agg || !attn || !short_out || C < 1 || CV < 1 || H < 1 || W < 1 || max_dis < 0 ||
+        max_dis > 7 || agg_buf < 0 || agg_buf >= (int)net->bufs.size() || short_buf < 0 || short_buf >= (int)net->bufs.size())
+        return fail(c, HAVC_E_INVALID, "cmn_short_term: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    // fork: stream2 starts behind everything the main stream holds so far (the producers of q / k / v), runs the local attention and the plan's
+    // `short` slice there, and records the join event havc_cmn_join_add waits for -- the main stream is free for the memory read meanwhile
+    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    int e = launch_local_correlation(q, k, attn, 1, C, H, W, max_dis, 1, 1.0f / sqrtf((float)C), c->stream2);
+    if (!e) e = launch_local_softmax(attn, q, rel_w, rel_b, 1, C, H, W, max_dis, 1, c->stream2);
+    if (!e) e = launch_local_agg(attn, v, agg, 1, CV, H, W, max_dis, 1, c->stream2);
+    c->stats.launches += 3;
+    if (e) { (void)hipStreamSynchronize(c->stream2); return hip_fail(c, (hipError_t)e, "cmn_short_term"); }
+    if (net->bound.empty()) net->bound.assign(net->bufs.size(), nullptr);
+    net->bound[agg_buf] = agg;
+    net->bound[short_buf] = short_out;
+    c->cur = c->stream2;
+    int rc = run_ops_locked(net, first_op, n_ops, 1);
+    c->cur = nullptr;
+    if (rc) { (void)hipStreamSynchronize(c->stream2); return rc; }
+    HIP_TRY(c, hipEventRecord(c->ev_join, c->stream2));
+    return HAVC_OK;
+}
+
+int havc_cmn_join_add(havc_ctx* c, float* readout, const float* short_out, int64_t n) {
+    if (!c || !readout || !short_out || n < 1) return fail(c, HAVC_E_INVALID, "cmn_join_add: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    int e = launch_vec_add(readout, short_out, n, c->stream);
+    c->stats.launches++;
+    if (e) return hip_fail(c, (hipError_t)e, "cmn_join_add");
+    return HAVC_OK;
+}
+
+int havc_cmn_value_in(havc_ctx* c, const float* image, const float* planes, float* value_in, int64_t pixels) {
+    if (!c || !image || !planes || !value_in || pixels < 1) return fail(c, HAVC_E_INVALID, "cmn_value_in: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    int e = launch_cmn_value_in(image, planes, value_in, pixels, c->stream);
+    c->stats.launches++;
+    if (e) return hip_fail(c, (hipError_t)e, "cmn_value_in");
+    return HAVC_OK;
+}
+
+int havc_dev_copy_2d(havc_ctx* c, void* d_dst, size_t dst_pitch, const void* d_src, size_t src_pitch, size_t width_bytes, size_t rows) {
+    if (!c || !d_dst || !d_src || width_bytes == 0 || rows == 0 || dst_pitch < width_bytes || src_pitch < width_bytes) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipMemcpy2DAsync(d_dst, dst_pitch, d_src, src_pitch, width_bytes, rows, hipMemcpyDeviceToDevice, c->stream));
+    return HAVC_OK;
+}
+
+int havc_net_bind_many(havc_net* n, int count, const int32_t* bufs, void* const* device_ptrs) {
+    if (!n || count < 0 || (count && (!bufs || !device_ptrs))) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(n->ctx->mu);
+    for (int i = 0; i < count; ++i)
+        if (bufs[i] < 0 || bufs[i] >= (int)n->bufs.size()) return fail(n->ctx, HAVC_E_INVALID, "net_bind_many: buffer id out of range");
+    if (n->bound.empty()) n->bound.assign(n->bufs.size(), nullptr);
+    for (int i = 0; i < count; ++i) n->bound[bufs[i]] = device_ptrs[i];
+    return HAVC_OK;
+}
+
+int havc_net_enqueue_slices(havc_net* n, int count, const int32_t* first_op, const int32_t* n_ops, const int32_t* batch) {
+    if (!n || count < 0 || (count && (!first_op || !n_ops || !batch))) return HAVC_E_INVALID;
+    havc_ctx* c = n->ctx;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    for (int i = 0; i < count; ++i)
+        if (int rc = run_ops_locked(n, first_op[i], n_ops[i], batch[i])) return rc;
+    return HAVC_OK;
 }
 
 int havc_dev_copy(havc_ctx* c, void* d_dst, const void* d_src, size_t nbytes) {

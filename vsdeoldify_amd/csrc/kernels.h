@@ -146,15 +146,23 @@ int launch_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* dst, int d
                          int v_taps, const uint8_t* orig, hipStream_t s);
 
 // ---- ColorMNet memory kernels (colormnet.hip) ----
-int launch_mem_similarity(const float* mk, const float* ms, const float* qk, const float* qe, float* sim, int B, int CK, int N, int HW, hipStream_t s);
+int launch_mem_similarity(const float* mk, const float* ms, const float* qk, const float* qe, float* sim, int B, int CK, int N, int HW, hipStream_t s,
+                          int64_t mpitch = 0);      // mpitch / vpitch: row pitch of mk / mv in elements (0 = N: the reference's contiguous tensors)
 int launch_mem_usage(const int* idx, const float* wgt, unsigned long long* acc, float* usage, int B, int N, int HW, int K, hipStream_t s);
 int launch_mem_dense_readout(const float* sim, const float* mv, float* out, int B, int CV, int N, int P, hipStream_t s);
 int mem_topk_splits(int N);
-int launch_mem_similarity_t(const float* mk, const float* ms, const float* qk, const float* qe, float* simT, int B, int CK, int N, int HW, hipStream_t s);
+int launch_mem_similarity_t(const float* mk, const float* ms, const float* qk, const float* qe, float* simT, int B, int CK, int N, int HW, hipStream_t s,
+                            int64_t mpitch = 0);
 bool mem_topk_select_supported(int N);
-int launch_mem_topk_select_readout(const float* simT, const float* mv, int* idx, float* wgt, float* out, int B, int CV, int N, int HW, int K, hipStream_t s);
+int launch_mem_topk_select_readout(const float* simT, const float* mv, int* idx, float* wgt, float* out, int B, int CV, int N, int HW, int K, hipStream_t s,
+                                   int64_t vpitch = 0);
 int launch_mem_topk_readout(const float* sim, const float* mv, int* idx, float* wgt, float* cand_val, int* cand_idx, float* out, int B, int CV, int N,
-                            int HW, int K, hipStream_t s);
+                            int HW, int K, hipStream_t s, int64_t vpitch = 0);
+int launch_mem_usage_update(const int* idx, const float* wgt, unsigned long long* acc, float* use, float* life, int from, int N, int HW, int K, hipStream_t s);
+int launch_cmn_value_in(const float* img, const float* planes, float* vin, int64_t P, hipStream_t s);
+int launch_vec_add(float* y, const float* x, int64_t n, hipStream_t s);
+int launch_cmn_frame_in(const uint8_t* rgb, float* lab, float* img, int w, int h, int Wp, int Hp, int pad_l, int pad_t, hipStream_t s);
+int launch_cmn_frame_out(const float* l_plane, const float* ab, uint8_t* rgb, int w, int h, int Wp, int Hp, int pad_l, int pad_t, hipStream_t s);
 int launch_local_correlation(const float* q, const float* k, float* out, int n, int C, int H, int W, int R, int dil, float qscale, hipStream_t s);
 int launch_local_softmax(float* qk, const float* q, const float* rel_w, const float* rel_b, int n, int C, int H, int W, int R, int dil, hipStream_t s);
 int launch_local_agg(const float* attn, const float* v, float* agg, int n, int CV, int H, int W, int R, int dil, hipStream_t s);

@@ -308,6 +308,55 @@ int launch_cmn_lab_to_rgb(const float* l_plane, const float* ab, uint8_t* rgb, i
     return (int)hipGetLastError();
 }
 
+// The frame transforms of ColorMNetRender WITH the padding InferenceCore puts around them (pad_divide_by 112, inference_core.py:49,123), so that
+// no tensor op sits between the frame and the network: rgb -> normalised Lab planes [3][h][w] AND the network input, the L plane three times,
+// zero-padded to [3][Hp][Wp] (offset pad_t / pad_l); and back: the L plane + the PADDED ab planes the decoder wrote -> u8 RGB of the frame.
+__global__ void cmn_frame_in_kernel(const uint8_t* __restrict__ rgb, float* __restrict__ lab, float* __restrict__ img, int w, int h, int Wp, int Hp,
+                                    int pad_l, int pad_t) {
+    const int64_t npix = (int64_t)w * h, nimg = (int64_t)Wp * Hp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nimg; i += (int64_t)gridDim.x * blockDim.x) {
+        const int yp = (int)(i / Wp), xp = (int)(i - (int64_t)yp * Wp);
+        const int y = yp - pad_t, x = xp - pad_l;
+        float Ln = 0.f;
+        if ((unsigned)y < (unsigned)h && (unsigned)x < (unsigned)w) {
+            const int64_t p = (int64_t)y * w + x;
+            const double R = srgb_to_linear(rgb[p * 3] / 255.0), G = srgb_to_linear(rgb[p * 3 + 1] / 255.0), B = srgb_to_linear(rgb[p * 3 + 2] / 255.0);
+            const double fx = lab_f((0.412453 * R + 0.357580 * G + 0.180423 * B) / 0.95047);
+            const double fy = lab_f(0.212671 * R + 0.715160 * G + 0.072169 * B);
+            const double fz = lab_f((0.019334 * R + 0.119193 * G + 0.950227 * B) / 1.08883);
+            const float L = (float)(116.0 * fy - 16.0), a = (float)(500.0 * (fx - fy)), b = (float)(200.0 * (fy - fz));
+            Ln = (L - 50.f) / 50.f;
+            lab[p] = Ln;
+            lab[npix + p] = a / 110.f;
+            lab[2 * npix + p] = b / 110.f;
+        }
+        if (img) { img[i] = Ln; img[nimg + i] = Ln; img[2 * nimg + i] = Ln; }
+    }
+}
+int launch_cmn_frame_in(const uint8_t* rgb, float* lab, float* img, int w, int h, int Wp, int Hp, int pad_l, int pad_t, hipStream_t s) {
+    hipLaunchKernelGGL(cmn_frame_in_kernel, dim3(grid_for((int64_t)Wp * Hp)), dim3(256), 0, s, rgb, lab, img, w, h, Wp, Hp, pad_l, pad_t);
+    return (int)hipGetLastError();
+}
+__global__ void cmn_frame_out_kernel(const float* __restrict__ lp, const float* __restrict__ ab, uint8_t* __restrict__ rgb, int w, int h, int Wp, int Hp,
+                                     int pad_l, int pad_t) {
+    const float s50 = (float)(1 / 50.), s110 = (float)(1 / 110.);
+    const int64_t npix = (int64_t)w * h, nimg = (int64_t)Wp * Hp;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / w), x = (int)(i - (int64_t)y * w);
+        const int64_t q = (int64_t)(y + pad_t) * Wp + x + pad_l;
+        const float L = (lp[i] - (-1.f)) / s50, a = ab[q] / s110, b = ab[nimg + q] / s110;
+        double r, g, bl;
+        lab_to_rgb01((double)L, (double)a, (double)b, r, g, bl);
+        rgb[i * 3] = (uint8_t)(r * 255.0);
+        rgb[i * 3 + 1] = (uint8_t)(g * 255.0);
+        rgb[i * 3 + 2] = (uint8_t)(bl * 255.0);
+    }
+}
+int launch_cmn_frame_out(const float* l_plane, const float* ab, uint8_t* rgb, int w, int h, int Wp, int Hp, int pad_l, int pad_t, hipStream_t s) {
+    hipLaunchKernelGGL(cmn_frame_out_kernel, dim3(grid_for((int64_t)w * h)), dim3(256), 0, s, l_plane, ab, rgb, w, h, Wp, Hp, pad_l, pad_t);
+    return (int)hipGetLastError();
+}
+
 // Eager module load (havc_create, under the library's set-up mutex): the HIP runtime loads a translation unit's code object on the first use
 // of one of its kernels; querying one here moves that -- and the big-LDS opt-ins below -- out of the first launch, which may come from
 // several host threads at once ("set-up is serialised").

@@ -20,6 +20,31 @@ def conv_out(n, k, s, p, d=1):
     return (n + 2 * p - d * (k - 1) - 1) // s + 1
 
 
+def splitk_count(rows, Npad, Kc):
+    """split-K count of a conv with `rows` GEMM rows: one frame of a generator leaves the encoder / bottleneck convs at 5 - 40 output tiles
+    for 256 CUs with 4 - 72 K-64 stages in series; cutting K puts up to ~256 blocks in flight (every part keeps >= 2 stages)"""
+    stages = Kc // 8
+    tiles = ((rows + 127) // 128) * ((Npad + 127) // 128)
+    if tiles >= 128 or stages < 4:
+        return 0
+    n = min(15, 256 // tiles, stages // 2)
+    return n if n >= 2 else 0
+
+
+class _SplitBuilder(PlanBuilder):
+    """PlanBuilder of the low-latency plans: adds the split-K count of the shape to plain convs"""
+
+    def __init__(self, frames):
+        super().__init__()
+        self.frames = frames
+
+    def conv(self, name, pc, x, y, stride=1, pad=0, dil=1, flags=0, **kw):
+        if not (flags & (nat.F_W_FROM_BUF | nat.F_PS_BLUR | nat.F_FUSE_PROJ | nat.F_FUSE_RGB8 | nat.F_OUT_RGB8)) and pc.Npad % 256 != 16:
+            Ho, Wo = conv_out(x.H, pc.kh, stride, pad, dil), conv_out(x.W, pc.kw, stride, pad, dil)
+            flags |= nat.F_SPLITK(splitk_count(Ho * Wo * self.frames, pc.Npad, pc.Kc))
+        return super().conv(name, pc, x, y, stride=stride, pad=pad, dil=dil, flags=flags, **kw)
+
+
 class DeoldifyGenerator:
     """Packs a reference state dict once; emits a plan per render size S = render_factor * 16."""
 
@@ -149,11 +174,15 @@ class DeoldifyGenerator:
         return y
 
     # ---- plan ---------------------------------------------------------------------------------
-    def plan(self, S):
+    def plan(self, S, split_for_frames=0):
+        """split_for_frames = n > 0: a LOW-LATENCY plan for nets that run n frames per launch (the reference's per-frame call shape, n = 1): convs
+        that give the 256 CUs fewer than 128 output tiles get a split-K count (HAVC_F_SPLITK: a block per (tile, K part), fp32 partial sums
+        added in a fixed order).  Results differ from the unsplit plan in fp32 summation order only; the default plan (0) keeps the
+        batch-independent bytes."""
         assert S % 16 == 0 and S >= 32, "render size must be render_factor*16"
         sd, deep = self.sd, self.arch == "deep"
         kind, nblk = RESNET[self.arch]
-        b = PlanBuilder(precise=self.precise)
+        b = _SplitBuilder(split_for_frames) if (split_for_frames and not self.precise) else PlanBuilder(precise=self.precise)
         pm = b.pm
         in_buf, out_buf = b.buf(S * S * 3, 1), b.buf(S * S * 3, 1)
 

@@ -71,10 +71,12 @@ class GeneratorRuntime:
             self._owns_weights = True
         self.nets = {}
 
-    def net(self, S, max_batch=1):
-        key = (S, max_batch)
+    def net(self, S, max_batch=1, low_latency=False):
+        """low_latency: the split-K plan for nets that run max_batch (<= 2) frames per launch (DeoldifyGenerator.plan)"""
+        low_latency = bool(low_latency) and max_batch <= 2 and not self.gen.precise
+        key = (S, max_batch, True) if low_latency else (S, max_batch)
         if key not in self.nets:
-            ops, bufs, i, o, names = self.gen.plan(S)
+            ops, bufs, i, o, names = self.gen.plan(S, split_for_frames=max_batch) if low_latency else self.gen.plan(S)
             n = nat.Net(self.ctx, self.weights, ops, bufs, i, o, S, max_batch)
             n.names = names
             if os.environ.get("HAVC_AUTOTUNE", "1") != "0":
@@ -97,10 +99,13 @@ class ModelImageRender:
     """Drop-in for vsdeoldify.deoldify.visualize.ModelImageRender."""
 
     def __init__(self, package_dir=None, modelname="video", render_factor=24, video_weight=0, device_index=0,
-                 state_dicts=None, max_batch=1, worker=0, coalesce=0, precision=None):
+                 state_dicts=None, max_batch=1, worker=0, coalesce=0, precision=None, low_latency=None):
         """`precision`: "fast" (default: fp16 activations and MFMA operands, fp32 accumulation: CIEDE2000 against the reference's fp32 path small
         in the mean but p99 1.2 - 2.3 on the final image) or "precise" (fp32-class arithmetic like the reference,
         deoldify/filters.py:45-68: hi / lo fp16 pairs on the same MFMA kernels, 3x the matrix work); None reads HAVC_PRECISION.
+        `low_latency` (None reads HAVC_LOW_LATENCY, default off): a render that colours ONE frame per call (max_batch 1, the reference's call
+        shape) builds its nets with split-K convs -- a single frame gives most layers 5 - 40 tiles for 256 CUs; bytes differ from the batched
+        nets in fp32 summation order only.
         `worker`: index of the per-thread context on this GPU (get_context): renders built with different worker indices run
         concurrently from different threads and share the packed weights.
         `coalesce` = N > 0: ONE render shared by N caller threads (the reference's per-frame call shape under VapourSynth's thread pool):
@@ -114,6 +119,7 @@ class ModelImageRender:
         self._worker = worker
         self._coalesce = coalesce
         self._batchers = {}
+        self._low_latency = (os.environ.get("HAVC_LOW_LATENCY", "0") != "0") if low_latency is None else bool(low_latency)
         self._precision = precision or os.environ.get("HAVC_PRECISION", "fast")
         if self._precision not in ("fast", "precise"):
             raise ValueError(f"precision must be 'fast' or 'precise', not {self._precision!r}")
@@ -157,8 +163,8 @@ class ModelImageRender:
             frames = np.ascontiguousarray(frames, dtype=np.uint8)
         n, S = frames.shape[0], frames.shape[1]
         assert tuple(frames.shape[1:]) == (S, S, 3) and S == self._render_factor * RENDER_BASE
-        v = self._video.net(S, self._max_batch)
-        s = self._second.net(S, self._max_batch) if self._second else None
+        v = self._video.net(S, self._max_batch, self._low_latency)
+        s = self._second.net(S, self._max_batch, self._low_latency) if self._second else None
         out = DeviceImage(self.ctx, frames.shape) if dev else np.empty_like(frames)
         nat.check(self.ctx.lib.havc_deoldify_frames(self.ctx.h, v.h, s.h if s else None, float(self._video_weight),
                                                     1 if post_process else 0, operand_ptr(frames), operand_ptr(out), n),
@@ -179,8 +185,8 @@ class ModelImageRender:
         po = [np.asarray(p) for p in planes_out]
         if any(p.shape != (S, S) or p.dtype != np.uint8 or p.strides[1] != 1 or not p.flags.writeable for p in po) or len({p.strides[0] for p in po}) != 1:
             raise ValueError("output planes must be three writable uint8 [S, S] arrays with one common row stride")
-        v = self._video.net(S, self._max_batch)
-        s = self._second.net(S, self._max_batch) if self._second else None
+        v = self._video.net(S, self._max_batch, self._low_latency)
+        s = self._second.net(S, self._max_batch, self._low_latency) if self._second else None
         pin = (C.c_void_p * 3)(*[p.ctypes.data for p in pl])
         pout = (C.c_void_p * 3)(*[p.ctypes.data for p in po])
         nat.check(self.ctx.lib.havc_deoldify_frame_planar(self.ctx.h, v.h, s.h if s else None, float(self._video_weight), 1 if post_process else 0,
@@ -225,8 +231,8 @@ class ModelImageRender:
             with _batcher_lock:
                 b = self._batchers.get(key)
                 if b is None:
-                    v = self._video.net(S, self._max_batch)
-                    s = self._second.net(S, self._max_batch) if self._second else None
+                    v = self._video.net(S, self._max_batch, self._low_latency)
+                    s = self._second.net(S, self._max_batch, self._low_latency) if self._second else None
                     b = self._batchers[key] = nat.Batcher(self.ctx, v, s, self._video_weight, post_process, callers=self._coalesce,
                                                           wait_us=int(os.environ.get("HAVC_COALESCE_WAIT_US", "300")))
         return b
@@ -239,7 +245,7 @@ class ModelImageRender:
                 outs.append(None)
                 continue
             try:
-                n = rt.net(S, self._max_batch)
+                n = rt.net(S, self._max_batch, self._low_latency)
                 o = np.empty_like(sq[None])
                 nat.check(self.ctx.lib.havc_deoldify_frames(self.ctx.h, n.h, None, 0.0, 0, nat.as_ptr(np.ascontiguousarray(sq[None])),
                                                             nat.as_ptr(o), 1), self.ctx.h)
