@@ -84,8 +84,18 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
     if (SK > 1) pid /= SK;
     const int m0 = (ABL == 9 ? (pid / NT) % 64 : pid / NT) * BM;      // ABL 9: L2-resident source, DMA ceiling
     const int n0 = (pid % NT) * BN;
-    const bool has_extra = EXTRA && (n0 + BN + 16 == p.Npad);
+    // EXTRA: Npad == 256 + 16 exactly (launch_pipe checks): ONE column tile, which has the extra fragment -- a compile-time fact, so the main loop
+    // carries no test for it
+    constexpr bool has_extra = EXTRA != 0;
     const int HoWo = p.Ho * p.Wo;
+    // EXTRA: the 8 pixel fragments x 1 extra column fragment are shared by the four N-waves of a pixel slab, two pixel fragments each.  Round 4:
+    // wave wn walks the pixel fragments ROTATED by 2 wn (accumulator index mi <-> pixel fragment PF(mi) = (mi + 2 wn) & 7), so that its two
+    // extra MFMAs sit at the static steps mi = 0, 1 of each K half for EVERY wave: the main loop has no wave-dependent branch any more (it had
+    // 16 `if (wn == mi >> 1)` scalar branches per stage around single MFMAs: ~5 % of the kernel).  The rotation is a scalar offset folded into the
+    // fragment address the stage toggle already adds; the epilogue maps mi back with PF().
+    const int rot = EXTRA ? wn * 2 * 2048 : 0;
+    auto aoff = [&](int mi) -> int { return EXTRA ? ((mi * 2048 + rot) & (FM * 2048 - 1)) : mi * 2048; };
+#define PF(mi) (EXTRA ? (((mi) + 2 * wn) & (FM - 1)) : (mi))
 
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.x), 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.w), 0, p.w_bytes, 0x00020000);
@@ -184,8 +194,8 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
 #pragma unroll
     for (int ni = 0; ni < FN; ++ni) bf[0][ni] = *reinterpret_cast<const half8*>(smem + b_l0 + ni * 2048);
     if (EXTRA) xb[0] = *reinterpret_cast<const half8*>(smem + x_l0);
-    af[0] = *reinterpret_cast<const half8*>(smem + a_l0);
-    af[1] = *reinterpret_cast<const half8*>(smem + a_l0 + 2048);
+    af[0] = *reinterpret_cast<const half8*>(smem + a_l0 + aoff(0));
+    af[1] = *reinterpret_cast<const half8*>(smem + a_l0 + aoff(1));
 
     // One 64-deep stage (NS steps of FN MFMAs).  LVL (compile time): 2 = stages kt+1 and kt+2 exist, 1 = only kt+1,
     // 0 = last stage.  Two LDS buffers; the single barrier of a stage sits at step NS-3, right after the LAST fragment
@@ -206,7 +216,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
             if (s == 0 && LVL == 2) e_n2 = kt_lane[(kt + 2) * 8];             // K table entry of stage kt+2
             {                                          // (1) pixel fragment two steps ahead (next stage's at the end)
                 const int s2 = s + 2;
-                if (s2 < NS && RD) af[s2 % 4] = *reinterpret_cast<const half8*>(cur + ((s2 / FM) ? a_l1 : a_l0) + (s2 % FM) * 2048);
+                if (s2 < NS && RD) af[s2 % 4] = *reinterpret_cast<const half8*>(cur + ((s2 / FM) ? a_l1 : a_l0) + aoff(s2 % FM));
             }
             if (s == NS - 3 && LVL >= 1) {             // (B) the barrier of this stage
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -217,7 +227,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
             }
             if (s >= NS - 2 && LVL >= 1) {             // first fragments of stage kt+1
                 const int j = s - (NS - 2);
-                af[(s + 2) % 4] = *reinterpret_cast<const half8*>(nxt + a_l0 + j * 2048);
+                af[(s + 2) % 4] = *reinterpret_cast<const half8*>(nxt + a_l0 + aoff(j));
 #pragma unroll
                 for (int ni = 2 * j; ni < 2 * j + 2; ++ni) bf[0][ni] = *reinterpret_cast<const half8*>(nxt + b_l0 + ni * 2048);
                 if (EXTRA && j == 1) xb[0] = *reinterpret_cast<const half8*>(nxt + x_l0);
@@ -241,9 +251,8 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
                 if (ABL == 4 || ABL == 9) asm volatile("" ::"v"(bf[ks][ni]), "v"(a));
                 else acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][ni], a, acc[ni][mi], 0, 0, 0);
             }
-            if (EXTRA && has_extra) {                  // extra column fragment x pixel fragment mi: N-wave mi >> 1
-                if (wn == (mi >> 1)) accx[mi & 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], a, accx[mi & 1], 0, 0, 0);
-            }
+            if (EXTRA && mi < 2)                       // extra column fragment x this wave's pixel fragments PF(0), PF(1) = 2 wn, 2 wn + 1: static steps
+                accx[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], a, accx[mi], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
         e_nx = e_n2;
@@ -274,6 +283,7 @@ __global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p
         return;
     }
 #include "conv_pipe_epilogue.inc"
+#undef PF
 }
 
 // =====================================================================================================================
@@ -496,7 +506,9 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs p) {
         const int y = ty * 16 + (local_row >> 4), x = tx * 16 + (local_row & 15);
         return (y < p.Ho && x < p.Wo) ? (tb * p.Ho + y) * p.Wo + x : 0x7fffffff;
     };
+#define PF(mi) (mi)
 #include "conv_pipe_epilogue.inc"
+#undef PF
 }
 
 // Opt a kernel in to > 64 KiB of dynamic LDS.  The attribute is per DEVICE (a process may hold contexts on several GPUs:
@@ -549,7 +561,7 @@ __global__ void splitk_reduce_kernel(const ConvArgs p) {
 template <int WM, int WN, int FM, int EXTRA, int ABL = 0>
 static int launch_pipe(const ConvArgs& a, hipStream_t s) {
     using G = Geo<WM, WN, FM, EXTRA>;
-    if ((a.Kc & 7) || !a.ktab || a.x_bytes == 0 || a.x_bytes >= OOB || a.w_bytes >= OOB) return (int)hipErrorInvalidValue;
+    if ((a.Kc & 7) || !a.ktab || a.x_bytes == 0 || a.x_bytes >= OOB || a.w_bytes >= OOB || (EXTRA && a.Npad != G::BN + 16)) return (int)hipErrorInvalidValue;
     const int MT = (a.M + G::BM - 1) / G::BM, NT = (a.Npad - 16 * EXTRA + G::BN - 1) / G::BN;
     const int SK = a.splitk > 1 ? a.splitk : 1;
     if (SK > 1 && (EXTRA || ABL || !a.ws || (a.Kc >> 3) < 2 * SK || (a.Npad & 3) ||
@@ -588,7 +600,7 @@ bool conv_splitk_cfg_ok(int cfg) {
 }
 
 bool conv_pipe_supported(const ConvArgs& a, int extra) {
-    return !(a.Kc & 7) && a.ktab && a.x_bytes != 0 && a.x_bytes < OOB && a.w_bytes < OOB && (!extra || (a.Npad - 16) % 256 == 0);
+    return !(a.Kc & 7) && a.ktab && a.x_bytes != 0 && a.x_bytes < OOB && a.w_bytes < OOB && (!extra || a.Npad == 272);
 }
 
 int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
