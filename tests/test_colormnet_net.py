@@ -599,3 +599,60 @@ def test_gpu_colorize_batch_frames_with_lookahead_matches_the_reference_render_c
     plain = run_render_scenario(name, gpu_network())
     d = np.abs(got.astype(np.int32) - plain.astype(np.int32))
     assert (d <= 2).mean() > 0.999, (int(d.max()), float((d <= 2).mean()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", list(SCENARIOS))
+def test_gpu_fast_step_equals_the_line_by_line_classes(name):
+    """colormnet_fast.py (banked memory, padded frames, forked short-term attention, preallocated results) against colormnet_core /
+    colormnet_memory (the reference's tensor bookkeeping line by line) on the four recorded scenarios: the same kernels on the same numbers in
+    the same order -- identical frames."""
+    net = gpu_network()
+    assert net.fast
+    fast = run_render_scenario(name, net)
+    net.fast = False
+    try:
+        plain = run_render_scenario(name, net)
+    finally:
+        net.fast = True
+    d = np.abs(fast.astype(np.int32) - plain.astype(np.int32))
+    assert d.max() == 0, (name, int(d.max()), float((d > 0).mean()))
+
+
+@pytest.mark.gpu
+def test_gpu_fast_step_long_clip_with_consolidation_and_lookahead():
+    """60 frames with mem_every = 2 and a small working memory: several consolidations into long-term prototypes, usage counters, the removal of
+    obsolete long-term elements -- through both implementations, frame by frame and with the key look-ahead; DeviceImage in / out."""
+    from vsdeoldify_amd.colormnet_render import ColorMNetRender
+    from vsdeoldify_amd.device import DeviceImage
+    net = gpu_network()
+    r = np.random.default_rng(4)
+    base = REN["frames"][0].astype(np.float32)
+    frames = [np.stack([np.clip(base + 6 * np.sin(t / 3.0) + r.normal(0, 2, base.shape), 0, 255).astype(np.uint8)] * 3, -1) for t in range(60)]
+    ref = REN["refs"][0]
+
+    def run(fast, lookahead):
+        net.fast = fast
+        try:
+            rnd = ColorMNetRender(image_size=-1, vid_length=len(frames), encode_mode=1, max_memory_frames=500, reset_on_ref_update=False, network=net,
+                                  lookahead=lookahead)
+            rnd.set_config("mem_every", 2)
+            rnd.set_config("max_mid_term_frames", 4)
+            rnd.set_config("min_mid_term_frames", 2)
+            rnd.set_config("num_prototypes", 16)
+            rnd.set_config("max_long_term_elements", 60)
+            rnd.set_config("enable_long_term_count_usage", True)
+            dev = [DeviceImage.from_numpy(net.ctx, f) for f in frames]
+            refs = [DeviceImage.from_numpy(net.ctx, ref) if t == 0 else None for t in range(len(frames))]
+            outs = rnd.colorize_batch_frames(dev, refs, False)
+            mem = rnd.processor.memory
+            return np.stack([o.numpy() for o in outs]), (mem.work_mem.size, mem.long_mem.size)
+        finally:
+            net.fast = True
+    a, sa = run(True, 1)
+    b, sb = run(False, 1)
+    assert sa == sb and sa[1] > 0, (sa, sb)                                   # the long-term memory was engaged, both ended with the same sizes
+    assert np.array_equal(a, b), (int(np.abs(a.astype(int) - b.astype(int)).max()), float((a != b).mean()))
+    c, sc = run(True, 8)                                                      # + key look-ahead (split-K counts of the batched pass: fp32 summation order)
+    d = np.abs(a.astype(int) - c.astype(int))
+    assert sc == sa and (d <= 2).mean() > 0.999, (sc, int(d.max()), float((d <= 2).mean()))

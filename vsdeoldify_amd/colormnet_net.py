@@ -472,6 +472,27 @@ class _Feat:
         self.g16, self.g8, self.g4, self.shape, self.skip8, self.skip4 = g16, g8, g4, shape, skip8, skip4
 
 
+class _FastBuffers:
+    """the per-frame results of one padded frame size, allocated once (colormnet_fast.py)"""
+
+    def __init__(self, network, H, W):
+        import torch
+        self.net = network._net(H, W)
+        self.H, self.W, self.h, self.w = H, W, H // 16, W // 16
+        hw, CV, HD, CK = self.h * self.w, network.value_dim, network.hidden_dim, network.key_dim
+        ws2 = (2 * MAX_DIS + 1) ** 2
+        with network.on_stream():
+            new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=network.device)
+            self.readout, self.short, self.agg, self.attn = new(2 * CV, hw), new(2 * CV, hw), new(hw, 2 * CV), new(ws2, hw)
+            self.prob, self.value_in, self.value = new(2, H, W), new(2, 5, H, W), new(2, CV, hw)
+            self.hidden = [new(1, 2, HD, self.h, self.w), new(1, 2, HD, self.h, self.w)]
+            self.last_key, self.last_value = new(1, CK, self.h, self.w), new(1, 2, CV, self.h, self.w)
+
+    def other_hidden(self, current):
+        """a hidden-state buffer that is not the one being read"""
+        return self.hidden[1] if (current is not None and current.data_ptr() == self.hidden[0].data_ptr()) else self.hidden[0]
+
+
 class _OnStream:
     """run a block on the library's stream; a caller that works on another torch stream is ordered before and after through events (no host sync)"""
 
@@ -523,6 +544,8 @@ class ColorMNetNetwork:
         self._armed, self._helper, self.worker = None, None, worker
         self.async_lookahead = os.environ.get("HAVC_CMN_ASYNC_LOOKAHEAD", "1") != "0"      # look-ahead pass on its own stream (0: on this network's stream)
         self.autotune = (os.environ.get("HAVC_AUTOTUNE", "1") != "0") if autotune is None else autotune
+        self.fast = os.environ.get("HAVC_CMN_FAST", "1") != "0"                           # colormnet_fast.py: the frame loop on pre-sized buffers
+        self._fastbufs = {}
         sd = self.plan.sd
         ws2 = (2 * MAX_DIS + 1) ** 2
         with self.on_stream():
@@ -592,7 +615,7 @@ class ColorMNetNetwork:
         The pass is only ENQUEUED here, on the helper context's stream, behind everything this network's stream holds so far; an event marks
         its end and the consumer (encode_key) makes this network's stream wait for it."""
         import torch
-        if not frames:
+        if frames is None or len(frames) == 0:
             return []
         B = len(frames)
         H, W = frames[0].shape[-2:]
@@ -603,7 +626,10 @@ class ColorMNetNetwork:
             if hn is not self and not _ordered:
                 hn.stream.wait_stream(self.stream)                    # whatever this stream still owes the frames first
             with torch.cuda.stream(hn.stream):
-                img = torch.stack([f.to(self.device, torch.float32) for f in frames], 0).contiguous()
+                if isinstance(frames, torch.Tensor):                  # a batch the caller assembled in place (prefetch_frames: havc_cmn_frame_in per slot)
+                    img = frames
+                else:
+                    img = torch.stack([f.to(self.device, torch.float32) for f in frames], 0).contiguous()
                 key, sel, shr = self._new(B, self.key_dim, h, w), self._new(B, self.key_dim, h, w), self._new(B, 1, h, w)
                 big, epf = {}, {}
                 feats = ("g16", "g8", "g4", "skip8", "skip4")
@@ -623,7 +649,7 @@ class ColorMNetNetwork:
             entries = []
             for i in range(B):
                 v = [big[n_][i * epf[n_]:(i + 1) * epf[n_] + 128] for n_ in feats]
-                entries.append((key[i:i + 1], shr[i:i + 1], sel[i:i + 1], _Feat(v[0], v[1], v[2], (H, W), v[3], v[4]), done, img))
+                entries.append((key[i:i + 1], shr[i:i + 1], sel[i:i + 1], _Feat(v[0], v[1], v[2], (H, W), v[3], v[4]), done, img[i]))
         return entries
 
     def lookahead_context(self):
@@ -641,6 +667,33 @@ class ColorMNetNetwork:
         from .colormnet_core import DIVIDE_BY, pad_divide_by
         from .device import is_device
         hn = self._helper_net() if self.async_lookahead else self
+        if self.fast:
+            # no tensor ops: every frame's Lab planes and its padded network input are written by ONE kernel straight into their batch slots
+            from .colormnet_fast import frame_pads
+            shape0 = tuple(frames[0].shape)
+            pad, Hp, Wp = frame_pads(shape0[0], shape0[1])
+            with self.on_stream():
+                if hn is not self:
+                    hn.stream.wait_stream(self.stream)
+                with torch.cuda.stream(hn.stream):
+                    B = len(frames)
+                    labs = torch.empty((B, 3, shape0[0], shape0[1]), dtype=torch.float32, device=self.device)
+                    img = torch.empty((B, 3, Hp, Wp), dtype=torch.float32, device=self.device)
+                    keep = []
+                    for i, f in enumerate(frames):
+                        if is_device(f):
+                            ptr = f.ptr
+                        else:
+                            a = np.ascontiguousarray(f, dtype=np.uint8)
+                            keep.append(a)
+                            ptr = nat.as_ptr(a)
+                        nat.check(hn.ctx.lib.havc_cmn_frame_in(hn.ctx.h, ptr, C.c_void_p(labs[i].data_ptr()), C.c_void_p(img[i].data_ptr()), shape0[1], shape0[0],
+                                                               Wp, Hp, pad[0], pad[2]), hn.ctx.h)
+                    if hn is not self:
+                        labs.record_stream(self.stream)
+                        img.record_stream(self.stream)
+                entries = self.prefetch_keys(img, max_batch=max_batch, _ordered=True)
+            return [labs[i] for i in range(len(frames))], entries
         with self.on_stream():
             if hn is not self:
                 hn.stream.wait_stream(self.stream)                    # frames the caller produced on this stream
@@ -769,6 +822,96 @@ class ColorMNetNetwork:
             self._keep = (agg,)
         return out.permute(2, 0, 1), attn
 
+    # ---- fast step (colormnet_fast.py): preallocated results, multi-bind / multi-slice calls, no tensor ops between the kernels ----
+    def fast_buffers(self, H, W):
+        key = (H, W)
+        if key not in self._fastbufs:
+            self._fastbufs[key] = _FastBuffers(self, H, W)
+        return self._fastbufs[key]
+
+    def _bind_run(self, net, binds, slices):
+        import ctypes as C
+        n = len(binds)
+        ids = (C.c_int32 * n)(*[net.io[k] for k, _ in binds])
+        ptrs = (C.c_void_p * n)(*[(t.data_ptr() if t is not None else None) for _, t in binds])
+        nat.check(self.ctx.lib.havc_net_bind_many(net.h, n, ids, ptrs), self.ctx.h)
+        m = len(slices)
+        sl = [net.slices[name] for name in slices]
+        nat.check(self.ctx.lib.havc_net_enqueue_slices(net.h, m, (C.c_int32 * m)(*[v[0] for v in sl]), (C.c_int32 * m)(*[v[1] for v in sl]),
+                                                       (C.c_int32 * m)(*[v[2] for v in sl])), self.ctx.h)
+
+    def short_term_fork(self, B, key, last_key, last_value):
+        """LocalGatedPropagation + the `short` slice on the context's second stream (attention.py:783-860); short_term_join adds the result to the readout"""
+        import ctypes as C
+        net = B.net
+        first, count, _ = net.slices["short"]
+        p = lambda t: C.c_void_p(t.data_ptr())
+        nat.check(self.ctx.lib.havc_cmn_short_term(self.ctx.h, net.h, first, count, net.io["agg"], net.io["short"], p(key), p(last_key), p(last_value),
+                                                   p(self.rel_w), p(self.rel_b), p(B.agg), p(B.attn), p(B.short), self.key_dim, 2 * self.value_dim, B.h, B.w,
+                                                   MAX_DIS), self.ctx.h)
+
+    def short_term_join(self, B):
+        import ctypes as C
+        nat.check(self.ctx.lib.havc_cmn_join_add(self.ctx.h, C.c_void_p(B.readout.data_ptr()), C.c_void_p(B.short.data_ptr()), B.readout.numel()), self.ctx.h)
+
+    def segment_fast(self, B, f, hidden_in, hidden_out):
+        """Decoder (+ HiddenUpdater when hidden_out is given) on B.readout -> B.prob (network.py:137-145)"""
+        binds = [("g16", f.g16), ("g8", f.g8), ("g4", f.g4), ("readout", B.readout), ("hidden", hidden_in), ("prob", B.prob),
+                 ("skip8", f.skip8), ("skip4", f.skip4)]
+        slices = ([] if f.skip8 is not None else ["skip"]) + ["segment"]
+        if hidden_out is not None:
+            binds.append(("hidden_out", hidden_out))
+            slices.append("segment_hidden")
+        self._bind_run(B.net, binds, slices)
+
+    def encode_value_fast(self, B, image, f16, planes, hidden_in, hidden_out):
+        """ValueEncoder (+ HiddenReinforcer when hidden_out is given) -> B.value (network.py:87-101); image [3, H, W] padded, planes [2, H, W]"""
+        import ctypes as C
+        nat.check(self.ctx.lib.havc_cmn_value_in(self.ctx.h, C.c_void_p(image.data_ptr()), C.c_void_p(planes.data_ptr()), C.c_void_p(B.value_in.data_ptr()),
+                                                 B.H * B.W), self.ctx.h)
+        binds = [("value_in", B.value_in), ("value", B.value), ("g16", f16.g16)]
+        slices = ["value"]
+        if hidden_out is not None:
+            binds += [("hidden", hidden_in), ("hidden_out", hidden_out)]
+            slices.append("value_hidden")
+        self._bind_run(B.net, binds, slices)
+
+    def keep_last(self, B, key):
+        import ctypes as C
+        for dst, src in ((B.last_key, key), (B.last_value, B.value)):
+            nat.check(self.ctx.lib.havc_dev_copy(self.ctx.h, C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), src.numel() * 4), self.ctx.h)
+
+    def frame_in(self, rgb_u8):
+        """u8 [h, w, 3] (host array or DeviceImage) -> (Lab planes [3, h, w], the padded network input [3, H, W], pads): ONE kernel"""
+        import ctypes as C
+        from .colormnet_fast import frame_pads
+        from .device import is_device
+        if is_device(rgb_u8):
+            shape, ptr, keep = rgb_u8.shape, rgb_u8.ptr, rgb_u8
+        else:
+            keep = np.ascontiguousarray(rgb_u8, dtype=np.uint8)
+            shape, ptr = keep.shape, nat.as_ptr(keep)
+        if len(shape) != 3 or shape[2] != 3:
+            raise ValueError("RGB image expected")
+        pad, Hp, Wp = frame_pads(shape[0], shape[1])
+        with self.on_stream():
+            lab, img = self._new(3, shape[0], shape[1]), self._new(3, Hp, Wp)
+            nat.check(self.ctx.lib.havc_cmn_frame_in(self.ctx.h, ptr, C.c_void_p(lab.data_ptr()), C.c_void_p(img.data_ptr()), shape[1], shape[0], Wp, Hp,
+                                                     pad[0], pad[2]), self.ctx.h)
+        return lab, img, pad
+
+    def frame_out(self, lab, prob_padded, pad, out=None):
+        """L plane of `lab` + the padded ab planes -> u8 [h, w, 3]: a host array (blocks) or `out` (a DeviceImage: only enqueued)"""
+        import ctypes as C
+        h, w = lab.shape[-2:]
+        Hp, Wp = prob_padded.shape[-2:]
+        host = out is None
+        if host:
+            out = np.empty((h, w, 3), np.uint8)
+        nat.check(self.ctx.lib.havc_cmn_frame_out(self.ctx.h, C.c_void_p(lab.data_ptr()), C.c_void_p(prob_padded.data_ptr()), nat.as_ptr(out) if host else out.ptr,
+                                                  w, h, Wp, Hp, pad[0], pad[2]), self.ctx.h)
+        return out
+
     # ---- ColorMNetRender's frame transforms (colormnet_render.py:285-301, 276-279) ----
     def image_to_lab(self, rgb_u8):
         """u8 [H, W, 3] (host array / PIL image, or a device.DeviceImage) -> normalised Lab [3, H, W] fp32 on the device"""
@@ -802,6 +945,7 @@ class ColorMNetNetwork:
         return out
 
     def close(self):
+        self._fastbufs.clear()
         if self._helper is not None:
             self._helper.close()
             self._helper = None

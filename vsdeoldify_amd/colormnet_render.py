@@ -90,7 +90,16 @@ class ColorMNetRender:
         self.network = network if network is not None else _load_network(self.project_dir, state_dict, device_index)
         self.config = default_config(vid_length, self.max_memory_frames, propagate)
         self.config.update(key_dim=self.network.key_dim, value_dim=self.network.value_dim, hidden_dim=self.network.hidden_dim)
-        self.processor = InferenceCore(self.network, self.config, device_index=device_index, memory_backend=memory_backend)
+        # the frame loop on pre-sized device buffers (colormnet_fast.py) whenever the network is the HIP one; the line-by-line classes
+        # (colormnet_core / colormnet_memory) otherwise: CPU tests of the state machine (memory_backend), HAVC_CMN_FAST=0
+        self._fast = memory_backend is None and getattr(self.network, "fast", False) and hasattr(self.network, "fast_buffers")
+        self.processor = self._new_processor()
+
+    def _new_processor(self):
+        if self._fast:
+            from .colormnet_fast import FastInferenceCore
+            return FastInferenceCore(self.network, self.config, device_index=self.device_index)
+        return InferenceCore(self.network, self.config, device_index=self.device_index, memory_backend=self._memory_backend)
 
     # ---- colormnet_render.py:162-193 ----
     def set_config(self, param_name=None, param_value=None):
@@ -154,11 +163,13 @@ class ColorMNetRender:
         if reset_1 or reset_2:
             self.frame_count = 0
             self.config["FirstFrameIsNotExemplar"] = True              # the reference image is the previous coloured frame
-            self.processor = InferenceCore(self.network, self.config, device_index=self.device_index, memory_backend=self._memory_backend)
+            self.processor = self._new_processor()
             ref = self.ref_img_valid
         else:
             ref = self.ref_img
             self.frame_count += 1
+        if self._fast:
+            return self._colorize_frame_fast(frame_i, ref)
         as_lab = lambda im: self.network.image_to_lab(im if is_device(im) else np.asarray(im))
         ahead = None                                                    # this frame went through prefetch(): its Lab planes and its key are waiting
         if self._ahead and self._ahead[0][0] is frame_i:
@@ -195,6 +206,51 @@ class ColorMNetRender:
         else:
             out = Image.fromarray(self.network.lab_to_image(lab[:1], prob))
         self.img = self.ref_img_valid = out                             # save_last_image (:303-305)
+        return out
+
+
+    def _colorize_frame_fast(self, frame_i, ref):
+        """the frame body above on the fast step (colormnet_fast.py): the frame is padded where it is converted to Lab, the step returns the padded
+        ab planes, the unpad is folded into the Lab -> RGB kernel: no tensor op between the kernels of a steady-state frame"""
+        from PIL import Image
+        from .device import DeviceImage, is_device
+        net = self.network
+        ahead = None
+        if self._ahead and self._ahead[0][0] is frame_i:
+            ahead = self._ahead.popleft()
+        elif self._ahead:
+            self._ahead.clear()
+        if ahead:
+            net.wait_prefetched(ahead[2])
+            lab, img = ahead[1], ahead[2][5]
+            from .colormnet_fast import frame_pads
+            pad = frame_pads(lab.shape[-2], lab.shape[-1])[0]
+        else:
+            lab, img, pad = net.frame_in(frame_i if is_device(frame_i) else np.asarray(frame_i))
+        ref_img = msk_ab = None
+        if ref is not None:
+            ref_lab, ref_img, _ = net.frame_in(ref if is_device(ref) else np.asarray(ref))
+            msk_ab = ref_lab[1:3]
+        if not self.first_mask_loaded:
+            if msk_ab is None:
+                return frame_i
+            self.first_mask_loaded = True
+        labels = None
+        if msk_ab is not None:
+            self.processor.set_all_labels(list(range(1, 3)))
+            labels = range(1, 3)
+        is_last = self.vid_length == self.total_colored_frames - 1
+        if ahead:
+            net.expect_prefetched(ahead[2])
+        if self.config["FirstFrameIsNotExemplar"]:
+            prob = self.processor.step_AnyExemplar_padded(img, pad, ref_img, msk_ab, labels, end=is_last)
+        else:
+            prob = self.processor.step_padded(img, pad, msk_ab, labels, end=is_last)
+        if is_device(frame_i):
+            out = net.frame_out(lab, prob, pad, out=DeviceImage(getattr(net, "ctx", frame_i.ctx), frame_i.shape))
+        else:
+            out = Image.fromarray(net.frame_out(lab, prob, pad))
+        self.img = self.ref_img_valid = out
         return out
 
 
