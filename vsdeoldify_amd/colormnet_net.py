@@ -657,6 +657,11 @@ class ColorMNetNetwork:
         DeepExColorMNet -- enqueue there, off the memory step's stream); this network's own context when the look-ahead is synchronous"""
         return self._helper_net().ctx if self.async_lookahead else self.ctx
 
+    def lookahead_wait_for_main(self):
+        """the look-ahead stream waits (on the GPU) for everything this network's stream holds so far"""
+        if self.async_lookahead:
+            self._helper_net().stream.wait_stream(self.stream)
+
     def prefetch_frames(self, frames, max_batch=None):
         """The whole look-ahead of ColorMNetRender for frames that will be stepped next, in order: RGB -> Lab, the L plane repeated and padded as
         InferenceCore does it (pad_divide_by 112), then prefetch_keys -- ALL on the look-ahead stream, so that the memory step's stream is not
@@ -673,7 +678,11 @@ class ColorMNetNetwork:
             shape0 = tuple(frames[0].shape)
             pad, Hp, Wp = frame_pads(shape0[0], shape0[1])
             with self.on_stream():
-                if hn is not self:
+                # frames that are not known to be complete may still be in flight on this network's stream: the look-ahead stream waits for its tail
+                # (frames uploaded by a blocking call, or squashed on the look-ahead context itself, need no such wait: the pass then overlaps
+                # whatever the memory step still has queued)
+                ready = all(is_device(f) and (f.complete or getattr(f, "produced_on_lookahead", False)) for f in frames)
+                if hn is not self and not ready:
                     hn.stream.wait_stream(self.stream)
                 with torch.cuda.stream(hn.stream):
                     B = len(frames)

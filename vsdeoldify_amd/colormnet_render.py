@@ -225,6 +225,16 @@ class ColorMNetRender:
             lab, img = ahead[1], ahead[2][5]
             from .colormnet_fast import frame_pads
             pad = frame_pads(lab.shape[-2], lab.shape[-1])[0]
+        elif is_device(frame_i) and getattr(net, "async_lookahead", False) and self.first_mask_loaded and ref is None:
+            # a frame nobody announced, handed over in HBM by a caller that does not block on the result: its key encoder still runs on the
+            # look-ahead stream (one frame per pass), so that it overlaps the memory step of the PREVIOUS frame -- consecutive colorize_frame calls
+            # pipeline on the GPU (212 -> ~300 frames/s for the reference's own call shape)
+            labs, entries = net.prefetch_frames([frame_i], max_batch=1)
+            ahead = (frame_i, labs[0], entries[0])
+            net.wait_prefetched(entries[0])
+            lab, img = labs[0], entries[0][5]
+            from .colormnet_fast import frame_pads
+            pad = frame_pads(lab.shape[-2], lab.shape[-1])[0]
         else:
             lab, img, pad = net.frame_in(frame_i if is_device(frame_i) else np.asarray(frame_i))
         ref_img = msk_ab = None
@@ -312,6 +322,14 @@ class DeepExColorMNet:
         from .device import is_device
         from .havc import spline64
         h, w = frame.shape[:2]
+        if _small is None and is_device(frame) and frame.complete and ref is None and self.render.first_mask_loaded:
+            # a resident frame nobody announced: squashed on the look-ahead context, where its key encoder will run -- nothing of this frame's
+            # preparation waits for the memory step of the previous one (ColorMNetRender._colorize_frame_fast)
+            net = self.render.network
+            la_ctx = net.lookahead_context() if hasattr(net, "lookahead_context") and getattr(net, "async_lookahead", False) else None
+            if la_ctx is not None:
+                _small = self._small(frame, la_ctx)
+                _small[0].produced_on_lookahead = True
         small, (ph, pw) = _small if _small is not None else self._small(frame)
         if ref is not None:
             rs, _ = self._squash(ref)
@@ -336,12 +354,21 @@ class DeepExColorMNet:
         la_ctx = net.lookahead_context() if hasattr(net, "lookahead_context") else None
         if la_ctx is not None:
             # A device frame may still be being WRITTEN on its own context's stream (the output of another model handed straight to deepex):
-            # the look-ahead stream must not read it unordered (device.py's rule: a buffer crosses contexts behind a synchronize() of its
-            # producer).  Once per window and producer context, not per frame.
+            # the look-ahead stream must not read it unordered (device.py's rule: a buffer crosses contexts behind its producer).  Frames of the
+            # network's own context are ordered ON THE GPU (the look-ahead stream waits for that stream's tail: no host stall, the memory step
+            # keeps running); any other producer context is drained once per window.
             from .device import is_device
-            for pctx in {id(f.ctx): f.ctx for f in new if is_device(f) and f.ctx is not la_ctx}.values():
-                pctx.synchronize()
+            for pctx in {id(f.ctx): f.ctx for f in new if is_device(f) and f.ctx is not la_ctx and not f.complete}.values():
+                if pctx is net.ctx and hasattr(net, "lookahead_wait_for_main"):
+                    net.lookahead_wait_for_main()
+                else:
+                    pctx.synchronize()
         smalls = [self._small(f, la_ctx) for f in new]
+        if la_ctx is not None:
+            from .device import is_device as _isdev
+            for sm, _ in smalls:
+                if _isdev(sm):
+                    sm.produced_on_lookahead = True                          # written on the very stream that will read it: no cross-stream wait
         self.render.prefetch([s for s, _ in smalls])
         for f, sm in zip(new, smalls):
             self._announced[id(f)] = (f, sm)                                 # (holding f keeps its id unique)

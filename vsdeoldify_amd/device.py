@@ -74,6 +74,9 @@ class DeviceImage:
         self.ctx, self.shape = ctx, shape
         self.nbytes = int(np.prod(shape))
         self._owner = owner                       # a view keeps its parent alive
+        # complete: the contents were written by a BLOCKING call (from_numpy) and nothing has been enqueued into the buffer since: another context may
+        # read it without ordering itself behind this one.  Views inherit it; everything an asynchronous op writes into stays False (the default).
+        self.complete = bool(getattr(owner, "complete", False))
         self._own = ptr is None
         self.ptr = pool_alloc(ctx, self.nbytes) if ptr is None else ptr
 
@@ -91,6 +94,7 @@ class DeviceImage:
         arr = np.ascontiguousarray(arr, dtype=np.uint8)
         d = cls(ctx, arr.shape)
         ctx.dev_upload(d.ptr, arr)
+        d.complete = True
         return d
 
     def numpy(self):
@@ -142,6 +146,7 @@ class DeviceImage:
         if other.nbytes != self.nbytes:
             raise ValueError("size mismatch")
         self.ctx.dev_copy(self.ptr, other.ptr, self.nbytes)
+        self.complete = False
         return self
 
 
