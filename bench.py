@@ -342,7 +342,9 @@ def other_configs_leg(args):
     import subprocess
     res = {}
     for cfg in ("c3", "c4", "c5"):
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "3", "--warmup", "1", "--no-extras", "--cpu-threads", str(args.cpu_threads)]
+        # (c5's first windows carry the exemplar, the growth of the working memory and the first consolidation: its steady state needs a longer warm-up)
+        steps, warm = ("8", "4") if cfg == "c5" else ("3", "1")
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", steps, "--warmup", warm, "--no-extras", "--cpu-threads", str(args.cpu_threads)]
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
         t0 = time.time()
