@@ -14,7 +14,7 @@ t = time.time()
 rt = GeneratorRuntime(ctx, synth_state_dict(arch, 1), arch, fuse_final=os.environ.get("FUSE_FINAL", "1") == "1",
                       fuse_blur=os.environ.get("FUSE_BLUR", "1") == "1")
 print(f"pack+upload {time.time()-t:.1f}s")
-net = rt.net(S, batch)
+net = rt.net(S, batch, os.environ.get("LOW_LATENCY", "0") == "1")
 for _ in range(2):
     ms = net.profile(batch)
 ms = np.mean([net.profile(batch) for _ in range(3)], axis=0)
