@@ -59,8 +59,15 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wav
 
 // ABL (profiling only, wrong results): 1 = no DMA inside the loop, 4 = no MFMA, 5 = no epilogue; ABL 30 (a product path): the precise epilogue
 // (Tried and dropped: staggering the DMA slots of the two waves sharing a SIMD -- 3-12 % slower, profiles/r1_conv_ablation.txt.)
+// __launch_bounds__(threads, 2): at most 256 registers per wave for EVERY tile geometry.  The 2- and 4-wave tiles (one wave per SIMD: the compiler may
+// use 512 registers, accumulators in AGPRs) came out with 127 v_accvgpr_read / _mov instructions per 32 MFMAs in their main loops -- the allocator
+// rotated the accumulators through the AGPR file every stage; capped at 256 the accumulators stay in place (round 4: the 128 x 128 / 128 x 256 /
+// 64 x 128 tiles 10 - 25 % faster on long-K shapes, profiles/r4_conv_tiles_register_cap.txt).  HAVC_PIPE_WPE=1 builds the old variant for A/B runs.
+#ifndef HAVC_PIPE_WPE
+#define HAVC_PIPE_WPE 2
+#endif
 template <int WM, int WN, int FM, int EXTRA, int ABL = 0>
-__global__ void __launch_bounds__(WM* WN * 64) conv_pipe_kernel(const ConvArgs p) {
+__global__ void __launch_bounds__(WM* WN * 64, HAVC_PIPE_WPE) conv_pipe_kernel(const ConvArgs p) {
     using G = Geo<WM, WN, FM, EXTRA>;
     constexpr int NW = G::NW, BM = G::BM, BN = G::BN, A_IT = G::A_IT, B_IT = G::B_IT, NS = G::NS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
