@@ -20,7 +20,7 @@ __device__ __forceinline__ int swzr(int row) { return (4 - ((row >> 2) & 3)) & 3
 __device__ __forceinline__ int swzk(int row) { return (4 - ((row >> 3) & 3)) & 3; }   // permuted key rows
 
 template <int D>
-__global__ void __launch_bounds__(256) self_attention_kernel(const half_t* __restrict__ qk, int qk_pitch, int f_coff,
+__global__ void __launch_bounds__(256, 2) self_attention_kernel(const half_t* __restrict__ qk, int qk_pitch, int f_coff,
                                                              int g_coff, const half_t* __restrict__ vT, int DV,
                                                              int npitch, const half_t* __restrict__ x, int x_cpitch,
                                                              int x_coff, half_t* __restrict__ out, int o_cpitch,

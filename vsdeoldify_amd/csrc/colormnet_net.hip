@@ -342,7 +342,7 @@ int launch_chan_attn(const half_t* q, int q_cp, int q_co, int64_t q_fs, const ha
 //       32 (f >> 1) + (i >> 2) 8 + (f & 1) 4 + (i & 3) (i = MFMA row), so a lane's eight P values of fragments 2s, 2s+1 are keys lg*8 .. +7 of
 //       the 32-key step s in natural order.  Row max / sum: in-lane over the lane's keys + __shfl_xor 16 / 32 over the 4 lanes of a query.
 constexpr int M64_KT = 64, M64_KP = 64 + 8, M64_VP = 64 + 8;
-__global__ void __launch_bounds__(256) mha64_kernel(const half_t* __restrict__ qkv, int cp, int q_co, int k_co, int v_co, int tok, half_t* __restrict__ o,
+__global__ void __launch_bounds__(256, 2) mha64_kernel(const half_t* __restrict__ qkv, int cp, int q_co, int k_co, int v_co, int tok, half_t* __restrict__ o,
                                                     int o_cp, int o_co, int o_tok, int heads, int L, float scale) {
     __shared__ __attribute__((aligned(16))) half_t Ks[M64_KT * M64_KP];
     __shared__ __attribute__((aligned(16))) half_t VsT[64 * M64_VP];

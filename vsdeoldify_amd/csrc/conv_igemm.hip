@@ -15,8 +15,10 @@
 
 __device__ __forceinline__ int swz(int row) { return (4 - ((row >> 2) & 3)) & 3; }
 
+// (__launch_bounds__(256, 2): at most 256 registers per wave -- with the 512 a 4-wave block may have, the allocator parked the accumulators in AGPRs
+//  and moved them through v_accvgpr_read / _write around every MFMA: 760 such moves for 16 MFMAs in the 128 x 128 tile's loop)
 template <int BM, int BN, int WM, int WN, bool PRECISE = false>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
+__global__ void __launch_bounds__(256, (BN > 256 ? 1 : 2)) conv_igemm_kernel(const ConvArgs p) {
     constexpr int FM = BM / WM / 16;  // 16-pixel fragments per wave
     constexpr int FN = BN / WN / 16;  // 16-channel fragments per wave
     constexpr int A_IT = BM * 4 / 256;

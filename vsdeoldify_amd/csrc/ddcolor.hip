@@ -650,7 +650,7 @@ __global__ void __launch_bounds__(128) mha32_split_kernel(const half_t* __restri
 // neighbouring fragments are keys lg * 8 .. + 7 of a 32-key step in natural order: the second MFMA's B operand needs no shuffle.
 typedef float float4v_dd __attribute__((ext_vector_type(4)));
 constexpr int MHA_VP = MHA_KC + 8;                 // V^T row pitch (halfs): 528 B rows spread the 16 rows of a fragment read over the banks
-__global__ void __launch_bounds__(256) mha32_split_mfma_kernel(const half_t* __restrict__ q, int q_cpitch, int q_coff, int q_tok,
+__global__ void __launch_bounds__(256, 2) mha32_split_mfma_kernel(const half_t* __restrict__ q, int q_cpitch, int q_coff, int q_tok,
                                                                const half_t* __restrict__ kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,
                                                                float* __restrict__ part, int heads, int Lq, int Lk, float scale) {
     __shared__ __attribute__((aligned(16))) half_t VsT[32 * MHA_VP];
