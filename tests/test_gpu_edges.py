@@ -97,7 +97,7 @@ def test_oom_returns_gray_input_like_the_reference(ctx, monkeypatch):
     img = Image.fromarray(_rgb(48, 80, 3))
     assert mir.get_transformed_image(img).size == img.size
 
-    def boom(S, max_batch=1):
+    def boom(S, max_batch=1, low_latency=False):
         raise nat.HavcOutOfMemory("simulated HAVC_E_OOM")
     monkeypatch.setattr(mir._video, "net", boom)
     for im in (img, img.resize((64, 64))):                       # non-square source, and a source already at the render size

@@ -191,6 +191,26 @@ class DDColorGenerator:
             src.append(s_i)
         tgt = const_tokens(sd[d + ".query_feat.weight"].astype(np.float32))
         scale = 1.0 / math.sqrt(E // HEADS)
+        # K / V projections of the cross attentions: they read only the projected feature level (not the query chain), and the layers i, i + 3, i + 6
+        # share a level -- ONE GEMM per level with the layers' K | V weights stacked along N (round 4: 9 launches of N = 512 -> 3 of N = 1536, off the
+        # sequential query chain); layer i then reads its K / V at channel offset (i // 3) * 2 E.  Same dot products: same bytes.
+        kv_level = []
+        for lv in range(min(3, self.dec_layers)):
+            s_lv = src[lv]
+            pos = position_sine(s_lv.H, s_lv.W)
+            Ws, cs = [], []
+            for i in range(lv, self.dec_layers, 3):
+                c = f"{d}.transformer_cross_attention_layers.{i}"
+                Wi, bi = sd[c + ".multihead_attn.in_proj_weight"].astype(np.float32), sd[c + ".multihead_attn.in_proj_bias"].astype(np.float32)
+                Ws.append(Wi[E:])
+                cs.append(np.concatenate([pos @ Wi[E:2 * E].T + bi[E:2 * E], np.broadcast_to(bi[2 * E:], (pos.shape[0], E))], axis=1))
+            Wcat, carr = np.concatenate(Ws, 0), np.concatenate(cs, 1)
+            ckv = b.tensor(s_lv.H, s_lv.W, carr.shape[1])
+            consts.append((ckv.buf, carr, ckv.cpitch, s_lv.H * s_lv.W))
+            kv = b.tensor(s_lv.H, s_lv.W, carr.shape[1])
+            name = f"{d}.cross_kv.level{lv}"
+            b.conv(name, self._lin(name, s_lv, Wcat), s_lv, kv, flags=nat.F_RESIDUAL, res=ckv)
+            kv_level.append(kv)
         for i in range(self.dec_layers):
             lv = i % 3
             s_lv = src[lv]
@@ -200,14 +220,8 @@ class DDColorGenerator:
             cq = const_tokens(qpos @ Wi[:E].T + bi[:E])
             q = tok(E)
             b.conv(c + ".q", self._lin(c + ".q", tgt, Wi[:E]), tgt, q, flags=nat.F_RESIDUAL, res=cq)
-            pos = position_sine(s_lv.H, s_lv.W)
-            ckv_arr = np.concatenate([pos @ Wi[E:2 * E].T + bi[E:2 * E], np.broadcast_to(bi[2 * E:], (pos.shape[0], E))], axis=1)
-            ckv = b.tensor(s_lv.H, s_lv.W, 2 * E)
-            consts.append((ckv.buf, ckv_arr, ckv.cpitch, s_lv.H * s_lv.W))
-            kv = b.tensor(s_lv.H, s_lv.W, 2 * E)
-            b.conv(c + ".kv", self._lin(c + ".kv", s_lv, Wi[E:]), s_lv, kv, flags=nat.F_RESIDUAL, res=ckv)
             a = tok(E)
-            b.mha(c + ".attn", q, kv, 0, E, a, HEADS, QUERIES, s_lv.H * s_lv.W, scale)
+            b.mha(c + ".attn", q, kv_level[lv], (i // 3) * 2 * E, (i // 3) * 2 * E + E, a, HEADS, QUERIES, s_lv.H * s_lv.W, scale)
             t1 = tok(E)
             b.conv(c + ".out", self._lin(c + ".out", a, sd[c + ".multihead_attn.out_proj.weight"], bias=sd[c + ".multihead_attn.out_proj.bias"]),
                    a, t1, flags=nat.F_RESIDUAL, res=tgt)
