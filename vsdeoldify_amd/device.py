@@ -76,9 +76,21 @@ class DeviceImage:
         self._owner = owner                       # a view keeps its parent alive
         # complete: the contents were written by a BLOCKING call (from_numpy) and nothing has been enqueued into the buffer since: another context may
         # read it without ordering itself behind this one.  Views inherit it; everything an asynchronous op writes into stays False (the default).
-        self.complete = bool(getattr(owner, "complete", False))
+        self._complete = False
         self._own = ptr is None
         self.ptr = pool_alloc(ctx, self.nbytes) if ptr is None else ptr
+
+    @property
+    def complete(self):
+        """the owner of a view decides (a view of a buffer that has been written into asynchronously since is not complete either)"""
+        return self._owner.complete if self._owner is not None else self._complete
+
+    @complete.setter
+    def complete(self, value):
+        if self._owner is not None:
+            self._owner.complete = value
+        else:
+            self._complete = bool(value)
 
     def __del__(self):
         try:
