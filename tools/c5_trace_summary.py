@@ -1,5 +1,5 @@
 """Per-kernel summary of the last N frames of a rocprofv3 --kernel-trace run of `bench.py --config c5` (every ColorMNet frame ends with one
-cmn_lab_to_rgb launch): time per frame, launches per frame, average duration.   python tools/c5_trace_summary.py <kernel_trace.csv> [frames]"""
+cmn_lab_to_rgb / cmn_frame_out launch): time per frame, launches per frame, average duration.   python tools/c5_trace_summary.py <kernel_trace.csv> [frames]"""
 import collections
 import csv
 import sys
@@ -7,7 +7,9 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("cmn_lab_to_rgb")]
+idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith(("cmn_lab_to_rgb", "cmn_frame_out"))]      # (round 4: the fast step ends a frame with cmn_frame_out)
+if not idx:
+    sys.exit("c5_trace_summary: no frame-ending kernel (cmn_lab_to_rgb / cmn_frame_out) in the trace")
 first = idx[-N - 1] + 1 if len(idx) > N else 0
 sel = rows[first:idx[-1] + 1]
 t0, t1 = int(sel[0]["Start_Timestamp"]), int(sel[-1]["End_Timestamp"])
