@@ -177,7 +177,10 @@ __global__ void __launch_bounds__(WM* WN * 64, HAVC_PIPE_WPE) conv_pipe_kernel(c
     // ABL 20 / 21 / 22 (round-3 schedule experiments, correct results): 20 = the remaining pieces in the first NS/4 steps instead of NS/2
     // (more time to land before the barrier), 21 = three early pieces (steps NS-3 .. NS-1, the first one right behind the barrier), 22 = both
     constexpr int EARLY = (ABL == 21 || ABL == 22) ? 3 : 2;    // pieces of stage kt+2 issued in the last steps of stage kt
-    constexpr int NSD = (ABL == 20 || ABL == 22) ? NS / 4 : NS / 2;   // the other pieces go out in the first NSD steps of stage kt+1
+    // the other pieces go out in the first NSD steps of stage kt+1.  (Round 4 re-measured NS / 4 for the rotated extra-column tile: 3 % faster in the
+    // isolated conv_bench, nothing in bench.py in a same-box A/B -- and two byte-identical instantiations of the kernel differ by 1 - 2 % in that micro
+    // benchmark depending on their position in the code object.  Not adopted: profiles/r4_conv_schedule_ab.txt.)
+    constexpr int NSD = (ABL == 20 || ABL == 22) ? NS / 4 : NS / 2;
     auto dma_piece = [&](int q, char* buf, int2 e, int kstage) {
         if (q < A_IT) dma16(rx, buf + (wave + q * NW) * 1024, a_voff(q, e), 0);
         else dma16(rw, buf + BM * 128 + (wave + (q - A_IT) * NW) * 1024, b_voff[q - A_IT], (unsigned)kstage * 128u);
