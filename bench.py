@@ -11,8 +11,11 @@ offline), activations fp16 with fp32 MFMA accumulation.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
   python bench.py --config c4          # BASELINE configs[3]: DeOldify + DDColor merge (combine_method=2) at 1080p
 
-`value` is the whole-job rate over the EXACTLY K timed steps (sum over all ranks; `value_per_gpu` = value / n_gpus).
-Beside it the line carries, measured in the same process after the timed region (rank 0, N = 1):
+`value` is the whole-job rate over the EXACTLY K timed steps (sum over all ranks; `value_per_gpu` = value / n_gpus); one step = 64 frames per GPU
+(--batch).  Beside it the line carries, measured in the same process after the timed region (rank 0, N = 1):
+  precise        the same step with ModelImageRender(precision="precise") (fp32-class arithmetic: the mode that meets CIEDE2000 < 1.0 per pixel),
+                 its own roofline and its parity against the same oracle frames
+  other_configs  BASELINE configs[2..4] (c3 / c4 / c5) as short child-process legs run BEFORE this process touches the GPU (--no-other-configs skips)
   sustained      the same step looped for >= --sustain-seconds (default 30 s): first-second and steady-state rates
   pcie_inclusive host frames in -> host frames out through havc_colorize_clip_host (pinned memory, uploads / passes /
                  downloads of consecutive batches overlapped on three streams)
