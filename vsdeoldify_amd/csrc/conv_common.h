@@ -8,12 +8,14 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 // GELU in its exact form 0.5 v (1 + erf(v / sqrt 2)) (nn.GELU() of the ConvNeXt block).  erf by Abramowitz & Stegun 7.1.26
-// (|error| < 1.5e-7 + the 1-ulp v_rcp / v_exp): three orders below the fp16 rounding of the stored result, and half the
+// (|error| < 1.5e-7 + the 1-ulp v_rcp / v_exp): three orders below the fp16 rounding of the stored result, and a third of the
 // instructions of libm's two-branch erff -- the epilogue of pwconv1 evaluates 0.4 G of these per frame.  One definition for every
-// conv kernel, so all tile configurations keep producing the same bytes.
+// conv kernel, so all tile configurations keep producing the same bytes.  The reciprocal is the bare v_rcp_f32: __frcp_rn expands
+// to the correctly rounded division sequence (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup: 10 of the 23 VALU
+// instructions per value until round 4, when the ConvNeXt pwconv1 epilogue turned out to spend 20 % of the GEMM's time here).
 __device__ __forceinline__ float gelu_erf(float v) {
     const float x = fabsf(v) * 0.70710678118654752f;
-    const float t = __frcp_rn(fmaf(0.3275911f, x, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
     p = fmaf(p, t, 1.421413741f);
     p = fmaf(p, t, -0.284496736f);
@@ -113,10 +115,10 @@ __device__ __forceinline__ void epilogue_frag_precise(const ConvArgs& p, const f
 // PRECISE is a COMPILE-TIME switch: the precise epilogue lives in kernel instantiations of its own, the fast kernels carry none of its
 // code (a run-time branch here cost the dominant fast kernel 60 % -- register allocation of the whole kernel changed).
 template <bool PRECISE = false>
-__device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v acc, int m, int n, int HoWo) {
+__device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v acc, int m, int n, int HoWo, const int flags) {
     if (m >= p.M || n >= p.Npad) return;
     if (PRECISE) { epilogue_frag_precise(p, acc, m, n, HoWo); return; }
-    const bool leaky = p.flags & HAVC_F_LEAKY;
+    const bool leaky = flags & HAVC_F_LEAKY;
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = acc[r];
@@ -124,7 +126,7 @@ __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v a
         const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
         v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
     }
-    if (p.flags & HAVC_F_OUT_RGB8) {
+    if (flags & HAVC_F_OUT_RGB8) {
         if (n == 0) {
             uint8_t* y = reinterpret_cast<uint8_t*>(p.y) + (int64_t)m * 3;
 #pragma unroll
@@ -138,21 +140,21 @@ __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v a
         }
         return;
     }
-    if (p.flags & HAVC_F_RELU_PRE) {
+    if (flags & HAVC_F_RELU_PRE) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : (leaky ? v[r] * p.f2 : 0.f);
     }
-    if (p.flags & HAVC_F_GELU) {
+    if (flags & HAVC_F_GELU) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
     }
-    if (p.flags & HAVC_F_AFFINE) {
+    if (flags & HAVC_F_AFFINE) {
         const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
         const float4 sh = *reinterpret_cast<const float4*>(p.shift + n);
         v[0] = v[0] * sc.x + sh.x; v[1] = v[1] * sc.y + sh.y;
         v[2] = v[2] * sc.z + sh.z; v[3] = v[3] * sc.w + sh.w;
     }
-    if (p.flags & HAVC_F_OUT_PIXSHUF) {
+    if (flags & HAVC_F_OUT_PIXSHUF) {
         const int q = n / p.Co, c = n - q * p.Co;
         if (q >= 4) return;
         const int b = m / HoWo, rem = m - b * HoWo, ho = rem / p.Wo, wo = rem - ho * p.Wo;
@@ -165,7 +167,7 @@ __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v a
     }
     if (n >= p.Co) return;
     const int64_t mo = out_pixel(p, m, HoWo);
-    if (p.flags & HAVC_F_RESIDUAL) {
+    if (flags & HAVC_F_RESIDUAL) {
         // Same rounding points as the LDS epilogue of the pipelined kernels (conv_pipe_epilogue.inc): the conv result is rounded
         // to fp16 BEFORE the residual is added (and once more after), so every tile configuration produces the same bytes and a
         // frame colours identically whatever configuration the heuristic / autotuner picks for a batch size.
@@ -173,12 +175,12 @@ __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v a
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = (float)(half_t)v[r] + (float)rv[r];
     }
-    if (p.flags & HAVC_F_RELU_POST) {
+    if (flags & HAVC_F_RELU_POST) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : (leaky ? v[r] * p.f2 : 0.f);
     }
     half_t* y = reinterpret_cast<half_t*>(p.y);
-    if (p.flags & HAVC_F_OUT_TRANSPOSED) {
+    if (flags & HAVC_F_OUT_TRANSPOSED) {
         const int b = m / HoWo;
         const int64_t base = (int64_t)b * p.Co * p.pix_pitch + (m - b * HoWo);
 #pragma unroll
@@ -191,3 +193,8 @@ __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v a
     }
 }
 
+
+template <bool PRECISE = false>
+__device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v acc, int m, int n, int HoWo) {
+    epilogue_frag<PRECISE>(p, acc, m, n, HoWo, p.flags);
+}

@@ -23,278 +23,7 @@
 #include <atomic>
 #include <type_traits>
 
-namespace {
-
-constexpr int FN = 4;                         // 16-channel fragments per wave: every wave owns 64 output channels
-constexpr unsigned OOB = 0xF0000000u;         // voffset beyond every descriptor range -> DMA writes zeros
-
-// Tile geometry: WM x WN waves, each wave (FM*16 pixels) x 64 channels.
-//   <2,4,8>: 256 x 256, 8 waves  (the big decoder / tail convs)
-//   <2,2,4>: 128 x 128, 4 waves  (encoder / bottleneck layers: more, smaller tiles; 2 blocks per CU)
-//   <1,4,8>: 128 x 256, 4 waves  (few pixels, many channels: the 18x18 / 35x35 layers)
-template <int WM, int WN, int FM, int EXTRA>
-struct Geo {
-    static constexpr int NW = WM * WN;
-    static constexpr int BM = WM * FM * 16, BN = WN * 64;
-    static constexpr int A_IT = BM / 8 / NW, B_IT = BN / 8 / NW;      // 1-KiB DMA pieces per wave per stage
-    static constexpr int NS = 2 * FM;                                 // steps per stage
-    static constexpr int PIECES = A_IT + B_IT;
-    static constexpr int ROWS = BM + BN + 16 * EXTRA;
-    static constexpr int STAGE_BYTES = ROWS * 128;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;
-    static_assert(BM % (8 * NW) == 0 && BN % (8 * NW) == 0 && NW % 2 == 0, "pieces must divide over an even number of waves");
-    static_assert(FM >= FN, "second-half weight fragments are prefetched during the first FM steps");
-    static_assert(FM % 2 == 0, "the 4-slot pixel-fragment ring wraps cleanly only when a stage has a multiple of 4 steps");
-    static_assert(!EXTRA || (WM == 2 && WN == 4 && FM == 8), "extra columns: 256x256 tile only");
-    static_assert(NW * FM * 2048 <= LDS_BYTES, "LDS epilogue image");
-};
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff, unsigned soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_ptr_t)lds_wave_base, 16, voff, soff, 0, 0);
-}
-
-}  // namespace
-
-// ABL (profiling only, wrong results): 1 = no DMA inside the loop, 4 = no MFMA, 5 = no epilogue; ABL 30 (a product path): the precise epilogue
-// (Tried and dropped: staggering the DMA slots of the two waves sharing a SIMD -- 3-12 % slower, profiles/r1_conv_ablation.txt.)
-// __launch_bounds__(threads, 2): at most 256 registers per wave for EVERY tile geometry.  The 2- and 4-wave tiles (one wave per SIMD: the compiler may
-// use 512 registers, accumulators in AGPRs) came out with 127 v_accvgpr_read / _mov instructions per 32 MFMAs in their main loops -- the allocator
-// rotated the accumulators through the AGPR file every stage; capped at 256 the accumulators stay in place (round 4: the 128 x 128 / 128 x 256 /
-// 64 x 128 tiles 10 - 25 % faster on long-K shapes, profiles/r4_conv_tiles_register_cap.txt).  HAVC_PIPE_WPE=1 builds the old variant for A/B runs.
-#ifndef HAVC_PIPE_WPE
-#define HAVC_PIPE_WPE 2
-#endif
-template <int WM, int WN, int FM, int EXTRA, int ABL = 0>
-__global__ void __launch_bounds__(WM* WN * 64, HAVC_PIPE_WPE) conv_pipe_kernel(const ConvArgs p) {
-    using G = Geo<WM, WN, FM, EXTRA>;
-    constexpr int NW = G::NW, BM = G::BM, BN = G::BN, A_IT = G::A_IT, B_IT = G::B_IT, NS = G::NS;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int lr = lane & 15, lg = lane >> 4;
-
-    const int nwg = gridDim.x;
-    int pid;
-    {
-        const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-        pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    }
-    const int NT = (p.Npad - 16 * EXTRA + BN - 1) / BN;
-    // split-K (HAVC_F_SPLITK): consecutive blocks are the K parts of one tile
-    const int SK = (!EXTRA && p.splitk > 1) ? p.splitk : 1;
-    const int part = SK > 1 ? pid % SK : 0;
-    if (SK > 1) pid /= SK;
-    const int m0 = (ABL == 9 ? (pid / NT) % 64 : pid / NT) * BM;      // ABL 9: L2-resident source, DMA ceiling
-    const int n0 = (pid % NT) * BN;
-    // EXTRA: Npad == 256 + 16 exactly (launch_pipe checks): ONE column tile, which has the extra fragment -- a compile-time fact, so the main loop
-    // carries no test for it
-    constexpr bool has_extra = EXTRA != 0;
-    const int HoWo = p.Ho * p.Wo;
-    // EXTRA: the 8 pixel fragments x 1 extra column fragment are shared by the four N-waves of a pixel slab, two pixel fragments each.  Round 4:
-    // wave wn walks the pixel fragments ROTATED by 2 wn (accumulator index mi <-> pixel fragment PF(mi) = (mi + 2 wn) & 7), so that its two
-    // extra MFMAs sit at the static steps mi = 0, 1 of each K half for EVERY wave: the main loop has no wave-dependent branch any more (it had
-    // 16 `if (wn == mi >> 1)` scalar branches per stage around single MFMAs: ~5 % of the kernel).  The rotation is a scalar offset folded into the
-    // fragment address the stage toggle already adds; the epilogue maps mi back with PF().
-    const int rot = EXTRA ? wn * 2 * 2048 : 0;
-    auto aoff = [&](int mi) -> int { return EXTRA ? ((mi * 2048 + rot) & (FM * 2048 - 1)) : mi * 2048; };
-#define PF(mi) (EXTRA ? (((mi) + 2 * wn) & (FM - 1)) : (mi))
-
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<half_t*>(p.w), 0, p.w_bytes, 0x00020000);
-
-    // ---- DMA lane role: row lane>>3 of an 8-row piece, LDS position lane&7, source chunk c = pos ^ f(row) ----
-    // wave w owns pieces w, w+NW, w+2NW, ... (same parity => same f) of both the pixel and the weight tile.
-    const int r8 = lane >> 3;
-    const int c = (lane & 7) ^ ((((wave & 1) << 2) + (r8 >> 1)) & 7);
-
-    unsigned a_base[A_IT];   // byte offset of (pixel row, tap 0, channel 0) in the input buffer (wraps when hi0/wi0 < 0)
-    int a_hw0[A_IT];         // hi0 | wi0 << 16 (signed 16-bit each)
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-        const int row = (wave + it * NW) * 8 + r8;
-        const int m = m0 + row;
-        const bool ok = m < p.M;
-        const int mm = ok ? m : 0;
-        int b = mm / HoWo;
-        const int rem = mm - b * HoWo;
-        int ho = rem / p.Wo;
-        int wo = rem - ho * p.Wo;
-        if (p.flags & HAVC_F_PS_BLUR) {                    // GEMM rows = 16x16 pixel tiles, origin (15 ty - 1, 15 tx - 1), clamped
-            const int tile = m0 / BM, tt = p.tiles_y * p.tiles_x;
-            b = tile / tt;
-            const int t = tile - b * tt, ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-            ho = min(max(ty * 15 - 1 + (row >> 4), 0), p.Ho - 1);
-            wo = min(max(tx * 15 - 1 + (row & 15), 0), p.Wo - 1);
-        }
-        const int hi0 = ok ? ho * p.stride - p.pad : -16384, wi0 = wo * p.stride - p.pad_w;
-        a_hw0[it] = (hi0 & 0xffff) | (wi0 << 16);
-        a_base[it] = (unsigned)((((int64_t)(b * p.Hi + hi0) * p.Wi + wi0) * p.x_cpitch + p.x_coff) * 2);
-    }
-    unsigned b_voff[B_IT];
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-        const int n = n0 + (wave + it * NW) * 8 + r8;
-        b_voff[it] = n < p.Npad ? (unsigned)((n * p.Kc + c) * 16) : OOB;
-    }
-    // extra 16 weight rows = pieces 32, 33 -> waves 6, 7
-    const unsigned x_voff = (unsigned)(((n0 + BN + (wave & 1) * 8 + r8) * p.Kc + c) * 16);
-    const bool extra_wave = has_extra && wave >= 6;
-
-    const int KT = p.Kc >> 3;
-    // this block's stages [kt0, kt1): the whole K, or part `part` of SK with EVEN boundaries (the LDS buffer of stage kt is kt & 1)
-    const int kt0 = SK > 1 ? ((KT * part / SK) & ~1) : 0;
-    const int kt1 = SK > 1 ? (part + 1 == SK ? KT : ((KT * (part + 1) / SK) & ~1)) : KT;
-    const int2* kt_lane = p.ktab + c;                  // this lane's chunk of every stage: kt_lane[kt * 8]
-
-    auto a_voff = [&](int it, int2 e) -> unsigned {
-        const int hi = (short)(a_hw0[it] & 0xffff) + (short)(e.y & 0xffff);
-        const int wi = (a_hw0[it] >> 16) + (e.y >> 16);
-        const bool ok = ((unsigned)hi < (unsigned)p.Hi) & ((unsigned)wi < (unsigned)p.Wi);
-        return ok ? a_base[it] + (unsigned)e.x : OOB;
-    };
-
-    // ---- fragment read addresses (bytes): per-lane constants + immediates; the second K half is base ^ 64 ----
-    const int fsw = (lr >> 1) & 7;
-    const int a_l0 = (wm * (FM * 16) + lr) * 128 + ((lg ^ fsw) << 4), a_l1 = a_l0 ^ 64;
-    const int b_l0 = BM * 128 + (wn * 64 + lr) * 128 + ((lg ^ fsw) << 4), b_l1 = b_l0 ^ 64;
-    const int x_l0 = (BM + BN + lr) * 128 + ((lg ^ fsw) << 4), x_l1 = x_l0 ^ 64;
-
-    float4v acc[FN][FM];
-    float4v accx[2];
-#pragma unroll
-    for (int ni = 0; ni < FN; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < FM; ++mi) acc[ni][mi] = float4v{0.f, 0.f, 0.f, 0.f};
-    accx[0] = accx[1] = float4v{0.f, 0.f, 0.f, 0.f};
-
-    // ---- prologue: all of stage 0, the first two pieces of stage 1, the first fragments of stage 0 ----
-    constexpr int P = G::PIECES;
-    // ABL 20 / 21 / 22 (round-3 schedule experiments, correct results): 20 = the remaining pieces in the first NS/4 steps instead of NS/2
-    // (more time to land before the barrier), 21 = three early pieces (steps NS-3 .. NS-1, the first one right behind the barrier), 22 = both
-    constexpr int EARLY = (ABL == 21 || ABL == 22) ? 3 : 2;    // pieces of stage kt+2 issued in the last steps of stage kt
-    // the other pieces go out in the first NSD steps of stage kt+1.  (Round 4 re-measured NS / 4 for the rotated extra-column tile: 3 % faster in the
-    // isolated conv_bench, nothing in bench.py in a same-box A/B -- and two byte-identical instantiations of the kernel differ by 1 - 2 % in that micro
-    // benchmark depending on their position in the code object.  Not adopted: profiles/r4_conv_schedule_ab.txt.)
-    constexpr int NSD = (ABL == 20 || ABL == 22) ? NS / 4 : NS / 2;
-    auto dma_piece = [&](int q, char* buf, int2 e, int kstage) {
-        if (q < A_IT) dma16(rx, buf + (wave + q * NW) * 1024, a_voff(q, e), 0);
-        else dma16(rw, buf + BM * 128 + (wave + (q - A_IT) * NW) * 1024, b_voff[q - A_IT], (unsigned)kstage * 128u);
-    };
-    int2 e_nx = kt_lane[kt0 * 8];
-#pragma unroll
-    for (int q = 0; q < P; ++q) dma_piece(q, smem, e_nx, kt0);
-    if (EXTRA && extra_wave) dma16(rw, smem + (BM + BN) * 128 + (wave & 1) * 1024, x_voff, 0);
-    e_nx = kt_lane[(kt1 - kt0 > 1 ? kt0 + 1 : kt0) * 8];
-    if (kt1 - kt0 > 1) {
-#pragma unroll
-        for (int q = 0; q < EARLY; ++q) dma_piece(q, smem + G::STAGE_BYTES, e_nx, kt0 + 1);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(e_nx.x), "+v"(e_nx.y));         // (see the note at the stage barrier)
-    __builtin_amdgcn_s_barrier();
-
-    half8 bf[2][FN];                                   // weight fragments, K half 0 / 1
-    half8 xb[2];                                       // extra-column weight fragment
-    half8 af[4];                                       // pixel fragment ring (two steps ahead)
-#pragma unroll
-    for (int ni = 0; ni < FN; ++ni) bf[0][ni] = *reinterpret_cast<const half8*>(smem + b_l0 + ni * 2048);
-    if (EXTRA) xb[0] = *reinterpret_cast<const half8*>(smem + x_l0);
-    af[0] = *reinterpret_cast<const half8*>(smem + a_l0 + aoff(0));
-    af[1] = *reinterpret_cast<const half8*>(smem + a_l0 + aoff(1));
-
-    // One 64-deep stage (NS steps of FN MFMAs).  LVL (compile time): 2 = stages kt+1 and kt+2 exist, 1 = only kt+1,
-    // 0 = last stage.  Two LDS buffers; the single barrier of a stage sits at step NS-3, right after the LAST fragment
-    // read of this stage's buffer has been issued: behind it (a) the buffer can be refilled (stage kt+2), so the DMA
-    // gets the rest of this stage plus most of the next one to land instead of racing the next barrier, and (b) stage
-    // kt+1's data is complete, so its first fragments are fetched under the MFMAs of steps NS-2, NS-1 -- the MFMA
-    // pipe no longer drains at a stage boundary.
-    auto stage = [&](int kt, auto lvl_tag) {
-        constexpr int LVL = ABL == 10 ? 0 : ABL == 1 ? (decltype(lvl_tag)::value ? 1 : 0) : decltype(lvl_tag)::value;
-        constexpr bool RD = ABL != 10;
-        constexpr bool DMA_ON = ABL != 1;
-        const char* cur = smem + (kt & 1) * G::STAGE_BYTES;
-        char* nxt = smem + ((kt & 1) ^ 1) * G::STAGE_BYTES;
-        int2 e_n2 = e_nx;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {                 // step s: K half s / FM, pixel fragment s % FM
-            const int ks = s / FM, mi = s % FM;
-            if (s == 0 && LVL == 2) e_n2 = kt_lane[(kt + 2) * 8];             // K table entry of stage kt+2
-            {                                          // (1) pixel fragment two steps ahead (next stage's at the end)
-                const int s2 = s + 2;
-                if (s2 < NS && RD) af[s2 % 4] = *reinterpret_cast<const half8*>(cur + ((s2 / FM) ? a_l1 : a_l0) + aoff(s2 % FM));
-            }
-            if (s == NS - 3 && LVL >= 1) {             // (B) the barrier of this stage
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                // "use" the table entry here, where nothing is outstanding: otherwise the compiler's own wait for that
-                // load lands at the top of the next stage as vmcnt(0) and drains the early pieces issued below.
-                asm volatile("" : "+v"(e_n2.x), "+v"(e_n2.y));
-                __builtin_amdgcn_s_barrier();
-            }
-            if (s >= NS - 2 && LVL >= 1) {             // first fragments of stage kt+1
-                const int j = s - (NS - 2);
-                af[(s + 2) % 4] = *reinterpret_cast<const half8*>(nxt + a_l0 + aoff(j));
-#pragma unroll
-                for (int ni = 2 * j; ni < 2 * j + 2; ++ni) bf[0][ni] = *reinterpret_cast<const half8*>(nxt + b_l0 + ni * 2048);
-                if (EXTRA && j == 1) xb[0] = *reinterpret_cast<const half8*>(nxt + x_l0);
-            }
-            if (ks == 0 && mi >= FM - FN && RD)        // (2) weight fragments of the second K half
-                bf[1][mi - (FM - FN)] = *reinterpret_cast<const half8*>(cur + b_l1 + (mi - (FM - FN)) * 2048);
-            if (EXTRA && s == 3) xb[1] = *reinterpret_cast<const half8*>(cur + x_l1);
-            if (LVL >= 1 && DMA_ON && s < NSD) {       // (3) the rest of stage kt+1's DMA pieces
-#pragma unroll
-                for (int q = EARLY + (s * (P - EARLY)) / NSD; q < EARLY + ((s + 1) * (P - EARLY)) / NSD; ++q)
-                    dma_piece(q, nxt, e_nx, kt + 1);
-            }
-            if (EXTRA && LVL >= 1 && DMA_ON && s == NSD) {
-                if (extra_wave) dma16(rw, nxt + (BM + BN) * 128 + (wave & 1) * 1024, x_voff, (unsigned)(kt + 1) * 128u);
-            }
-            if (LVL == 2 && DMA_ON && s >= NS - EARLY) //     and, behind the barrier, the first pieces of stage kt+2
-                dma_piece(s - (NS - EARLY), const_cast<char*>(cur), e_n2, kt + 2);
-            const half8 a = af[s % 4];                 // (4) the MFMAs of this step
-#pragma unroll
-            for (int ni = 0; ni < FN; ++ni) {
-                if (ABL == 4 || ABL == 9) asm volatile("" ::"v"(bf[ks][ni]), "v"(a));
-                else acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[ks][ni], a, acc[ni][mi], 0, 0, 0);
-            }
-            if (EXTRA && mi < 2)                       // extra column fragment x this wave's pixel fragments PF(0), PF(1) = 2 wn, 2 wn + 1: static steps
-                accx[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xb[ks], a, accx[mi], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        e_nx = e_n2;
-    };
-    // Static priority for the younger half of an 8-wave block (two waves per SIMD): waves 4-7 lose the VALU / issue arbitration to the older
-    // half on every stage (priority, then age: MI355X_MICROARCH.md "Two waves per SIMD", item 4).  ONE s_setprio before the loop, no flips:
-    // 5.99 -> 5.83 ms on the tail conv (interleaved same-box A/B, profiles/r3_conv_experiments.txt).  Scheduling only: same bytes.
-    if (NW == 8 && p.prio && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-    int kt = kt0;
-    for (; kt + 2 < kt1; ++kt) stage(kt, std::integral_constant<int, 2>{});
-    if (kt1 - kt0 >= 2) { stage(kt, std::integral_constant<int, 1>{}); ++kt; }
-    stage(kt, std::integral_constant<int, 0>{});
-
-    auto gm = [&](int local_row) -> int { return m0 + local_row; };
-    const int lp = lr;                                     // MFMA column lr carries pixel lr of its fragment
-    if (!EXTRA && SK > 1) {                                // split-K: raw fp32 partial sums, lane = pixel lr, channels lg*4 .. +3 of each fragment
-#pragma unroll
-        for (int mi = 0; mi < FM; ++mi) {
-            const int m = m0 + wm * (FM * 16) + mi * 16 + lr;
-            if (m >= p.M) continue;
-            float* row = p.ws + ((int64_t)part * p.M + m) * p.Npad;
-#pragma unroll
-            for (int ni = 0; ni < FN; ++ni) {
-                const int n = n0 + wn * 64 + ni * 16 + lg * 4;
-                if (n < p.Npad) *reinterpret_cast<float4v*>(row + n) = acc[ni][mi];
-            }
-        }
-        return;
-    }
-#include "conv_pipe_epilogue.inc"
-#undef PF
-}
+#include "conv_pipe_kernel.inc"
 
 // =====================================================================================================================
 // conv_halo_kernel: 3x3 stride-1 pad-1 convolutions on 16x16-pixel tiles with HALO REUSE.
@@ -517,23 +246,12 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs p) {
         return (y < p.Ho && x < p.Wo) ? (tb * p.Ho + y) * p.Wo + x : 0x7fffffff;
     };
 #define PF(mi) (mi)
+    const int eflags = p.flags;
+    auto opix = [&](int m) -> int64_t { return (int64_t)m; };          // launch_halo requires out step 1
 #include "conv_pipe_epilogue.inc"
 #undef PF
 }
 
-// Opt a kernel in to > 64 KiB of dynamic LDS.  The attribute is per DEVICE (a process may hold contexts on several GPUs:
-// render.get_context caches one per device_index), so the "done" state is a bit per device ordinal, set with an atomic OR
-// (VapourSynth worker threads may race here; setting the attribute twice is harmless).
-template <auto Kernel>
-static void ensure_lds_optin(int lds_bytes) {
-    static std::atomic<uint64_t> done{0};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const uint64_t bit = 1ull << (dev & 63);
-    if (done.load(std::memory_order_acquire) & bit) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    done.fetch_or(bit, std::memory_order_release);
-}
 
 template <int EXTRA, int ABL = 0>
 static int launch_halo(const ConvArgs& a0, hipStream_t s) {
@@ -568,7 +286,7 @@ __global__ void splitk_reduce_kernel(const ConvArgs p) {
     }
 }
 
-template <int WM, int WN, int FM, int EXTRA, int ABL = 0>
+template <int WM, int WN, int FM, int EXTRA, int ABL = 0, int EF = -1>
 static int launch_pipe(const ConvArgs& a, hipStream_t s) {
     using G = Geo<WM, WN, FM, EXTRA>;
     if ((a.Kc & 7) || !a.ktab || a.x_bytes == 0 || a.x_bytes >= OOB || a.w_bytes >= OOB || (EXTRA && a.Npad != G::BN + 16)) return (int)hipErrorInvalidValue;
@@ -579,8 +297,9 @@ static int launch_pipe(const ConvArgs& a, hipStream_t s) {
         return (int)hipErrorInvalidValue;
     constexpr int LDS = G::LDS_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    ensure_lds_optin<conv_pipe_kernel<WM, WN, FM, EXTRA, ABL>>(LDS);
-    hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, ABL>), dim3(MT * NT * SK), dim3(G::NW * 64), LDS, s, a);
+    if (EF >= 0 && ((a.flags & HAVC_EPI_MASK) != EF || a.oss != 1 || !a.bias)) return (int)hipErrorInvalidValue;
+    ensure_lds_optin<conv_pipe_kernel<WM, WN, FM, EXTRA, ABL, EF>>(LDS);
+    hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, ABL, EF>), dim3(MT * NT * SK), dim3(G::NW * 64), LDS, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || SK == 1) return (int)e;
     const int64_t work = (int64_t)a.M * (a.Npad >> 2);
@@ -599,6 +318,7 @@ void preload_conv_pipe() {
     PL(2, 4, 8, 0, 30); PL(2, 4, 8, 1, 30); PL(2, 2, 4, 0, 30); PL(1, 4, 8, 0, 30); PL(1, 2, 4, 0, 30); PL(2, 4, 4, 0, 30); PL(4, 2, 4, 0, 30);
     PL(4, 1, 4, 0, 30); PL(2, 1, 4, 0, 30);
 #undef PL
+    preload_conv_pipe_ef();
     ensure_lds_optin<conv_halo_kernel<0, 0>>(2 * 46 * 1024 + 2 * 256 * 128);
     ensure_lds_optin<conv_halo_kernel<1, 0>>(2 * 46 * 1024 + 2 * 272 * 128);
     (void)hipGetLastError();
@@ -628,6 +348,10 @@ int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
         }
         return (int)hipErrorInvalidValue;
     }
+    {   // the hot layer kinds on the main tile geometries: kernels with their epilogue flags fixed at compile time (conv_igemm_pipe_ef.hip)
+        const int r = launch_conv_pipe_ef(a, cfg, s);
+        if (r != -1) return r;
+    }
     switch (cfg) {
         case 60: return launch_pipe<2, 4, 8, 0>(a, s);        // 256 x 256
         case 61: return launch_pipe<2, 4, 8, 1>(a, s);        // 256 x (256 + 16)
@@ -640,6 +364,8 @@ int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
         case 69: return launch_pipe<2, 4, 8, 0, 9>(a, s);
         case 73: return launch_pipe<2, 4, 8, 0, 10>(a, s);
         case 65: return launch_pipe<2, 4, 8, 0, 5>(a, s);
+        case 68: return launch_pipe<2, 4, 8, 0, 12>(a, s);    // generic epilogue without its global stores
+        case 78: return launch_pipe<2, 4, 8, 0, 14>(a, s);    // generic epilogue, every store into one 2-MiB window (cache-resident)
         case 66: return launch_pipe<2, 4, 8, 0, 11>(a, s);    // PS_BLUR epilogue without its global stores
         case 67: return launch_pipe<2, 4, 8, 0, 13>(a, s);    // PS_BLUR epilogue with plain instead of non-temporal stores
         case 80: return launch_halo<0>(a, s);                 // 3x3 s1 p1, 16x16-pixel tiles with halo reuse

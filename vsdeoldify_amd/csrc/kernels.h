@@ -49,6 +49,7 @@ struct ConvArgs {
 // returns hipError_t as int
 int launch_conv(const ConvArgs& a, hipStream_t s);
 int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s);
+int launch_conv_pipe_ef(const ConvArgs& a, int cfg, hipStream_t s);   // compile-time epilogue flags; -1 = no such kernel (conv_igemm_pipe_ef.hip)
 bool conv_splitk_cfg_ok(int cfg);      // tile configurations that may run with ConvArgs::splitk > 1 (the plain pipelined tiles)
 const char* conv_config_name(const ConvArgs& a);
 
@@ -171,6 +172,7 @@ int launch_range_stats(const void* p, int elem_bytes, int64_t n, unsigned* stats
 
 // ---- eager module load + big-LDS opt-ins, one function per translation unit (called once per device from havc_create) ----
 void preload_conv_pipe();
+void preload_conv_pipe_ef();
 void preload_conv_igemm();
 void preload_elementwise();
 void preload_zhang();
