@@ -171,7 +171,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=None, help="frames per step per GPU (default: 64 for the headline config, 32 for c3 / c4 / c5)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per step per GPU (default: 64 for the headline config and c3, 32 for c4 / c5)")
     ap.add_argument("--clip-frames", type=int, default=None, help="distinct synthetic frames resident per GPU (default: one step's worth)")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 = BASELINE configs[1] (headline), c3 = configs[2] (DDColor large, input 512), c4 = configs[3] (DeOldify+DDColor merge), "
@@ -184,7 +184,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=32, help="threads for the CPU-oracle baseline leg")
     args = ap.parse_args()
     if args.batch is None:              # 64 frames per step fill the small encoder / decoder layers better than 32 (+2 %, same-box A/B; 105 GB of activations)
-        args.batch = 64 if args.config == "c2" else 32
+        # c3 (DDColor): 64 frames = 65 536 tokens at the 768-channel stage -> 768 tiles of 256 x 256 for pwconv2 = exactly 3 per CU; at 32 frames
+        # 384 tiles = 1.5 per CU and the GEMM runs at 75 % (profiles/r4_ddcolor_batch_sweep.txt: 1.09 -> 1.01 ms per frame of GPU ops)
+        args.batch = 64 if args.config in ("c2", "c3") else 32
     if args.clip_frames is None:
         args.clip_frames = args.batch
 

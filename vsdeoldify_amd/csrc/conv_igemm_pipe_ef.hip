@@ -3,6 +3,11 @@
 // the epilogue shrinks from ~24 000 instructions with ~390 scalar branches (every layer kind's path, flags tested inside the unrolled fragment
 // loops) to 1 000 - 2 500 instructions: 10 - 20 % of a short-K GEMM (ConvNeXt pwconv1 768 -> 3072 + GELU: 0.115 -> 0.101 ms at 16 frames,
 // 192 -> 768: 0.307 -> 0.245 ms; profiles/r4_epilogue_ablation.txt).  HAVC_EPI_SPECIAL=0 switches them off (A/B runs).
+// Two translation units (parallel build): this file = the 256 x 256 / 256 x 272 / 128 x 128 / 256 x 128 / 128 x 256 tiles; conv_igemm_pipe_ef2.hip
+// (this file again with HAVC_EF_PART 1) = the small tiles of the encoders and of ColorMNet's one-frame launches.
+#ifndef HAVC_EF_PART
+#define HAVC_EF_PART 0
+#endif
 #include "conv_common.h"
 #include <atomic>
 #include <cstdlib>
@@ -31,24 +36,36 @@ constexpr int RELU = HAVC_F_RELU_PRE, AFF = HAVC_F_AFFINE, RES = HAVC_F_RESIDUAL
 // layer kinds (epilogue flag sets) with a kernel of their own, per tile geometry:
 //   0              bias only (K / V / Q projections, input projections)              RELU           conv + ReLU (BN folded: ResNet conv1 / conv2, tail res-block conv 1)
 //   RELU | AFF     conv -> ReLU -> BatchNorm (the DeOldify decoder / middle convs)   RES            conv + residual
-//   AFF | RES      ConvNeXt pwconv2: layer scale, + block input                      RES | POST     ResNet conv3: + identity, ReLU
+//   AFF | RES      ConvNeXt pwconv2: layer scale, + block input                      RES | POST     ResNet conv3: + identity, ReLU (POST alone: ColorMNet)
 //   GELU           ConvNeXt pwconv1                                                  RELU | PS      1x1 conv + ReLU + PixelShuffle (without the fused blur)
 // and on the 256 x 256 tile only: RELU | PS | PS_BLUR (shuffle + blur fused), RELU | FUSE_PROJ (DDColor last_shuf + einsum + refine);
 // on the 256 x 272 tile: RELU (tail res-block conv 1) and RELU | RES | FUSE_RGB8 (conv 2 + layers.11 + SigmoidRange + u8).
 #define HAVC_EF_COMMON(X, WM, WN, FM) \
     X(WM, WN, FM, 0, 0) X(WM, WN, FM, 0, RELU) X(WM, WN, FM, 0, RELU | AFF) X(WM, WN, FM, 0, RES) X(WM, WN, FM, 0, AFF | RES) \
-    X(WM, WN, FM, 0, RES | POST) X(WM, WN, FM, 0, HAVC_F_GELU)
+    X(WM, WN, FM, 0, RES | POST) X(WM, WN, FM, 0, POST) X(WM, WN, FM, 0, HAVC_F_GELU)
+#if HAVC_EF_PART == 0
 #define HAVC_EF_ALL(X) \
     HAVC_EF_COMMON(X, 2, 4, 8) X(2, 4, 8, 0, RELU | PS) X(2, 4, 8, 0, RELU | PS | HAVC_F_PS_BLUR) X(2, 4, 8, 0, RELU | HAVC_F_FUSE_PROJ) \
     X(2, 4, 8, 1, RELU) X(2, 4, 8, 1, RELU | RES | HAVC_F_FUSE_RGB8) \
     HAVC_EF_COMMON(X, 2, 2, 4) HAVC_EF_COMMON(X, 4, 2, 4) HAVC_EF_COMMON(X, 2, 4, 4)
+#else
+#define HAVC_EF_ALL(X) \
+    HAVC_EF_COMMON(X, 1, 2, 4) HAVC_EF_COMMON(X, 1, 4, 4) HAVC_EF_COMMON(X, 2, 2, 6) HAVC_EF_COMMON(X, 1, 4, 8) HAVC_EF_COMMON(X, 4, 1, 4) \
+    HAVC_EF_COMMON(X, 2, 1, 4)
+#endif
 
-constexpr int geo_cfg(int WM, int WN, int FM, int EX) {
-    return (WM == 2 && WN == 4 && FM == 8) ? 60 + EX : (WM == 2 && WN == 2 && FM == 4) ? 70 : (WM == 4 && WN == 2 && FM == 4) ? 98 : (WM == 2 && WN == 4 && FM == 4) ? 96 : -1;
+constexpr int geo_cfg(int WM, int WN, int FM, int EX) {               // the configuration ids of launch_conv_pipe (conv_igemm_pipe.hip)
+    return (WM == 2 && WN == 4 && FM == 8) ? 60 + EX : (WM == 2 && WN == 2 && FM == 4) ? 70 : (WM == 4 && WN == 2 && FM == 4) ? 98 :
+           (WM == 2 && WN == 4 && FM == 4) ? 96 : (WM == 1 && WN == 2 && FM == 4) ? 72 : (WM == 1 && WN == 4 && FM == 4) ? 91 :
+           (WM == 2 && WN == 2 && FM == 6) ? 93 : (WM == 1 && WN == 4 && FM == 8) ? 71 : (WM == 4 && WN == 1 && FM == 4) ? 99 :
+           (WM == 2 && WN == 1 && FM == 4) ? 92 : -1;
 }
 
 }  // namespace
 
+#if HAVC_EF_PART == 0
+int launch_conv_pipe_ef2(const ConvArgs& a, int cfg, int ef, hipStream_t s);
+void preload_conv_pipe_ef2();
 // -1: no specialised kernel for this (tile configuration, layer kind) -- the caller launches the run-time-flag kernel
 int launch_conv_pipe_ef(const ConvArgs& a, int cfg, hipStream_t s) {
     static const bool on = [] { const char* e = getenv("HAVC_EPI_SPECIAL"); return !e || atoi(e) != 0; }();
@@ -57,12 +74,27 @@ int launch_conv_pipe_ef(const ConvArgs& a, int cfg, hipStream_t s) {
 #define X(WM, WN, FM, EX, EF) if (cfg == geo_cfg(WM, WN, FM, EX) && ef == (EF)) return launch_ef<WM, WN, FM, EX, (EF)>(a, s);
     HAVC_EF_ALL(X)
 #undef X
-    return -1;
+    return launch_conv_pipe_ef2(a, cfg, ef, s);
 }
 
 void preload_conv_pipe_ef() {
 #define X(WM, WN, FM, EX, EF) optin_ef<WM, WN, FM, EX, (EF)>();
     HAVC_EF_ALL(X)
 #undef X
+    preload_conv_pipe_ef2();
     (void)hipGetLastError();
 }
+#else
+int launch_conv_pipe_ef2(const ConvArgs& a, int cfg, int ef, hipStream_t s) {
+#define X(WM, WN, FM, EX, EF) if (cfg == geo_cfg(WM, WN, FM, EX) && ef == (EF)) return launch_ef<WM, WN, FM, EX, (EF)>(a, s);
+    HAVC_EF_ALL(X)
+#undef X
+    return -1;
+}
+
+void preload_conv_pipe_ef2() {
+#define X(WM, WN, FM, EX, EF) optin_ef<WM, WN, FM, EX, (EF)>();
+    HAVC_EF_ALL(X)
+#undef X
+}
+#endif
