@@ -50,6 +50,8 @@ SHAPES = {  # name: (Cin, Cout, k, stride, pad, H, W, flags)
     "attn_qk": (512, 128, 1, 1, 0, 70, 70, 0),
     "ddkv2": (256, 512, 1, 1, 0, 64, 64, 0),                        # DDColor colour decoder: K / V projection of the 1/8 feature level (+res: the position term)
     "ddkv1": (256, 512, 1, 1, 0, 32, 32, 0),
+    "ddkv_l2": (256, 1536, 1, 1, 0, 128, 128, 0),                  # all three layers' K / V of the 1/4 level in one GEMM (cross_kv.level2)
+    "ddlast": (256, 4096, 1, 1, 0, 128, 128, nat.F_RELU_PRE),      # last_shuf without the fused projection
     "l4ps": (2048, 2048, 1, 1, 0, 18, 18, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),
     "l5ps": (512, 2048, 1, 1, 0, 35, 35, nat.F_RELU_PRE | nat.F_OUT_PIXSHUF),
 }

@@ -246,12 +246,13 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs p) {
         return (y < p.Ho && x < p.Wo) ? (tb * p.Ho + y) * p.Wo + x : 0x7fffffff;
     };
 #define PF(mi) (mi)
+#define HAVC_STAMP(i) do { } while (0)
     const int eflags = p.flags;
     auto opix = [&](int m) -> int64_t { return (int64_t)m; };          // launch_halo requires out step 1
 #include "conv_pipe_epilogue.inc"
 #undef PF
+#undef HAVC_STAMP
 }
-
 
 template <int EXTRA, int ABL = 0>
 static int launch_halo(const ConvArgs& a0, hipStream_t s) {
@@ -364,6 +365,8 @@ int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
         case 69: return launch_pipe<2, 4, 8, 0, 9>(a, s);
         case 73: return launch_pipe<2, 4, 8, 0, 10>(a, s);
         case 65: return launch_pipe<2, 4, 8, 0, 5>(a, s);
+        case 162: return launch_pipe<2, 4, 8, 0, 40, 0>(a, s);   // bias-only epilogue with phase time stamps (tools/conv_timeline.py)
+        case 163: return launch_pipe<2, 4, 8, 0, 40, HAVC_F_GELU>(a, s);
         case 68: return launch_pipe<2, 4, 8, 0, 12>(a, s);    // generic epilogue without its global stores
         case 78: return launch_pipe<2, 4, 8, 0, 14>(a, s);    // generic epilogue, every store into one 2-MiB window (cache-resident)
         case 66: return launch_pipe<2, 4, 8, 0, 11>(a, s);    // PS_BLUR epilogue without its global stores
