@@ -367,6 +367,7 @@ int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
         case 65: return launch_pipe<2, 4, 8, 0, 5>(a, s);
         case 162: return launch_pipe<2, 4, 8, 0, 40, 0>(a, s);   // bias-only epilogue with phase time stamps (tools/conv_timeline.py)
         case 163: return launch_pipe<2, 4, 8, 0, 40, HAVC_F_GELU>(a, s);
+        case 164: return launch_pipe<2, 4, 8, 1, 40, HAVC_F_RELU_PRE>(a, s);   // the tail res-block conv (256 x 272 tile)
         case 68: return launch_pipe<2, 4, 8, 0, 12>(a, s);    // generic epilogue without its global stores
         case 78: return launch_pipe<2, 4, 8, 0, 14>(a, s);    // generic epilogue, every store into one 2-MiB window (cache-resident)
         case 66: return launch_pipe<2, 4, 8, 0, 11>(a, s);    // PS_BLUR epilogue without its global stores

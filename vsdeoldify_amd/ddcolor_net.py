@@ -50,6 +50,9 @@ class DDColorGenerator:
         self._frozen = False
         self.fuse_tail = os.environ.get("HAVC_DD_FUSE_TAIL", "1") != "0"      # A/B switch: einsum + refine folded into the last_shuf conv
         self.fuse_dwln = os.environ.get("HAVC_DD_FUSE_DWLN", "1") != "0"      # A/B switch: dwconv + LayerNorm as one kernel
+        # encoder.norm{0,1,2} feed nothing but the decoder's BatchNorm + ReLU on the skip connection: LayerNorm -> BN -> ReLU as ONE LayerNorm launch with
+        # the BN folded into its gamma / beta, written straight into the concat buffer (round 4: the separate affine pass was 1.2 ms per 64 frames)
+        self.fuse_skip_norm = os.environ.get("HAVC_DD_FUSE_SKIPNORM", "1") != "0" and self.fuse_tail
         self.plan(64)
         self.blob = self.pack.blob()
         self._frozen = True
@@ -124,7 +127,10 @@ class DDColorGenerator:
                                 scale=sd[p + ".gamma"].astype(np.float32), shift=np.zeros(c, np.float32))
                 b.conv(p + ".pwconv2", pc2, hbuf, alt, flags=nat.F_AFFINE | nat.F_RESIDUAL, res=x)
                 x, alt = alt, x
-            feats.append(self._ln(b, f"{e}.norm{i}", f"{e}.norm{i}", x, b.tensor(x.H, x.W, c), 1e-6))
+            if self.fuse_skip_norm and i < 3:
+                feats.append(x)                                # the raw stage output: normalised inside the decoder stage that consumes it
+            else:
+                feats.append(self._ln(b, f"{e}.norm{i}", f"{e}.norm{i}", x, b.tensor(x.H, x.W, c), 1e-6))
 
         # ---- decoder: three UnetBlockWide stages (deoldify/unet.py:170-205 family) ----
         outs, up = [], feats[3]
@@ -142,8 +148,19 @@ class DDColorGenerator:
             cat_pitch = pitch_for(ups + sks)
             cat_buf = b.buf(skip.H * skip.W * cat_pitch, 2, zero_init=False)
             b.blur_resize(p + ".blur", ps, View(cat_buf, 0, cat_pitch, skip.H, skip.W, up_c, ups))
-            so, sho = self._vecs(p + ".bn", lambda p=p: bn_scale_shift(sd, p + ".bn"))
-            b.affine(p + ".bn", skip, View(cat_buf, ups, cat_pitch, skip.H, skip.W, skip.C, sks), so, sho, relu=True)
+            skip_view = View(cat_buf, ups, cat_pitch, skip.H, skip.W, skip.C, sks)
+            if self.fuse_skip_norm:
+                nk = f"{e}.norm{2 - li}"
+
+                def make_norm_bn(p=p, nk=nk):
+                    s_bn, sh_bn = bn_scale_shift(sd, p + ".bn")
+                    return ((sd[nk + ".weight"].astype(np.float32) * s_bn).astype(np.float32),
+                            (sd[nk + ".bias"].astype(np.float32) * s_bn + sh_bn).astype(np.float32))
+                g, be = self._vecs(nk + "+" + p + ".bn", make_norm_bn)
+                b.layernorm(nk + "+bn", skip, skip_view, g, be, 1e-6, relu=True)
+            else:
+                so, sho = self._vecs(p + ".bn", lambda p=p: bn_scale_shift(sd, p + ".bn"))
+                b.affine(p + ".bn", skip, skip_view, so, sho, relu=True)
             cat = View(cat_buf, 0, cat_pitch, skip.H, skip.W, up_c + skip.C, ups + sks, np.concatenate([np.arange(up_c), ups + np.arange(skip.C)]))
 
             def make_conv(p=p, cat=cat):
