@@ -1,6 +1,7 @@
 // HBM-bound / small kernels of the DDColor path (architecture: oracle/ddcolor.py).  NHWC fp16 activations,
 // fp32 arithmetic.  Token tensors (the 100 colour queries) use the same layout with H = 1, W = tokens.
 #include "kernels.h"
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 
@@ -56,14 +57,50 @@ int launch_dwconv7(const half_t* x, const half_t* w, const float* bias, half_t* 
 // ---- LayerNorm over the C channels of every pixel / token (biased variance, two passes in registers) ----
 // LP lanes share a pixel (up to 4 16-byte chunks per lane), 64 / LP pixels per wave: C = 192 -> 8 lanes x 3 chunks, 8 pixels per wave
 // (one wave per pixel left 40 of 64 lanes idle there).  C <= 2048.  Channels C .. C8*8-1 (padding) are written as 0.
+// Round 4: a lane's channels are the same for every pixel it visits, so its gamma / beta sit in registers (they were 64 scalar loads per lane per
+// pixel), the grid is at most 1 024 blocks (four waves per SIMD, all resident) walking the pixels, and the LP-lane sums use DPP adds inside 16-lane rows instead of LDS-path shuffles.
+__device__ __forceinline__ float ln_dpp_add(float v, int ctrl) {
+    switch (ctrl) {            // the DPP control must be an immediate
+        case 0xB1: return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+        case 0x4E: return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+        case 0x141: return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+        default: return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));     // row_mirror
+    }
+}
 template <int LP>
-__global__ void layernorm_c_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ gamma,
+__device__ __forceinline__ float ln_group_sum(float v) {       // sum over the LP-lane group of the lane, result in every lane of the group
+    v = ln_dpp_add(v, 0xB1);
+    v = ln_dpp_add(v, 0x4E);
+    v = ln_dpp_add(v, 0x141);                                  // 8 lanes
+    if (LP >= 16) v = ln_dpp_add(v, 0x140);                    // 16 lanes (one DPP row)
+    if (LP >= 32) v += __shfl_xor(v, 16);
+    if (LP >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+template <int LP>
+__global__ void __launch_bounds__(256) layernorm_c_kernel(const half_t* __restrict__ x, half_t* __restrict__ y, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float eps, int64_t npix, int C, int x_cpitch, int x_coff, int y_cpitch,
                                    int y_coff, int relu) {
     constexpr int PPW = 64 / LP;                               // pixels per wave
     const int lane = threadIdx.x & 63, l = lane % LP, sub = lane / LP;
     const int C8 = (C + 7) / 8;
     const int64_t wave0 = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float g[4][8], bt[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c0 = (l + k * LP) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { g[k][e] = 0.f; bt[k][e] = 0.f; }
+        if (c0 + 8 <= C) {
+            const float4 g0 = *reinterpret_cast<const float4*>(gamma + c0), g1 = *reinterpret_cast<const float4*>(gamma + c0 + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(beta + c0), b1 = *reinterpret_cast<const float4*>(beta + c0 + 4);
+            g[k][0] = g0.x; g[k][1] = g0.y; g[k][2] = g0.z; g[k][3] = g0.w; g[k][4] = g1.x; g[k][5] = g1.y; g[k][6] = g1.z; g[k][7] = g1.w;
+            bt[k][0] = b0.x; bt[k][1] = b0.y; bt[k][2] = b0.z; bt[k][3] = b0.w; bt[k][4] = b1.x; bt[k][5] = b1.y; bt[k][6] = b1.z; bt[k][7] = b1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (c0 + e < C) { g[k][e] = gamma[c0 + e]; bt[k][e] = beta[c0 + e]; }
+        }
+    }
     for (int64_t p0 = wave0 * PPW; p0 < npix; p0 += nwaves * PPW) {
         const int64_t p = p0 + sub;
         const bool live = p < npix;
@@ -72,14 +109,15 @@ __global__ void layernorm_c_kernel(const half_t* __restrict__ x, half_t* __restr
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int c8 = l + k * LP;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
             if (live && c8 < C8) {
                 const half8 h = *reinterpret_cast<const half8*>(x + p * x_cpitch + x_coff + c8 * 8);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { v[k][e] = (c8 * 8 + e < C) ? (float)h[e] : 0.f; sum += v[k][e]; }
             }
         }
-#pragma unroll
-        for (int o = LP / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        sum = ln_group_sum<LP>(sum);
         const float mean = sum / (float)C;
         float sq = 0.f;
 #pragma unroll
@@ -89,8 +127,7 @@ __global__ void layernorm_c_kernel(const half_t* __restrict__ x, half_t* __restr
 #pragma unroll
                 for (int e = 0; e < 8; ++e) if (c8 * 8 + e < C) { const float d = v[k][e] - mean; sq += d * d; }
         }
-#pragma unroll
-        for (int o = LP / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+        sq = ln_group_sum<LP>(sq);
         const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -100,7 +137,7 @@ __global__ void layernorm_c_kernel(const half_t* __restrict__ x, half_t* __restr
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = c8 * 8 + e;
-                    float t = c < C ? (v[k][e] - mean) * rstd * gamma[c] + beta[c] : 0.f;
+                    float t = c < C ? (v[k][e] - mean) * rstd * g[k][e] + bt[k][e] : 0.f;
                     if (relu) t = fmaxf(t, 0.f);                       // ColorMNet Fuse: relu(norm3(x)) (colormnet/model/resnet.py:395-396)
                     o[e] = (half_t)t;
                 }
@@ -114,7 +151,7 @@ int launch_layernorm_c(const half_t* x, half_t* y, const float* gamma, const flo
     if (C > 2048) return (int)hipErrorInvalidValue;
     const int need = ((C + 7) / 8 + 3) / 4;                    // lanes per pixel at 4 chunks per lane
 #define LN_LAUNCH(LP)                                                                                                                          \
-    hipLaunchKernelGGL(layernorm_c_kernel<LP>, dim3(grid_for_dd((npix + 64 / LP - 1) / (64 / LP), 4)), dim3(256), 0, s, x, y, gamma, beta, eps, npix, \
+    hipLaunchKernelGGL(layernorm_c_kernel<LP>, dim3(std::min(grid_for_dd((npix + 64 / LP - 1) / (64 / LP), 4), 1024)), dim3(256), 0, s, x, y, gamma, beta, eps, npix, \
                        C, x_cpitch, x_coff, y_cpitch, y_coff, relu)
     if (need <= 8) LN_LAUNCH(8);
     else if (need <= 16) LN_LAUNCH(16);
