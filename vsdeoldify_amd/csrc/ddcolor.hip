@@ -182,6 +182,18 @@ __device__ __forceinline__ float dpp_sum8(float v) {          // sum over the 8-
     return v + __builtin_bit_cast(float, t);
 }
 
+template <bool WAVE>
+__device__ __forceinline__ float dw_group_sum(float v) {      // 8-lane sums, or (WAVE) the whole wave's sum in every lane
+    v = dpp_sum8(v);
+    if (WAVE) {
+        int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false);     // row_mirror: 16 lanes
+        v += __builtin_bit_cast(float, t);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+    }
+    return v;
+}
+
 constexpr int DWLN_T = 4, DWLN_R = 4;
 constexpr unsigned DWLN_OOB = 0xF0000000u;        // voffset beyond every descriptor range: the buffer load returns zeros
 static inline size_t dwln_lds_bytes(int C, bool wf32, int threads) {
@@ -200,7 +212,8 @@ __global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __res
                                                                    int H, int W, unsigned x_bytes, int x_cpitch, int x_coff, int y_cpitch,
                                                                    int y_coff, int w_pitch) {
     constexpr int T = DWLN_T, R = DWLN_R, NP = T * R, XR = R + 6;
-    constexpr int C = C4 * 4, S = THREADS / C4, G = C4 / 8;
+    constexpr bool WAVE_SUM = (C4 % 64 == 0);                  // a patch's threads are whole waves: LayerNorm partials per wave (DPP + 2 shuffles), not per 8 lanes
+    constexpr int C = C4 * 4, S = THREADS / C4, G = WAVE_SUM ? C4 / 64 : C4 / 8;
     constexpr int WB = WF32 ? 16 : 8;                         // bytes of one thread's weights per tap
     extern __shared__ __attribute__((aligned(16))) char dw_smem[];
     const int tid = threadIdx.x;
@@ -366,11 +379,11 @@ __global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __res
         for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int j = 0; j < R; ++j)
-                part[t * R + j] = dpp_sum8((acc[t][j][0][0] + acc[t][j][0][1]) + (acc[t][j][1][0] + acc[t][j][1][1]));
+                part[t * R + j] = dw_group_sum<WAVE_SUM>((acc[t][j][0][0] + acc[t][j][0][1]) + (acc[t][j][1][0] + acc[t][j][1][1]));
         auto block_sum = [&](float (&v)[NP]) {                  // v: 8-lane sums in, per-pixel sums over all C4 groups out
-            if (active && (c4 & 7) == 0) {
+            if (active && (c4 & (WAVE_SUM ? 63 : 7)) == 0) {
 #pragma unroll
-                for (int p = 0; p < NP; p += 4) *reinterpret_cast<float4*>(my_red + (c4 >> 3) * NP + p) = float4{v[p], v[p + 1], v[p + 2], v[p + 3]};
+                for (int p = 0; p < NP; p += 4) *reinterpret_cast<float4*>(my_red + (c4 >> (WAVE_SUM ? 6 : 3)) * NP + p) = float4{v[p], v[p + 1], v[p + 2], v[p + 3]};
             }
             __syncthreads();
 #pragma unroll
@@ -398,7 +411,7 @@ __global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __res
                     acc[t][j][k][1] -= mean;
                     sq += acc[t][j][k][0] * acc[t][j][k][0] + acc[t][j][k][1] * acc[t][j][k][1];
                 }
-                part[t * R + j] = dpp_sum8(sq);
+                part[t * R + j] = dw_group_sum<WAVE_SUM>(sq);
             }
         block_sum(part);
         if (valid) {
@@ -409,7 +422,7 @@ __global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __res
                 for (int j = 0; j < R; ++j) {
                     const int ho = ho0 + t, wo = wo0 + j;
                     if (ho >= H || wo >= W) continue;
-                    const float rstd = 1.0f / sqrtf(part[t * R + j] * inv_c + eps);
+                    const float rstd = __builtin_amdgcn_rsqf(part[t * R + j] * inv_c + eps);      // v_rsq_f32 (1 ulp); 1 / sqrtf was a 20-instruction division sequence, 16 times per thread
                     half4 o;
                     o[0] = (half_t)(acc[t][j][0][0] * rstd * g4.x + b4.x);
                     o[1] = (half_t)(acc[t][j][0][1] * rstd * g4.y + b4.y);
