@@ -309,7 +309,7 @@ def main():
         "whole_path_tflops": round(total_frames * 2759.32e9 / elapsed / 1e12 / world, 2),
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                      "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "conv_pipe_kernel<2,4,8,1> (layers.10 res-block 3x3 259->259 @560x560, 2 launches/pass; the 2nd also runs layers.11/12 in its epilogue)",
+                     "kernel": "conv_pipe_kernel<2,4,8,1,0,EF> (layers.10 res-block 3x3 259->259 @560x560, 2 launches/pass: EF=1 conv + ReLU, EF=261 conv + ReLU + residual with layers.11/12 in its epilogue; rocprof lists the two instantiations separately, this is their mean)",
                      "launches_timed": int(launches.value), "frames_per_launch": round(frames_per_launch, 2), "avg_launch_ms": round(avg_ms.value, 4),
                      "flops_per_launch": conv_flops},
         "gpu_ms_per_frame": round(st.total_ms / max(st.frames, 1), 4),
@@ -565,7 +565,7 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
     if ddcolor_only:            # 27 tagged GEMMs per pass: tokens x 768 -> 3072 at 32 x 32 tokens per frame
         per_pass, flops_frame, kname = 27, 2.0 * 32 * 32 * 768 * 3072, "conv_pipe_kernel (ConvNeXt-L stage 2 pwconv1 + GELU, 768 -> 3072 at 32x32 tokens per frame, 27 launches per pass)"
     else:                       # 2 tagged convs per pass: 3x3 259 -> 259 at 384 x 384
-        per_pass, flops_frame, kname = 2, 2.0 * 384 * 384 * 259 * 259 * 9, "conv_pipe_kernel<2,4,8,1> (DeOldify video layers.10 res-block 3x3 259->259 @384x384, 2 launches per pass)"
+        per_pass, flops_frame, kname = 2, 2.0 * 384 * 384 * 259 * 259 * 9, "conv_pipe_kernel<2,4,8,1,0,EF> (DeOldify video layers.10 res-block 3x3 259->259 @384x384, 2 launches per pass: EF=1 and EF=261)"
     fpl = args.steps * args.batch * per_pass / max(int(launches.value), 1)
     achieved = flops_frame * fpl / (avg_ms.value * 1e-3) / 1e12 if avg_ms.value > 0 else 0.0
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4),

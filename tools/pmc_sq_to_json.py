@@ -4,7 +4,7 @@ import collections, csv, glob, json, sys
 
 label = sys.argv[1] if len(sys.argv) > 1 else "r3"
 src = sys.argv[2] if len(sys.argv) > 2 else "gpurun_out"
-KERNEL = sys.argv[3] if len(sys.argv) > 3 else "conv_pipe_kernel<2, 4, 8, 1, 0>"
+KERNEL = sys.argv[3] if len(sys.argv) > 3 else "conv_pipe_kernel<2, 4, 8, 1, 0"
 rec = {"kernel": KERNEL, "command": "tools/pmc_bench_sq.sh (rocprofv3 --kernel-trace --pmc ..., bench.py --steps 2 --warmup 1)", "counters": {}}
 for d in ("pmc_bench_sq1", "pmc_bench_sq2"):
     cands = glob.glob(f"{src}/{d}/*/*counter_collection.csv")

@@ -9,7 +9,7 @@ import csv, glob, json, os, shutil, sys
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 label = sys.argv[2] if len(sys.argv) > 2 else "r2"
 src = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out"
-KERNEL = "conv_pipe_kernel<2, 4, 8, 1, 0>"
+KERNEL = "conv_pipe_kernel<2, 4, 8, 1, 0"       # <2,4,8,1,0,EF>: conv1 (EF = RELU) and conv2 (EF = RELU | RESIDUAL | FUSE_RGB8) are two instantiations since round 4
 
 
 def per_launch(kind, counter):

@@ -21,6 +21,8 @@
 // EXTRA = 1: 16 extra output columns (the 259-channel tail: Npad = 256 + 16) as 2 more MFMAs per wave per K half.
 #include "conv_common.h"
 #include <atomic>
+#include <cstdio>
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_pipe_kernel.inc"
@@ -352,6 +354,21 @@ int launch_conv_pipe(const ConvArgs& a, int cfg, hipStream_t s) {
     {   // the hot layer kinds on the main tile geometries: kernels with their epilogue flags fixed at compile time (conv_igemm_pipe_ef.hip)
         const int r = launch_conv_pipe_ef(a, cfg, s);
         if (r != -1) return r;
+        static const bool trace = getenv("HAVC_EPI_TRACE") != nullptr;        // which (tile, layer kind) pairs still run the run-time-flag kernel
+        if (trace) {
+            static std::atomic<uint64_t> seen[64];
+            const uint64_t key = ((uint64_t)cfg << 32) | (uint32_t)(a.flags & 0xffff) | ((uint64_t)(a.splitk > 1) << 48) | ((uint64_t)(a.oss != 1) << 49) | ((uint64_t)(!a.bias) << 50);
+            for (auto& e : seen) {
+                uint64_t cur = e.load();
+                if (cur == key) break;
+                if (cur == 0 && e.compare_exchange_strong(cur, key)) {
+                    fprintf(stderr, "havc: run-time-flag conv kernel: cfg %d flags 0x%x splitk %d out_step %d bias %d (M %d, N %d, K %d)\n", cfg, a.flags & 0xffff, a.splitk, a.oss,
+                            a.bias != nullptr, a.M, a.Npad, a.Kc * 8);
+                    break;
+                }
+                if (cur == key) break;
+            }
+        }
     }
     switch (cfg) {
         case 60: return launch_pipe<2, 4, 8, 0>(a, s);        // 256 x 256
