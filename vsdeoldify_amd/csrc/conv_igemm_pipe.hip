@@ -300,7 +300,7 @@ static int launch_pipe(const ConvArgs& a, hipStream_t s) {
         return (int)hipErrorInvalidValue;
     constexpr int LDS = G::LDS_BYTES;
     static_assert(LDS <= 160 * 1024, "LDS budget");
-    if (EF >= 0 && ((a.flags & HAVC_EPI_MASK) != EF || a.oss != 1 || !a.bias)) return (int)hipErrorInvalidValue;
+    if (EF >= 0 && ((a.flags & HAVC_EPI_MASK) != EF || a.oss != 1)) return (int)hipErrorInvalidValue;
     ensure_lds_optin<conv_pipe_kernel<WM, WN, FM, EXTRA, ABL, EF>>(LDS);
     hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, ABL, EF>), dim3(MT * NT * SK), dim3(G::NW * 64), LDS, s, a);
     hipError_t e = hipGetLastError();
