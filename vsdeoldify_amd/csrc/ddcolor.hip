@@ -700,74 +700,97 @@ __global__ void __launch_bounds__(128) mha32_split_kernel(const half_t* __restri
 // neighbouring fragments are keys lg * 8 .. + 7 of a 32-key step in natural order: the second MFMA's B operand needs no shuffle.
 typedef float float4v_dd __attribute__((ext_vector_type(4)));
 constexpr int MHA_VP = MHA_KC + 8;                 // V^T row pitch (halfs): 528 B rows spread the 16 rows of a fragment read over the banks
+// Round 4: a block walks `nch` consecutive 256-key chunks of its (head, frame) with a running (max, sum, acc) per query fragment before it writes
+// its partial state: at 16 384 keys x 64 frames the {m, l, acc[32]} partials of 64 splits per head were 0.45 GB written and read again by the merge
+// kernel next to 1.07 GB of K / V; with four chunks per block they are a quarter of that.  nch is chosen by the launcher (>= 1 024 blocks stay).
 __global__ void __launch_bounds__(256, 2) mha32_split_mfma_kernel(const half_t* __restrict__ q, int q_cpitch, int q_coff, int q_tok,
                                                                const half_t* __restrict__ kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,
-                                                               float* __restrict__ part, int heads, int Lq, int Lk, float scale) {
+                                                               float* __restrict__ part, int heads, int Lq, int Lk, float scale, int nch) {
     __shared__ __attribute__((aligned(16))) half_t VsT[32 * MHA_VP];
     const int c = blockIdx.x, h = blockIdx.y, b = blockIdx.z, nsplit = gridDim.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
-    const int k0 = c * MHA_KC, nk = min(MHA_KC, Lk - k0);
-    const half_t* kb = kv + ((int64_t)b * kv_tok + k0) * kv_cpitch + h * 32;
-    // V tile -> LDS, transposed: thread (key, chunk) scatters its 8 channels into 8 rows
-    for (int i = tid; i < MHA_KC * 4; i += 256) {
-        const int key = i >> 2, ch = i & 3;
-        half8 t;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t[e] = (half_t)0.f;
-        if (key < nk) t = *reinterpret_cast<const half8*>(kb + (int64_t)key * kv_cpitch + v_coff + ch * 8);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) VsT[(ch * 8 + e) * MHA_VP + key] = t[e];
-    }
-    // K fragments of the whole split in registers: 16 fragments x 16 B per lane
-    half8 kf[16];
-#pragma unroll
-    for (int f = 0; f < 16; ++f) {
-        const int key = 32 * (f >> 1) + (lr >> 2) * 8 + (f & 1) * 4 + (lr & 3);
-        kf[f] = *reinterpret_cast<const half8*>(kb + (int64_t)min(key, nk - 1) * kv_cpitch + k_coff + lg * 8);     // masked below when key >= nk
-    }
-    __syncthreads();
     const int nqf = (Lq + 15) / 16;
-    for (int qfi = wave; qfi < nqf; qfi += 4) {
-        const int iq = qfi * 16 + lr;
-        const half8 qv = *reinterpret_cast<const half8*>(q + ((int64_t)b * q_tok + min(iq, Lq - 1)) * q_cpitch + q_coff + h * 32 + lg * 8);
-        float4v_dd sacc[16];
-        float mx = -INFINITY;
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    float4v_dd o0_run[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, o1_run[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int chk = 0; chk < nch; ++chk) {
+        const int k0 = (c * nch + chk) * MHA_KC, nk = min(MHA_KC, Lk - k0);
+        if (nk <= 0) break;                                    // block-uniform
+        const half_t* kb = kv + ((int64_t)b * kv_tok + k0) * kv_cpitch + h * 32;
+        if (chk) __syncthreads();                              // every wave is done with the previous chunk's V image
+        // V tile -> LDS, transposed: thread (key, chunk) scatters its 8 channels into 8 rows
+        for (int i = tid; i < MHA_KC * 4; i += 256) {
+            const int key = i >> 2, ch = i & 3;
+            half8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (half_t)0.f;
+            if (key < nk) t = *reinterpret_cast<const half8*>(kb + (int64_t)key * kv_cpitch + v_coff + ch * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) VsT[(ch * 8 + e) * MHA_VP + key] = t[e];
+        }
+        // K fragments of the whole chunk in registers: 16 fragments x 16 B per lane
+        half8 kf[16];
 #pragma unroll
         for (int f = 0; f < 16; ++f) {
-            sacc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[f], qv, float4v_dd{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            const int key = 32 * (f >> 1) + (lr >> 2) * 8 + (f & 1) * 4 + (lr & 3);
+            kf[f] = *reinterpret_cast<const half8*>(kb + (int64_t)min(key, nk - 1) * kv_cpitch + k_coff + lg * 8);     // masked below when key >= nk
+        }
+        __syncthreads();
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = 32 * (f >> 1) + lg * 8 + (f & 1) * 4 + r;
-                sacc[f][r] = key < nk ? sacc[f][r] * scale : -INFINITY;
-                mx = fmaxf(mx, sacc[f][r]);
+        for (int slot = 0; slot < 2; ++slot) {
+            const int qfi = wave + slot * 4;
+            if (qfi >= nqf) continue;                          // wave-uniform
+            const int iq = qfi * 16 + lr;
+            const half8 qv = *reinterpret_cast<const half8*>(q + ((int64_t)b * q_tok + min(iq, Lq - 1)) * q_cpitch + q_coff + h * 32 + lg * 8);
+            float4v_dd sacc[16];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int f = 0; f < 16; ++f) {
+                sacc[f] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[f], qv, float4v_dd{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = 32 * (f >> 1) + lg * 8 + (f & 1) * 4 + r;
+                    sacc[f][r] = key < nk ? sacc[f][r] * scale : -INFINITY;
+                    mx = fmaxf(mx, sacc[f][r]);
+                }
             }
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 16));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float l = 0.f;
-        float4v_dd o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+            mx = fmaxf(mx, __shfl_xor(mx, 16));
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run[slot], mx);        // finite: a chunk has at least one key
+            const float alpha = __expf(m_run[slot] - m_new);   // exp(-inf) = 0 on the first chunk
+            float l = 0.f;
+            float4v_dd o0 = o0_run[slot], o1 = o1_run[slot];
 #pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) {
-            half8 pf;
+            for (int r = 0; r < 4; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float pv = __expf(sacc[2 * s2 + (j >> 2)][j & 3] - mx);
-                l += pv;
-                pf[j] = (half_t)pv;
+            for (int s2 = 0; s2 < 8; ++s2) {
+                half8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float pv = __expf(sacc[2 * s2 + (j >> 2)][j & 3] - m_new);
+                    l += pv;
+                    pf[j] = (half_t)pv;
+                }
+                const half8 v0 = *reinterpret_cast<const half8*>(&VsT[lr * MHA_VP + s2 * 32 + lg * 8]);
+                const half8 v1 = *reinterpret_cast<const half8*>(&VsT[(16 + lr) * MHA_VP + s2 * 32 + lg * 8]);
+                o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0, pf, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, pf, o1, 0, 0, 0);
             }
-            const half8 v0 = *reinterpret_cast<const half8*>(&VsT[lr * MHA_VP + s2 * 32 + lg * 8]);
-            const half8 v1 = *reinterpret_cast<const half8*>(&VsT[(16 + lr) * MHA_VP + s2 * 32 + lg * 8]);
-            o0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v0, pf, o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(v1, pf, o1, 0, 0, 0);
+            l += __shfl_xor(l, 16);
+            l += __shfl_xor(l, 32);
+            m_run[slot] = m_new;
+            l_run[slot] = l_run[slot] * alpha + l;
+            o0_run[slot] = o0;
+            o1_run[slot] = o1;
         }
-        l += __shfl_xor(l, 16);
-        l += __shfl_xor(l, 32);
-        if (iq < Lq) {
-            float* op = part + ((((int64_t)b * heads + h) * nsplit + c) * Lq + iq) * 34;
-            if (lg == 0) { op[0] = mx; op[1] = l; }
+    }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { op[2 + lg * 4 + r] = o0[r]; op[2 + 16 + lg * 4 + r] = o1[r]; }
-        }
+    for (int slot = 0; slot < 2; ++slot) {
+        const int qfi = wave + slot * 4, iq = qfi * 16 + lr;
+        if (qfi >= nqf || iq >= Lq) continue;
+        float* op = part + ((((int64_t)b * heads + h) * nsplit + c) * Lq + iq) * 34;
+        if (lg == 0) { op[0] = m_run[slot]; op[1] = l_run[slot]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { op[2 + lg * 4 + r] = o0_run[slot][r]; op[2 + 16 + lg * 4 + r] = o1_run[slot][r]; }
     }
 }
 
@@ -801,14 +824,23 @@ __global__ void mha32_merge_kernel(const float* __restrict__ part, half_t* __res
 int mha32_nsplit(int Lk) { return (Lk + MHA_KC - 1) / MHA_KC; }
 int launch_mha32_split(const half_t* q, int q_cpitch, int q_coff, int q_tok, const half_t* kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,
                        half_t* o, int o_cpitch, int o_coff, int o_tok, float* part, int B, int heads, int Lq, int Lk, float scale, hipStream_t s) {
-    const int nsplit = mha32_nsplit(Lk);
+    const int nchunks = mha32_nsplit(Lk);                                     // 256-key chunks; the partial-state buffer is sized for one split per chunk
     static const bool v1 = getenv("HAVC_MHA_V1") != nullptr;                  // A/B switch (profiling): the one-thread-per-query kernel
+    static const int nch_env = [] { const char* e = getenv("HAVC_MHA_NCH"); return e ? atoi(e) : 0; }();       // A/B: chunks per block (0 = automatic)
+    // chunks per block: as many (<= 4) as keep >= 1 024 blocks in flight (one frame of the coarse level stays at one chunk per block)
+    int nch = 1;
+    if (!v1) {
+        const int64_t blocks1 = (int64_t)nchunks * heads * B;
+        nch = nch_env > 0 ? nch_env : (int)std::min<int64_t>(4, std::max<int64_t>(1, blocks1 / 1024));
+        nch = std::max(1, std::min(nch, nchunks));
+    }
+    const int nsplit = (nchunks + nch - 1) / nch;
     if (v1)
         hipLaunchKernelGGL(mha32_split_kernel, dim3(nsplit, heads, B), dim3(128), 0, s, q, q_cpitch, q_coff, q_tok, kv, kv_cpitch, k_coff, v_coff, kv_tok,
                            part, heads, Lq, Lk, scale);
     else
         hipLaunchKernelGGL(mha32_split_mfma_kernel, dim3(nsplit, heads, B), dim3(256), 0, s, q, q_cpitch, q_coff, q_tok, kv, kv_cpitch, k_coff, v_coff,
-                           kv_tok, part, heads, Lq, Lk, scale);
+                           kv_tok, part, heads, Lq, Lk, scale, nch);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(mha32_merge_kernel, dim3(grid_for_dd((int64_t)B * heads * Lq * 4)), dim3(256), 0, s, part, o, o_cpitch, o_coff, o_tok, B, heads,
