@@ -2,6 +2,7 @@
 // Integer arithmetic follows OpenCV's 8-bit BT.601 "YUV" fixed point (yuv_shift = 14) and Pillow's
 // ImagingBlend exactly (bit-exact targets; see oracle/cvcolor.py, oracle/imaging.py).
 #include "kernels.h"
+#include <cstdlib>
 
 static inline int grid_for(int64_t work) {
     int64_t b = (work + 255) / 256;
@@ -162,6 +163,60 @@ __global__ void __launch_bounds__(256) resize_h_kernel(const uint8_t* __restrict
     }
 }
 
+// Round 4: the same pass with the taps in REGISTERS.  resize_h_kernel above fetches w[x * taps + t] inside the tap loop: 64 lanes, 64 different cache
+// lines per load instruction, 87 such instructions per output row segment -- the texture-address unit, not the arithmetic, set its 3.0 ms per 64
+// squashed 1080p frames.  Here a thread owns ONE output column of a 256-column tile for a chunk of rows: its taps and its (edge-clamped) byte
+// offsets are loaded once, the tile's source span of each row is staged in LDS, and the tap loop is LDS byte reads + the same mul / add sequence
+// (ascending taps, product rounded before the add): bit-identical to resize_h_kernel.  TMAX bounds the unrolled tap loop (taps <= TMAX).
+template <int TMAX>
+__global__ void __launch_bounds__(256) resize_h_rows_kernel(const uint8_t* __restrict__ src, float* __restrict__ tmp, const int* __restrict__ start,
+                                                            const float* __restrict__ wts, int taps, int sw, int dw, int64_t rows, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rowbuf[];
+    const int x0 = blockIdx.x * 256, x = x0 + threadIdx.x;
+    const bool active = x < dw;
+    const int xl = min(x0 + 255, dw - 1);
+    int lo = start[x0], hi = start[xl] + taps - 1;             // the tile's source span (start[] ascends with x)
+    lo = lo < 0 ? 0 : (lo >= sw ? sw - 1 : lo);
+    hi = hi < 0 ? 0 : (hi >= sw ? sw - 1 : hi);
+    const int span_bytes = (hi - lo + 1) * 3;
+    float w[TMAX];
+    int off[TMAX];
+    {
+        const int s0 = active ? start[x] : 0;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            w[t] = (active && t < taps) ? wts[(int64_t)x * taps + t] : 0.f;
+            int sx = s0 + t;
+            sx = sx < 0 ? 0 : (sx >= sw ? sw - 1 : sx);
+            sx = sx < lo ? lo : (sx > hi ? hi : sx);               // (inactive lanes / t >= taps: any address inside the span)
+            off[t] = (sx - lo) * 3;
+        }
+    }
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+    for (int64_t row = r0; row < r1; ++row) {
+        const uint8_t* sp = src + (row * sw + lo) * 3;
+        const int a0 = (int)(reinterpret_cast<uintptr_t>(sp) & 3);
+        const uint32_t* wp = reinterpret_cast<const uint32_t*>(sp - a0);
+        const int nwords = (a0 + span_bytes + 3) >> 2;            // an over-read stays inside the last aligned dword of the span's row
+        __syncthreads();
+        for (int i = threadIdx.x; i < nwords; i += 256) reinterpret_cast<uint32_t*>(rowbuf)[i] = wp[i];
+        __syncthreads();
+        if (!active) continue;
+        const unsigned char* rb = rowbuf + a0;
+        float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            if (t < taps) {
+                const unsigned char* q = rb + off[t];
+                const float wt = w[t];
+                r += wt * q[0]; g += wt * q[1]; b += wt * q[2];
+            }
+        }
+        float* o = tmp + (row * dw + x) * 3;
+        o[0] = r; o[1] = g; o[2] = b;
+    }
+}
+
 // pass 2 (vertical): float [n][sh][dw][3] -> u8 [n][dh][dw][3]; if orig != null, fuse chroma_post_process
 // (vsfilters.py:863-899 -> imfilters.py:312-321): keep luma of orig, take U,V of the resampled colour.
 // A thread produces VR consecutive output rows of one column: their tap windows overlap almost entirely (the window start
@@ -226,10 +281,30 @@ int launch_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* dst, int d
                          const int* h_start, const float* h_w, int h_taps, const int* v_start, const float* v_w,
                          int v_taps, const uint8_t* orig, hipStream_t s) {
     const int64_t rows = (int64_t)n_frames * sh;
-    const size_t lds = (size_t)(sw * 3 + 8 + 15) & ~(size_t)15;
-    if (lds > 64 * 1024) return (int)hipErrorInvalidValue;            // rows beyond 21 800 pixels: not a video frame
-    hipLaunchKernelGGL(resize_h_kernel, dim3((unsigned)(rows < 65535 * 16 ? rows : 65535 * 16)), dim3(256), lds, s, src, tmp, h_start, h_w,
-                       h_taps, sw, dw, rows);
+    static const bool old_h = getenv("HAVC_RESIZE_V1") != nullptr;             // A/B switch (profiling): the one-block-per-row horizontal pass
+    // source span of a 256-column tile: 256 outputs step (sw / dw) source pixels each, plus the taps
+    const size_t span_px = (size_t)((255.0 * sw) / dw) + h_taps + 4;
+    const size_t lds_t = (span_px * 3 + 8 + 15) & ~(size_t)15;
+    if (!old_h && h_taps <= 48 && lds_t <= 48 * 1024) {
+        const int xt = (dw + 255) / 256;
+        // 16 rows per block amortise the per-thread tap loads; a single frame (ColorMNet: one squash per call) does not fill the chip that way and
+        // keeps the one-block-per-row pass (measured: c5 -0.7 % with one row per block here)
+        const int rpb = 16;
+        const int64_t chunks = (rows + rpb - 1) / rpb;
+        if (chunks * xt >= 2048 && chunks <= 65535) {
+            if (h_taps <= 12) hipLaunchKernelGGL(resize_h_rows_kernel<12>, dim3(xt, (unsigned)chunks), dim3(256), lds_t, s, src, tmp, h_start, h_w, h_taps, sw, dw, rows, rpb);
+            else if (h_taps <= 32) hipLaunchKernelGGL(resize_h_rows_kernel<32>, dim3(xt, (unsigned)chunks), dim3(256), lds_t, s, src, tmp, h_start, h_w, h_taps, sw, dw, rows, rpb);
+            else hipLaunchKernelGGL(resize_h_rows_kernel<48>, dim3(xt, (unsigned)chunks), dim3(256), lds_t, s, src, tmp, h_start, h_w, h_taps, sw, dw, rows, rpb);     // 1080p -> 384 x 216 (ColorMNet): 41 taps
+            goto vertical;
+        }
+    }
+    {
+        const size_t lds = (size_t)(sw * 3 + 8 + 15) & ~(size_t)15;
+        if (lds > 64 * 1024) return (int)hipErrorInvalidValue;            // rows beyond 21 800 pixels: not a video frame
+        hipLaunchKernelGGL(resize_h_kernel, dim3((unsigned)(rows < 65535 * 16 ? rows : 65535 * 16)), dim3(256), lds, s, src, tmp, h_start, h_w,
+                           h_taps, sw, dw, rows);
+    }
+vertical:
     const int groups = (dh + VR - 1) / VR;
     hipLaunchKernelGGL(resize_v_kernel, dim3(grid_for((int64_t)n_frames * groups * dw)), dim3(256), 0, s, tmp, dst, orig,
                        v_start, v_w, v_taps, sh, dh, dw, n_frames);
