@@ -277,6 +277,77 @@ __global__ void __launch_bounds__(256) resize_v_kernel(const float* __restrict__
     }
 }
 
+// Round 4: the vertical pass with FOUR consecutive pixels per thread (dw % 4 == 0, dword-aligned images): a tap row is three 16-byte loads of the
+// fp32 intermediate instead of twelve scalar ones, the source-luma pixels and the result are three dwords each instead of twelve byte accesses.
+// Per output the same taps in the same order with the same mul / add sequence as resize_v_kernel: bit-identical.
+__global__ void __launch_bounds__(256) resize_v4_kernel(const float* __restrict__ tmp, uint8_t* __restrict__ dst, const uint8_t* __restrict__ orig,
+                                                        const int* __restrict__ start, const float* __restrict__ wts, int taps, int sh, int dh,
+                                                        int dw, int n_frames) {
+    const int groups = (dh + VR - 1) / VR, dw4 = dw >> 2;
+    const int64_t total = (int64_t)n_frames * groups * dw4;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % dw4) * 4;
+        const int gy = (int)((i / dw4) % groups);
+        const int f = (int)(i / ((int64_t)dw4 * groups));
+        const int y0 = gy * VR;
+        int s0[VR];
+        float acc[VR][12];
+        int lo = 0x7fffffff, hi = -0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < VR; ++k) {
+            const int y = y0 + k < dh ? y0 + k : dh - 1;
+            s0[k] = start[y];
+            lo = s0[k] < lo ? s0[k] : lo;
+            hi = s0[k] + taps - 1 > hi ? s0[k] + taps - 1 : hi;
+#pragma unroll
+            for (int j = 0; j < 12; ++j) acc[k][j] = 0.f;
+        }
+        const float* base = tmp + (int64_t)f * sh * dw * 3 + (int64_t)x * 3;
+        for (int su = lo; su <= hi; ++su) {
+            const int sy = su < 0 ? 0 : (su >= sh ? sh - 1 : su);
+            const float4* p4 = reinterpret_cast<const float4*>(base + (int64_t)sy * dw * 3);
+            const float4 a = p4[0], b = p4[1], c = p4[2];
+            const float p[12] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w};
+#pragma unroll
+            for (int k = 0; k < VR; ++k) {
+                const int t = su - s0[k];
+                if (t >= 0 && t < taps) {
+                    const int y = y0 + k < dh ? y0 + k : dh - 1;
+                    const float wt = wts[(int64_t)y * taps + t];
+#pragma unroll
+                    for (int j = 0; j < 12; ++j) acc[k][j] += wt * p[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VR; ++k) {
+            const int y = y0 + k;
+            if (y >= dh) break;
+            const int64_t o = ((int64_t)(f * dh + y) * dw + x) * 3;
+            int v[12];
+#pragma unroll
+            for (int j = 0; j < 12; ++j) v[j] = sat8((int)floorf(acc[k][j] + 0.5f));
+            if (orig) {
+                const uint32_t* op = reinterpret_cast<const uint32_t*>(orig + o);
+                const uint32_t o0 = op[0], o1 = op[1], o2 = op[2];
+                const int ob[12] = {(int)(o0 & 255), (int)((o0 >> 8) & 255), (int)((o0 >> 16) & 255), (int)(o0 >> 24), (int)(o1 & 255), (int)((o1 >> 8) & 255),
+                                    (int)((o1 >> 16) & 255), (int)(o1 >> 24), (int)(o2 & 255), (int)((o2 >> 8) & 255), (int)((o2 >> 16) & 255), (int)(o2 >> 24)};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    int yy, u, vv, y2, u2, v2;
+                    rgb2yuv(v[q * 3], v[q * 3 + 1], v[q * 3 + 2], yy, u, vv);
+                    rgb2yuv(ob[q * 3], ob[q * 3 + 1], ob[q * 3 + 2], y2, u2, v2);
+                    yuv2rgb(y2, u, vv, v[q * 3], v[q * 3 + 1], v[q * 3 + 2]);
+                }
+            }
+            uint32_t* dp = reinterpret_cast<uint32_t*>(dst + o);
+            dp[0] = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+            dp[1] = (uint32_t)v[4] | ((uint32_t)v[5] << 8) | ((uint32_t)v[6] << 16) | ((uint32_t)v[7] << 24);
+            dp[2] = (uint32_t)v[8] | ((uint32_t)v[9] << 8) | ((uint32_t)v[10] << 16) | ((uint32_t)v[11] << 24);
+        }
+    }
+}
+
 int launch_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh, int n_frames, float* tmp,
                          const int* h_start, const float* h_w, int h_taps, const int* v_start, const float* v_w,
                          int v_taps, const uint8_t* orig, hipStream_t s) {
@@ -306,8 +377,14 @@ int launch_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* dst, int d
     }
 vertical:
     const int groups = (dh + VR - 1) / VR;
-    hipLaunchKernelGGL(resize_v_kernel, dim3(grid_for((int64_t)n_frames * groups * dw)), dim3(256), 0, s, tmp, dst, orig,
-                       v_start, v_w, v_taps, sh, dh, dw, n_frames);
+    const bool quad = !old_h && (dw & 3) == 0 && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(orig)) & 3) == 0 &&
+                      (reinterpret_cast<uintptr_t>(tmp) & 15) == 0;
+    if (quad)
+        hipLaunchKernelGGL(resize_v4_kernel, dim3(grid_for((int64_t)n_frames * groups * (dw >> 2))), dim3(256), 0, s, tmp, dst, orig,
+                           v_start, v_w, v_taps, sh, dh, dw, n_frames);
+    else
+        hipLaunchKernelGGL(resize_v_kernel, dim3(grid_for((int64_t)n_frames * groups * dw)), dim3(256), 0, s, tmp, dst, orig,
+                           v_start, v_w, v_taps, sh, dh, dw, n_frames);
     return (int)hipGetLastError();
 }
 
