@@ -146,7 +146,6 @@ __global__ void __launch_bounds__(256) resize_h_kernel(const uint8_t* __restrict
         __syncthreads();
         for (int i = threadIdx.x; i < nwords; i += 256) reinterpret_cast<uint32_t*>(rowbuf)[i] = wp[i];
         __syncthreads();
-        const unsigned char* rb = rowbuf + a0;
         for (int x = threadIdx.x; x < dw; x += 256) {
             const int s0 = start[x];
             const float* w = wts + (int64_t)x * taps;
@@ -155,7 +154,11 @@ __global__ void __launch_bounds__(256) resize_h_kernel(const uint8_t* __restrict
                 int sx = s0 + t;
                 sx = sx < 0 ? 0 : (sx >= sw ? sw - 1 : sx);
                 const float wt = w[t];
-                r += wt * rb[sx * 3]; g += wt * rb[sx * 3 + 1]; b += wt * rb[sx * 3 + 2];
+                // the pixel's three bytes through one aligned two-dword LDS read + v_alignbyte (byte / unaligned halfword LDS reads cost ~30 clocks each)
+                const unsigned addr = (unsigned)(a0 + sx * 3);
+                const uint32_t* pw = reinterpret_cast<const uint32_t*>(rowbuf + (addr & ~3u));
+                const uint32_t px = __builtin_amdgcn_alignbyte(pw[1], pw[0], addr & 3u);
+                r += wt * (float)(px & 255u); g += wt * (float)((px >> 8) & 255u); b += wt * (float)((px >> 16) & 255u);
             }
             float* o = tmp + (row * dw + x) * 3;
             o[0] = r; o[1] = g; o[2] = b;
@@ -170,7 +173,7 @@ __global__ void __launch_bounds__(256) resize_h_kernel(const uint8_t* __restrict
 // (ascending taps, product rounded before the add): bit-identical to resize_h_kernel.  TMAX bounds the unrolled tap loop (taps <= TMAX).
 template <int TMAX>
 __global__ void __launch_bounds__(256) resize_h_rows_kernel(const uint8_t* __restrict__ src, float* __restrict__ tmp, const int* __restrict__ start,
-                                                            const float* __restrict__ wts, int taps, int sw, int dw, int64_t rows, int rows_per_block) {
+                                                            const float* __restrict__ wts, int taps, int sw, int dw, int64_t rows, int rows_per_block, int out_off, int vec_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rowbuf[];
     const int x0 = blockIdx.x * 256, x = x0 + threadIdx.x;
     const bool active = x < dw;
@@ -193,27 +196,56 @@ __global__ void __launch_bounds__(256) resize_h_rows_kernel(const uint8_t* __res
         }
     }
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-    for (int64_t row = r0; row < r1; ++row) {
+    // The span of row r + 1 is fetched into registers (<= 4 dwords per thread: spans up to 4 KiB) while row r is multiplied: the staging loop of the first
+    // version waited for every pair of loads before the LDS write -- two or three exposed memory latencies per row, 17 000 clocks per row on the counters.
+    uint32_t pre[4];
+    int a0 = 0;
+    auto fetch = [&](int64_t row) {
         const uint8_t* sp = src + (row * sw + lo) * 3;
-        const int a0 = (int)(reinterpret_cast<uintptr_t>(sp) & 3);
+        a0 = (int)(reinterpret_cast<uintptr_t>(sp) & 3);
         const uint32_t* wp = reinterpret_cast<const uint32_t*>(sp - a0);
         const int nwords = (a0 + span_bytes + 3) >> 2;            // an over-read stays inside the last aligned dword of the span's row
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + k * 256;
+            pre[k] = i < nwords ? wp[i] : 0u;
+        }
+    };
+    fetch(r0);
+    for (int64_t row = r0; row < r1; ++row) {
+        const int a0_row = a0;
+        __syncthreads();                                           // the previous row's taps and its output tile are read
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i * 4 < out_off) reinterpret_cast<uint32_t*>(rowbuf)[i] = pre[k];
+        }
         __syncthreads();
-        for (int i = threadIdx.x; i < nwords; i += 256) reinterpret_cast<uint32_t*>(rowbuf)[i] = wp[i];
-        __syncthreads();
-        if (!active) continue;
-        const unsigned char* rb = rowbuf + a0;
+        if (row + 1 < r1) fetch(row + 1);
         float r = 0.f, g = 0.f, b = 0.f;
+        // every one of the TMAX taps, no test: taps beyond the table's count carry weight 0 (x + 0 * q == x: same bits) -- the LDS reads of a
+        // row can then be issued together instead of one latency per tap
+        // a pixel = the three bytes at an arbitrary byte address: ONE aligned two-dword read + v_alignbyte instead of byte / halfword reads (the
+        // compiler merged q[0], q[1] into ds_read_u16 at odd addresses: ~30 clocks per LDS instruction on the counters, and the pass scaled with them)
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
-            if (t < taps) {
-                const unsigned char* q = rb + off[t];
-                const float wt = w[t];
-                r += wt * q[0]; g += wt * q[1]; b += wt * q[2];
-            }
+            const unsigned addr = (unsigned)(a0_row + off[t]);
+            const uint32_t* pw = reinterpret_cast<const uint32_t*>(rowbuf + (addr & ~3u));
+            const uint32_t px = __builtin_amdgcn_alignbyte(pw[1], pw[0], addr & 3u);
+            const float wt = w[t];
+            r += wt * (float)(px & 255u); g += wt * (float)((px >> 8) & 255u); b += wt * (float)((px >> 16) & 255u);
         }
-        float* o = tmp + (row * dw + x) * 3;
-        o[0] = r; o[1] = g; o[2] = b;
+        if (vec_out) {            // dw % 4 == 0: the tile's 3 x 256 floats leave through LDS as 16-byte stores
+            float* ob = reinterpret_cast<float*>(rowbuf + out_off);
+            ob[threadIdx.x * 3] = r; ob[threadIdx.x * 3 + 1] = g; ob[threadIdx.x * 3 + 2] = b;
+            __syncthreads();
+            const int nvec = (min(256, dw - x0) * 3) >> 2;
+            if ((int)threadIdx.x < nvec)
+                reinterpret_cast<float4*>(tmp + (row * dw + x0) * 3)[threadIdx.x] = reinterpret_cast<const float4*>(ob)[threadIdx.x];
+        } else if (active) {
+            float* o = tmp + (row * dw + x) * 3;
+            o[0] = r; o[1] = g; o[2] = b;
+        }
     }
 }
 
@@ -356,16 +388,23 @@ int launch_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* dst, int d
     // source span of a 256-column tile: 256 outputs step (sw / dw) source pixels each, plus the taps
     const size_t span_px = (size_t)((255.0 * sw) / dw) + h_taps + 4;
     const size_t lds_t = (span_px * 3 + 8 + 15) & ~(size_t)15;
-    if (!old_h && h_taps <= 48 && lds_t <= 48 * 1024) {
+    if (!old_h && h_taps <= 48 && lds_t <= 4096) {                           // (spans up to 4 KiB: four prefetched dwords per thread)
         const int xt = (dw + 255) / 256;
         // 16 rows per block amortise the per-thread tap loads; a single frame (ColorMNet: one squash per call) does not fill the chip that way and
         // keeps the one-block-per-row pass (measured: c5 -0.7 % with one row per block here)
         const int rpb = 16;
         const int64_t chunks = (rows + rpb - 1) / rpb;
         if (chunks * xt >= 2048 && chunks <= 65535) {
-            if (h_taps <= 12) hipLaunchKernelGGL(resize_h_rows_kernel<12>, dim3(xt, (unsigned)chunks), dim3(256), lds_t, s, src, tmp, h_start, h_w, h_taps, sw, dw, rows, rpb);
-            else if (h_taps <= 32) hipLaunchKernelGGL(resize_h_rows_kernel<32>, dim3(xt, (unsigned)chunks), dim3(256), lds_t, s, src, tmp, h_start, h_w, h_taps, sw, dw, rows, rpb);
-            else hipLaunchKernelGGL(resize_h_rows_kernel<48>, dim3(xt, (unsigned)chunks), dim3(256), lds_t, s, src, tmp, h_start, h_w, h_taps, sw, dw, rows, rpb);     // 1080p -> 384 x 216 (ColorMNet): 41 taps
+            const int vec_out = ((dw & 3) == 0 && (reinterpret_cast<uintptr_t>(tmp) & 15) == 0) ? 1 : 0;
+            const int out_off = (int)lds_t;                                    // [256][3] floats behind the staged span
+            const size_t lds_all = lds_t + 256 * 3 * sizeof(float);
+#define HAVC_RH(T) hipLaunchKernelGGL(resize_h_rows_kernel<T>, dim3(xt, (unsigned)chunks), dim3(256), lds_all, s, src, tmp, h_start, h_w, h_taps, sw, dw, rows, rpb, out_off, vec_out)
+            if (h_taps <= 9) HAVC_RH(9);              // every up-sampling pass
+            else if (h_taps <= 17) HAVC_RH(17);
+            else if (h_taps <= 29) HAVC_RH(29);       // 1920 -> 560 (c2), 1920 -> 512 is 31 taps
+            else if (h_taps <= 32) HAVC_RH(32);
+            else HAVC_RH(48);                         // 1920 -> 384 (c4): 41 taps
+#undef HAVC_RH
             goto vertical;
         }
     }
