@@ -1,5 +1,5 @@
 """Per-kernel summary of the TIMED steps of a rocprofv3 --kernel-trace run of bench.py (the raw --stats file also counts the
-autotuner's trial launches and the warm-up).  A bench step starts with resize_h_kernel (Spline64 squash) and holds two of them
+autotuner's trial launches and the warm-up).  A bench step starts with resize_h_kernel / resize_h_rows_kernel (Spline64 squash) and holds two of them
 (down, up): kernels from the (2 * warmup)-th resize_h launch on are the timed region.
    python tools/trace_summary.py <kernel_trace.csv> <warmup> > profiles/..."""
 import csv, sys, collections
@@ -7,7 +7,7 @@ import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 warm = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("resize_h_kernel")]
+starts = [i for i, r in enumerate(rows) if "resize_h_kernel" in r["Kernel_Name"] or "resize_h_rows_kernel" in r["Kernel_Name"]]
 first = starts[2 * warm] if len(starts) > 2 * warm else 0
 sel = rows[first:]
 agg = collections.OrderedDict()
