@@ -71,6 +71,10 @@ __device__ __forceinline__ void epilogue_frag_precise(const ConvArgs& p, const f
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : (leaky ? v[r] * p.f2 : 0.f);
     }
+    if (p.flags & HAVC_F_GELU) {                               // nn.GELU() in its exact form, libm erff (the fast path's 1.5e-7 polynomial is for fp16 results)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = 0.5f * v[r] * (1.f + erff(v[r] * 0.70710678118654752f));
+    }
     if (p.flags & HAVC_F_AFFINE) {
         const float4 sc = *reinterpret_cast<const float4*>(p.scale + n);
         const float4 sh = *reinterpret_cast<const float4*>(p.shift + n);

@@ -383,7 +383,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             if (a.splitk == 1) a.splitk = 0;
             a.pscale = 1.f;
             if (op.flags & HAVC_F_PRECISE) {
-                if ((op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_FUSE_PROJ | HAVC_F_OUT_TRANSPOSED | HAVC_F_W_FROM_BUF | HAVC_F_GELU)) || a.splitk ||
+                if ((op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_FUSE_PROJ | HAVC_F_OUT_TRANSPOSED | HAVC_F_W_FROM_BUF)) || a.splitk ||
                     !(op.f3 > 0.f) || (op.src_cpitch & 15) || (!(op.flags & HAVC_F_OUT_RGB8) && (op.dst_cpitch & 15)))
                     return fail(c, HAVC_E_INVALID, "conv op: PRECISE needs a plain conv (no fused / transposed / split-K form), f3 = accumulator scale > 0, hi|lo pixel rows");
                 a.pscale = op.f3;
@@ -533,13 +533,23 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             }
             e = launch_prep_rgb8((const uint8_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
                                  op.src2 >= 0 ? (half_t*)bufptr(n, op.src2) : nullptr, op.res_cpitch, op.res_coff,
-                                 (int64_t)batch * op.Hi * op.Wi, s);
+                                 (int64_t)batch * op.Hi * op.Wi, s, op.aux0 > 0 && op.res_coff + 8 + op.aux0 <= op.res_cpitch ? op.aux0 : 0);
             break;
         case HAVC_OP_SUBSAMPLE2:
+            if (op.flags & HAVC_F_PRECISE) {
+                e = launch_subsample2_p((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), batch, op.Ho, op.Wo, op.Hi, op.Wi, op.Ci,
+                                        op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff, s);
+                break;
+            }
             e = launch_subsample2((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), batch, op.Ho, op.Wo, op.Hi, op.Wi, op.Ci,
                                   op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff, s);
             break;
         case HAVC_OP_PROJ2:
+            if (op.flags & HAVC_F_PRECISE) {
+                e = launch_proj2_p((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, op.Ci, wptr<float>(n, op.w_off), wptr<float>(n, op.bias_off),
+                                   op.flags & 3, op.f0, (float*)bufptr(n, op.dst), (int64_t)batch * op.Hi * op.Wi, s);
+                break;
+            }
             e = launch_proj2((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, op.Ci, wptr<float>(n, op.w_off),
                              wptr<float>(n, op.bias_off), op.flags, op.f0, (float*)bufptr(n, op.dst), (int64_t)batch * op.Hi * op.Wi, s);
             break;
@@ -548,10 +558,15 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             break;
         case HAVC_OP_PREP_LAB_L:
             e = launch_prep_lab_l((const uint8_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
-                                  (int64_t)batch * op.Hi * op.Wi, s);
+                                  (int64_t)batch * op.Hi * op.Wi, s, (op.flags & HAVC_F_PRECISE) ? op.dst_cpitch >> 1 : 0);
             break;
         case HAVC_OP_DWCONV7:
             if (op.w_off < 0 || (op.Ci & 7)) return fail(c, HAVC_E_INVALID, "dwconv7 op: weights / channel count");
+            if (op.flags & HAVC_F_PRECISE) {                   // fp32 weights [49][Kc]
+                e = launch_dwconv7_p((const half_t*)bufptr(n, op.src), wptr<float>(n, op.w_off), wptr<float>(n, op.bias_off), (half_t*)bufptr(n, op.dst), batch,
+                                     op.Hi, op.Wi, op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff, op.Kc, s);
+                break;
+            }
             e = launch_dwconv7((const half_t*)bufptr(n, op.src), wptr<half_t>(n, op.w_off), wptr<float>(n, op.bias_off), (half_t*)bufptr(n, op.dst),
                                batch, op.Hi, op.Wi, op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff, op.Kc, s);
             break;
@@ -566,10 +581,25 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             if (op.w_off < 0 || op.Ho < 1 || op.Ho > op.Kc || op.Ho > op.Wi || (op.Ci & 7) || n->bufdesc[op.dst].elem_bytes != 4 ||
                 (uint64_t)n->bufdesc[op.dst].elems_per_frame < (uint64_t)2 * op.Ci)
                 return fail(c, HAVC_E_INVALID, "fold-queries op: R weights, query count, fp32 [2][Ci] destination");
+            if (op.flags & HAVC_F_PRECISE) {
+                e = launch_fold_queries_p((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, op.Wi, wptr<float>(n, op.w_off), op.Kc, op.Ho,
+                                          (float*)bufptr(n, op.dst), batch, op.Ci, s);
+                break;
+            }
             e = launch_fold_queries((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, op.Wi, wptr<float>(n, op.w_off), op.Kc, op.Ho,
                                     (float*)bufptr(n, op.dst), batch, op.Ci, s);
             break;
         case HAVC_OP_SHUF4_BLUR_AB:
+            if (op.flags & HAVC_F_PRECISE) {
+                // precise form: src = the last_shuf conv's pair tensor [Hi][Wi][16 x 256], aux0 = the folded projection (fp32 [2][256] per frame, FOLD_QUERIES)
+                if (op.w_off < 0 || op.bias_off < 0 || op.src2 < 0 || op.aux0 < 0 || op.aux0 >= (int)n->bufs.size() || n->bufdesc[op.aux0].elem_bytes != 4 ||
+                    (uint64_t)n->bufdesc[op.aux0].elems_per_frame < 512 || n->bufdesc[op.src].elem_bytes != 2 || op.Ci != 16 * 256)
+                    return fail(c, HAVC_E_INVALID, "shuffle+blur(ab) op, precise: weights, image view, projection buffer (aux0), 4096-channel pair source");
+                e = launch_shuf4_blur_proj_p((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, (const float*)bufptr(n, op.aux0),
+                                             (const half_t*)bufptr(n, op.src2), op.res_cpitch, op.res_coff, wptr<float>(n, op.w_off), wptr<float>(n, op.bias_off),
+                                             (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff, batch, op.Hi, op.Wi, s);
+                break;
+            }
             if (op.w_off < 0 || op.bias_off < 0 || op.src2 < 0 || n->bufdesc[op.src].elem_bytes != 4 ||
                 (uint64_t)n->bufdesc[op.src].elems_per_frame < (uint64_t)op.Hi * op.Wi * 32)
                 return fail(c, HAVC_E_INVALID, "shuffle+blur(ab) op: weights, image view, fp32 [Hi*Wi][16][2] source");
@@ -579,12 +609,24 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             break;
         case HAVC_OP_LAYERNORM:
             if (op.scale_off < 0 || op.shift_off < 0) return fail(c, HAVC_E_INVALID, "layernorm op: gamma / beta");
+            if (op.flags & HAVC_F_PRECISE) {
+                e = launch_layernorm_p((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), wptr<float>(n, op.scale_off), wptr<float>(n, op.shift_off),
+                                       op.f0, (int64_t)batch * op.Hi * op.Wi, op.Ci, op.src_cpitch, op.src_coff, op.dst_cpitch, op.dst_coff,
+                                       (op.flags & HAVC_F_RELU_POST) ? 1 : 0, s);
+                break;
+            }
             e = launch_layernorm_c((const half_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), wptr<float>(n, op.scale_off),
                                    wptr<float>(n, op.shift_off), op.f0, (int64_t)batch * op.Hi * op.Wi, op.Ci, op.src_cpitch, op.src_coff,
                                    op.dst_cpitch, op.dst_coff, s, (op.flags & HAVC_F_RELU_POST) ? 1 : 0);
             break;
         case HAVC_OP_MHA:
             if (op.src2 < 0 || op.Ci != op.kh * 32) return fail(c, HAVC_E_INVALID, "mha op: K/V buffer, head dim 32");
+            if (op.flags & HAVC_F_PRECISE) {
+                e = launch_mha32_p((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, op.Wi, (const half_t*)bufptr(n, op.src2), op.res_cpitch,
+                                   op.res_coff, op.aux0, op.Wo, (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff, op.Wi, batch, op.kh, op.Hi, op.Ho,
+                                   op.f0, s);
+                break;
+            }
             if (op.aux1 >= 0 && op.aux1 < (int)n->bufs.size() && n->bufdesc[op.aux1].elem_bytes == 4) {
                 // keys split over blocks (K / V staged in LDS once per block), partial softmax states in the fp32 buffer aux1
                 if ((size_t)n->bufdesc[op.aux1].elems_per_frame < (size_t)op.kh * mha32_nsplit(op.Ho) * op.Hi * 34)
@@ -606,7 +648,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
         case HAVC_OP_PREP_DDCOLOR:
             e = launch_prep_ddcolor((const uint8_t*)bufptr(n, op.src), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
                                     op.src2 >= 0 ? (half_t*)bufptr(n, op.src2) : nullptr, op.res_cpitch, op.res_coff,
-                                    (int64_t)batch * op.Hi * op.Wi, s);
+                                    (int64_t)batch * op.Hi * op.Wi, s, (op.flags & HAVC_F_PRECISE) ? 1 : 0);
             break;
         case HAVC_OP_EW: {
             EwArgs a{};
@@ -858,7 +900,7 @@ static void preload_device_locked(int dev) {
     static uint64_t done = 0;                              // guarded by g_setup_mu
     if (done & (1ull << (dev & 63))) return;
     preload_conv_pipe(); preload_conv_igemm(); preload_elementwise(); preload_zhang(); preload_attention(); preload_colorfilters();
-    preload_tweaks(); preload_ddcolor(); preload_colormnet(); preload_colormnet_net(); preload_precise();
+    preload_tweaks(); preload_ddcolor(); preload_colormnet(); preload_colormnet_net(); preload_precise(); preload_precise2();
     hipFuncAttributes a;
     (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(scratch_warm_kernel));
     (void)hipGetLastError();
@@ -1632,7 +1674,9 @@ static int ddcolor_batch_locked(havc_ctx* c, havc_net* net, const uint8_t* d_in,
     net->in_override = nullptr;
     if (rc) return rc;
     c->stats.total_flops += net->flops_per_frame * b;
-    int e = launch_ddcolor_post(d_in, (const half_t*)net->bufs[net->out_buf], ab_pitch, 0, S, S, d_out_u8, d_out_planes, planes_half, b, width, height, c->stream);
+    const bool precise = !net->ops.empty() && (net->ops[0].flags & HAVC_F_PRECISE);          // precise nets: the ab map is a hi / lo pair tensor
+    int e = launch_ddcolor_post(d_in, (const half_t*)net->bufs[net->out_buf], ab_pitch, 0, S, S, d_out_u8, d_out_planes, planes_half, b, width, height, c->stream,
+                                precise ? ab_pitch >> 1 : 0);
     c->stats.launches++;
     if (e) return hip_fail(c, (hipError_t)e, "ddcolor post");
     return HAVC_OK;

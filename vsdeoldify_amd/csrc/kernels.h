@@ -62,13 +62,13 @@ int launch_affine(const half_t* x, half_t* y, const float* scale, const float* s
 int launch_copy_ch(const half_t* x, half_t* y, int64_t npix, int C, int x_cpitch, int x_coff, int y_cpitch,
                    int y_coff, hipStream_t s);
 int launch_prep_rgb8(const uint8_t* rgb, half_t* y0, int y0_cpitch, int y0_coff, half_t* y1, int y1_cpitch,
-                     int y1_coff, int64_t npix, hipStream_t s);
+                     int y1_coff, int64_t npix, hipStream_t s, int y1_fill = 0);   // y1_fill: pad channels behind y1's 8 that may be zeroed too
 int launch_subsample2(const half_t* x, half_t* y, int B, int Ho, int Wo, int Hi, int Wi, int C, int x_cpitch, int x_coff,
                       int y_cpitch, int y_coff, hipStream_t s);
 int launch_proj2(const half_t* x, int x_cpitch, int x_coff, int C, const float* w, const float* bias, int mode, float mul,
                  float* out, int64_t npix, hipStream_t s);
 int launch_bilinear2(const float* x, float* y, int B, int Hi, int Wi, int Ho, int Wo, float mul, hipStream_t s);
-int launch_prep_lab_l(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff, int64_t npix, hipStream_t s);
+int launch_prep_lab_l(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff, int64_t npix, hipStream_t s, int y_lo = 0);   // y_lo > 0: hi / lo pair (precise)
 // Pillow 8bpc resample passes (integer coefficient tables from the host) and the Zhang post-process
 int launch_pil_resize_passes(const uint8_t* src, int sw, int sh, uint8_t* tmp, uint8_t* dst, int dw, int dh, int n_frames,
                              const int* hb, const int* hk, int hks, const int* vb, const int* vk, int vks, hipStream_t s);
@@ -95,9 +95,9 @@ int launch_color_temporal_stabilizer(const uint8_t* const* frames, const double*
                                      hipStream_t s);
 // ddcolor.hip (+ the Lab wrapper kernels in zhang.hip)
 int launch_prep_ddcolor(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff, half_t* y2, int y2_cpitch, int y2_coff, int64_t npix,
-                        hipStream_t s);
+                        hipStream_t s, int precise = 0);
 int launch_ddcolor_post(const uint8_t* orig, const half_t* ab, int ab_cpitch, int ab_coff, int abH, int abW, uint8_t* out_u8, void* out_planes,
-                        int planes_half, int n_frames, int w, int h, hipStream_t s);
+                        int planes_half, int n_frames, int w, int h, hipStream_t s, int ab_lo = 0);          // ab_lo > 0: the ab map is a hi / lo pair tensor
 int launch_planar_f_to_rgb8(const void* planes, int is_half, uint8_t* rgb, int64_t npix, hipStream_t s);
 int launch_planar_to_rgb8(const uint8_t* planes, uint8_t* rgb, int64_t npix, hipStream_t s);
 int launch_rgb8_to_planar(const uint8_t* rgb, uint8_t* planes, int64_t npix, hipStream_t s);
@@ -193,6 +193,21 @@ int launch_blur_resize_p(const half_t* x, half_t* y, int B, int Hi, int Wi, int 
 int launch_affine_p(const half_t* x, half_t* y, const float* scale, const float* shift, int relu, int64_t npix, int C, int x_cpitch, int x_coff, int y_cpitch,
                     int y_coff, hipStream_t s);
 bool attention_p_supported(int d, int C);
+// precise2.hip: the non-conv ops of DDColor and the Zhang colorizers on hi / lo pairs
+int launch_proj2_p(const half_t* x, int x_cpitch, int x_coff, int C, const float* w, const float* bias, int mode, float mul, float* out, int64_t npix,
+                   hipStream_t s);
+int launch_layernorm_p(const half_t* x, half_t* y, const float* gamma, const float* beta, float eps, int64_t npix, int C, int x_cpitch, int x_coff,
+                       int y_cpitch, int y_coff, int relu, hipStream_t s);
+int launch_dwconv7_p(const half_t* x, const float* w, const float* bias, half_t* y, int B, int H, int W, int C, int x_cpitch, int x_coff, int y_cpitch,
+                     int y_coff, int w_pitch, hipStream_t s);
+int launch_mha32_p(const half_t* q, int q_cpitch, int q_coff, int q_tok, const half_t* kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok, half_t* o,
+                   int o_cpitch, int o_coff, int o_tok, int B, int heads, int Lq, int Lk, float scale, hipStream_t s);
+int launch_fold_queries_p(const half_t* e, int e_cpitch, int e_coff, int tok, const float* r, int r_pitch, int nq, float* out, int B, int C, hipStream_t s);
+int launch_shuf4_blur_proj_p(const half_t* x, int x_cpitch, int x_coff, const float* M, const half_t* img, int img_cpitch, int img_coff, const float* rimg,
+                             const float* bias, half_t* y, int y_cpitch, int y_coff, int B, int Hi, int Wi, hipStream_t s);
+int launch_subsample2_p(const half_t* x, half_t* y, int B, int Ho, int Wo, int Hi, int Wi, int C, int x_cpitch, int x_coff, int y_cpitch, int y_coff,
+                        hipStream_t s);
+void preload_precise2();
 int launch_attention_p(const half_t* qk, int qk_cpitch, int f_coff, int g_coff, int d, int64_t qk_fs, const half_t* h, int h_cpitch, int h_coff, int64_t h_fs,
                        const half_t* x, int x_cpitch, int x_coff, int64_t x_fs, half_t* out, int o_cpitch, int o_coff, int64_t o_fs, float* stats, int B, int N,
                        int C, float gamma, hipStream_t s);

@@ -25,19 +25,31 @@ __device__ __forceinline__ double rgb_to_L(int r, int g, int b) {
 
 // model input: u8 RGB -> (float32(L) - 50) / 100 in channel 0 of an 8-channel fp16 pixel (channels 1..7 zero:
 // siggraph17's ab hints and mask are zeros, siggraph17.py:129-132)
-__global__ void prep_lab_l_kernel(const uint8_t* __restrict__ rgb, half_t* __restrict__ y, int y_cpitch, int y_coff, int64_t npix) {
+// y_lo > 0 (precise mode, HAVC_F_PRECISE): the value is stored as a hi / lo fp16 pair, the lo plane y_lo elements behind the hi plane
+__device__ __forceinline__ void split_pair(float v, half_t& hi, half_t& lo) {
+    hi = (half_t)v;
+    lo = (half_t)((v - (float)hi) * 2048.f);
+}
+__global__ void prep_lab_l_kernel(const uint8_t* __restrict__ rgb, half_t* __restrict__ y, int y_cpitch, int y_coff, int64_t npix, int y_lo) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
         const float L = (float)rgb_to_L(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
-        half8 o;
+        half8 o, ol;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (half_t)0.f;
-        o[0] = (half_t)((L - 50.f) / 100.f);
+        for (int e = 0; e < 8; ++e) o[e] = ol[e] = (half_t)0.f;
+        const float v = (L - 50.f) / 100.f;
+        o[0] = (half_t)v;
+        if (y_lo) {
+            half_t a, b;
+            split_pair(v, a, b);
+            o[0] = a; ol[0] = b;
+            *reinterpret_cast<half8*>(y + i * y_cpitch + y_coff + y_lo) = ol;
+        }
         *reinterpret_cast<half8*>(y + i * y_cpitch + y_coff) = o;
     }
 }
 
-int launch_prep_lab_l(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff, int64_t npix, hipStream_t s) {
-    hipLaunchKernelGGL(prep_lab_l_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, y, y_cpitch, y_coff, npix);
+int launch_prep_lab_l(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff, int64_t npix, hipStream_t s, int y_lo) {
+    hipLaunchKernelGGL(prep_lab_l_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, y, y_cpitch, y_coff, npix, y_lo);
     return (int)hipGetLastError();
 }
 
@@ -118,27 +130,33 @@ __device__ __forceinline__ void lab_to_rgb01(double L, double a, double bb, doub
     b = fmin(fmax(linear_to_srgb(kRgbFromXyz[6] * X + kRgbFromXyz[7] * Y + kRgbFromXyz[8] * Z), 0.0), 1.0);
 }
 __global__ void prep_ddcolor_kernel(const uint8_t* __restrict__ rgb, half_t* __restrict__ y, int y_cpitch, int y_coff, half_t* __restrict__ y2,
-                                    int y2_cpitch, int y2_coff, int64_t npix) {
+                                    int y2_cpitch, int y2_coff, int64_t npix, int precise) {
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
         const double L = rgb_to_L(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
         double c[3];
         lab_to_rgb01(L, 0.0, 0.0, c[0], c[1], c[2]);
-        half8 o;
+        half8 o, ol;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (half_t)0.f;
+        for (int e = 0; e < 8; ++e) o[e] = ol[e] = (half_t)0.f;
 #pragma unroll
-        for (int e = 0; e < 3; ++e) o[e] = (half_t)(((float)c[e] - mean[e]) / stdv[e]);
+        for (int e = 0; e < 3; ++e) {
+            const float v = ((float)c[e] - mean[e]) / stdv[e];
+            o[e] = (half_t)v;
+            if (precise) { half_t a, b; split_pair(v, a, b); o[e] = a; ol[e] = b; }
+        }
         *reinterpret_cast<half8*>(y + i * y_cpitch + y_coff) = o;
+        if (precise) *reinterpret_cast<half8*>(y + i * y_cpitch + y_coff + (y_cpitch >> 1)) = ol;        // precise: pixel row = [hi: P | lo: P]
         if (y2) {                                           // the refine conv's image slice: 3 channels at an arbitrary (4-aligned) offset
             half_t* q = y2 + i * y2_cpitch + y2_coff;
             q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+            if (precise) { q += y2_cpitch >> 1; q[0] = ol[0]; q[1] = ol[1]; q[2] = ol[2]; }
         }
     }
 }
 int launch_prep_ddcolor(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff, half_t* y2, int y2_cpitch, int y2_coff, int64_t npix,
-                        hipStream_t s) {
-    hipLaunchKernelGGL(prep_ddcolor_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, y, y_cpitch, y_coff, y2, y2_cpitch, y2_coff, npix);
+                        hipStream_t s, int precise) {
+    hipLaunchKernelGGL(prep_ddcolor_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, y, y_cpitch, y_coff, y2, y2_cpitch, y2_coff, npix, precise);
     return (int)hipGetLastError();
 }
 // Lab(L of the original frame, ab from the network: fp16 NHWC channels 0, 1 at abH x abW, bilinear align_corners=False to the
@@ -147,7 +165,9 @@ int launch_prep_ddcolor(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff,
 // shape vs-deoldify hands to / takes from vsddcolor.ddcolor (vsslib/vsmodels.py:353-363) -- instead of interleaved u8.
 __global__ void ddcolor_post_kernel(const uint8_t* __restrict__ orig, const half_t* __restrict__ ab, int ab_cpitch, int ab_coff, int abH,
                                     int abW, uint8_t* __restrict__ out, void* __restrict__ out_planes, int planes_half, int n_frames, int w, int h,
-                                    float sh, float sw) {
+                                    float sh, float sw, int ab_lo) {
+    // ab_lo > 0 (precise nets): the ab map is a hi / lo pair tensor, lo plane ab_lo elements behind the hi plane
+    auto rd = [&](const half_t* p) -> float { return ab_lo ? (float)p[0] + (float)p[ab_lo] * (1.f / 2048.f) : (float)p[0]; };
     const int64_t total = (int64_t)n_frames * w * h;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % w), y = (int)((i / w) % h), f = (int)(i / ((int64_t)w * h));
@@ -155,8 +175,8 @@ __global__ void ddcolor_post_kernel(const uint8_t* __restrict__ orig, const half
         const half_t* base = ab + (int64_t)f * abH * abW * ab_cpitch + ab_coff;
         float a, bb;
         if (abH == h && abW == w) {
-            a = (float)base[((int64_t)y * abW + x) * ab_cpitch];
-            bb = (float)base[((int64_t)y * abW + x) * ab_cpitch + 1];
+            a = rd(base + ((int64_t)y * abW + x) * ab_cpitch);
+            bb = rd(base + ((int64_t)y * abW + x) * ab_cpitch + 1);
         } else {
             int y0, y1, x0, x1;
             float ly, lx;
@@ -165,8 +185,8 @@ __global__ void ddcolor_post_kernel(const uint8_t* __restrict__ orig, const half
             const half_t *p00 = base + ((int64_t)y0 * abW + x0) * ab_cpitch, *p01 = base + ((int64_t)y0 * abW + x1) * ab_cpitch,
                          *p10 = base + ((int64_t)y1 * abW + x0) * ab_cpitch, *p11 = base + ((int64_t)y1 * abW + x1) * ab_cpitch;
             const float hy = 1.f - ly, hx = 1.f - lx;
-            a = hy * (hx * (float)p00[0] + lx * (float)p01[0]) + ly * (hx * (float)p10[0] + lx * (float)p11[0]);
-            bb = hy * (hx * (float)p00[1] + lx * (float)p01[1]) + ly * (hx * (float)p10[1] + lx * (float)p11[1]);
+            a = hy * (hx * rd(p00) + lx * rd(p01)) + ly * (hx * rd(p10) + lx * rd(p11));
+            bb = hy * (hx * rd(p00 + 1) + lx * rd(p01 + 1)) + ly * (hx * rd(p10 + 1) + lx * rd(p11 + 1));
         }
         double r, g, b;
         lab_to_rgb01(L, (double)a, (double)bb, r, g, b);
@@ -185,9 +205,9 @@ __global__ void ddcolor_post_kernel(const uint8_t* __restrict__ orig, const half
     }
 }
 int launch_ddcolor_post(const uint8_t* orig, const half_t* ab, int ab_cpitch, int ab_coff, int abH, int abW, uint8_t* out_u8, void* out_planes,
-                        int planes_half, int n_frames, int w, int h, hipStream_t s) {
+                        int planes_half, int n_frames, int w, int h, hipStream_t s, int ab_lo) {
     hipLaunchKernelGGL(ddcolor_post_kernel, dim3(grid_for((int64_t)n_frames * w * h)), dim3(256), 0, s, orig, ab, ab_cpitch, ab_coff, abH, abW, out_u8,
-                       out_planes, planes_half, n_frames, w, h, (float)abH / (float)h, (float)abW / (float)w);
+                       out_planes, planes_half, n_frames, w, h, (float)abH / (float)h, (float)abW / (float)w, ab_lo);
     return (int)hipGetLastError();
 }
 

@@ -13,6 +13,8 @@ from .plan import (TAG_TAIL_RES, PlanBuilder, View, WeightPack, bn_scale_shift, 
                    pad_to, pitch_for, to_np)
 
 RESNET = {"wide": ("bottleneck", [3, 4, 23, 3]), "deep": ("basic", [3, 4, 6, 3])}
+import os
+FUSE_BLUR_MIN_H = int(os.environ.get("HAVC_FUSE_BLUR_MIN_H", "64"))      # smallest low-res side the fused shuffle + blur conv is used for
 Y_RANGE = (-3.0, 3.0)          # SigmoidRange(*y_range), deoldify/generators.py:33,111
 
 
@@ -116,8 +118,8 @@ class DeoldifyGenerator:
 
     def _fuse_blur(self, x, up_c, out_hw):
         """HAVC_F_PS_BLUR applies when the blur is not followed by a resize, the channel count tiles by 64 and the 15/16
-        tile overlap wastes little (H >= 128: 280 -> 19 tiles of 15 = 1.8 %, 140 -> 7 %, 70 -> 7 % but M is tiny there)."""
-        return self.fuse_blur and 2 * x.H == out_hw and self._blur_pad_ok(up_c) and x.H >= 128
+        tile overlap wastes little (280 -> 19 tiles of 15 = 1.8 %, 140 -> 7 %, 70 -> 14 %: round 5 measured the 70 -> 140 stage too: 1.63 -> 1.08 ms per 64 frames)."""
+        return self.fuse_blur and 2 * x.H == out_hw and self._blur_pad_ok(up_c) and x.H >= FUSE_BLUR_MIN_H
 
     @staticmethod
     def _blur_pad_ok(up_c):
@@ -193,7 +195,7 @@ class DeoldifyGenerator:
         tail_buf = b.buf(S * S * tail_pitch, 2, zero_init=c8s != c8)
         tail_cmap = np.concatenate([np.arange(c8), c8s + np.arange(3)])
         x0 = b.tensor(S, S, 3, zero_init=False)
-        b.prep_rgb8("prep", in_buf, S, x0, View(tail_buf, c8s, tail_pitch, S, S, 3, 8))
+        b.prep_rgb8("prep", in_buf, S, x0, View(tail_buf, c8s, tail_pitch, S, S, 3, 8), y1_fill=tail_pitch // pm - tail_span)
 
         # ---- encoder: torchvision resnet children()[:-2] ----
         e = "layers.0"

@@ -339,11 +339,12 @@ class PlanBuilder:
         return self._op(name, type=nat.OP_PREP_LAB_L, src=in_buf, dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=S, Wi=S,
                         Ci=8, Ho=S, Wo=S, Co=8)
 
-    def prep_rgb8(self, name, in_buf, S, y0, y1=None):
+    def prep_rgb8(self, name, in_buf, S, y0, y1=None, y1_fill=0):
+        """y1_fill: pad channels behind y1's 8-channel slot that no op reads and the kernel may zero as well (whole 64-byte stores)"""
         kw = dict(type=nat.OP_PREP_RGB8, src=in_buf, dst=y0.buf, dst_coff=y0.coff, dst_cpitch=y0.cpitch, Hi=S, Wi=S,
                   Ci=8, Ho=S, Wo=S, Co=8)
         if y1 is not None:
-            kw.update(src2=y1.buf, res_coff=y1.coff, res_cpitch=y1.cpitch)
+            kw.update(src2=y1.buf, res_coff=y1.coff, res_cpitch=y1.cpitch, aux0=0 if self.precise else y1_fill)
         return self._op(name, **kw)
 
     # ---- DDColor ops (csrc/ddcolor.hip) ----
