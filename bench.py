@@ -13,8 +13,11 @@ offline), activations fp16 with fp32 MFMA accumulation.
 
 `value` is the whole-job rate over the EXACTLY K timed steps (sum over all ranks; `value_per_gpu` = value / n_gpus); one step = 64 frames per GPU
 (--batch).  Beside it the line carries, measured in the same process after the timed region (rank 0, N = 1):
-  precise        the same step with ModelImageRender(precision="precise") (fp32-class arithmetic: the mode that meets CIEDE2000 < 1.0 per pixel),
-                 its own roofline and its parity against the same oracle frames
+  precise        the same step with ModelImageRender(precision="precise") (fp32-class arithmetic; measured against the oracle: mean ~1e-3, p99 0.000,
+                 >= 99.97 % of the pixels below CIEDE2000 1.0, residual maximum 2.5 - 3.6 = single truncation flips of uint8(x * 255), which two fp32
+                 evaluations of the reference differ by as well), its own roofline and its parity against the same oracle frames.  Every parity object
+                 carries `meets_contract` (p99 < 1.0 and >= 99 % of the pixels below 1.0) and `every_pixel_below_1` (the literal reading: false
+                 for any implementation that is not bit-identical to the reference's summation order)
   other_configs  BASELINE configs[2..4] (c3 / c4 / c5) as short child-process legs run BEFORE this process touches the GPU (--no-other-configs skips)
   sustained      the same step looped for >= --sustain-seconds (default 30 s): first-second and steady-state rates
   pcie_inclusive host frames in -> host frames out through havc_colorize_clip_host (pinned memory, uploads / passes /
@@ -52,8 +55,12 @@ PARITY_FRAMES = (4, 2, 2)                       # frames of the clip checked per
 
 
 def _stats(de, d):
-    return {"ciede2000_mean": round(float(de.mean()), 4), "ciede2000_p99": round(float(np.percentile(de, 99)), 4),
-            "ciede2000_max": round(float(de.max()), 4), "pixels_with_dE_below_1": round(float((de < 1.0).mean()), 5),
+    """`meets_contract`: north_star's "within CIEDE2000 < 1.0 of the reference" read as p99 < 1.0 AND >= 99 % of the pixels below 1.0 (the thresholds of
+    tests/test_gpu_precise.py); `every_pixel_below_1`: the literal per-pixel reading (ciede2000_max < 1.0)."""
+    p99, frac, mx = float(np.percentile(de, 99)), float((de < 1.0).mean()), float(de.max())
+    return {"ciede2000_mean": round(float(de.mean()), 4), "ciede2000_p99": round(p99, 4),
+            "ciede2000_max": round(mx, 4), "pixels_with_dE_below_1": round(frac, 5),
+            "meets_contract": bool(p99 < 1.0 and frac >= 0.99), "every_pixel_below_1": bool(mx < 1.0),
             "bytes_within_1lsb": round(float((d <= 1).mean()), 5), "bytes_within_2lsb": round(float((d <= 2).mean()), 5)}
 
 
@@ -107,15 +114,16 @@ def cpu_baseline_and_parity(cc_main, frames, threads, device_index, cc_precise=N
                        "note": "fp16 MFMA operands; floor / decomposition in profiles/r2_precision_study.txt" if m == "fast" else
                                "hi / lo fp16 pairs, three-segment convs, fp32 epilogues and attention (HAVC_F_PRECISE): what is left is the fp32 summation-order floor"})
         out[m] = parity
-    base = {"value": round(cpu_n / cpu_s, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+    base = {"value": round(cpu_n / cpu_s, 5), "unit": "frames/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
             "sample": f"{cpu_n} frames of the 1080p clip (2 U-Net passes at 560x560 fp32 + Spline64/YUV tail each), {cpu_s:.1f} s"}
     return base, out["fast"], out.get("precise")
 
 
 def precise_leg(args, sds, device_index, frames, fbytes):
-    """The mode that meets the CIEDE2000 < 1.0 contract per pixel: the same step on the same clip with
-    ModelImageRender(precision="precise") -- hi / lo fp16 activation pairs, three K segments per conv on the same MFMA kernels (3x the matrix
-    work), fp32 epilogues and attention.  16 frames per step (activations are twice as large).  Returns (leg dict, ClipColorizer)."""
+    """The fp32-class mode: the same step on the same clip with ModelImageRender(precision="precise") -- hi / lo fp16
+    activation pairs, three K segments per conv on the same MFMA kernels (3x the matrix work), fp32 epilogues and attention.  What it measures
+    against the oracle is in the leg's `parity` object (p99 0.000, >= 99.97 % of the pixels below 1.0, `meets_contract`; the residual maximum of
+    2.5 - 3.6 is a uint8 truncation flip on isolated pixels).  16 frames per step (activations are twice as large).  Returns (leg dict, ClipColorizer)."""
     from vsdeoldify_amd import _native as nat
     from vsdeoldify_amd.clip import ClipColorizer
     batch = min(16, args.batch)
@@ -166,6 +174,12 @@ def off(p, nbytes):
     return ctypes.c_void_p(p.value + nbytes)
 
 
+def cpu_threads(args):
+    """threads of the CPU-oracle legs: all host cores unless --cpu-threads caps them"""
+    n = os.cpu_count() or 1
+    return min(n, args.cpu_threads) if args.cpu_threads and args.cpu_threads > 0 else n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,7 +195,7 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short c3 / c4 / c5 legs of the default run")
     ap.add_argument("--no-precise", action="store_true", help="skip the precise-mode leg (ModelImageRender(precision='precise'))")
     ap.add_argument("--sustain-seconds", type=float, default=30.0)
-    ap.add_argument("--cpu-threads", type=int, default=32, help="threads for the CPU-oracle baseline leg")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU-oracle baseline leg (0 = all host cores: os.cpu_count())")
     args = ap.parse_args()
     if args.batch is None:              # 64 frames per step fill the small encoder / decoder layers better than 32 (+2 %, same-box A/B; 105 GB of activations)
         # c3 (DDColor): 64 frames = 65 536 tokens at the 768-channel stage -> 768 tiles of 256 x 256 for pwconv2 = exactly 3 per CU; at 32 frames
@@ -325,7 +339,7 @@ def main():
         except Exception as e:                          # never lose the headline line to the second mode
             out["precise"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, parity, parity_p = cpu_baseline_and_parity(cc, frames, min(os.cpu_count() or 1, args.cpu_threads), local_rank, cc_precise)
+        base, parity, parity_p = cpu_baseline_and_parity(cc, frames, cpu_threads(args), local_rank, cc_precise)
         out["cpu_baseline"] = base
         out["parity"] = parity
         if parity_p is not None:
@@ -367,7 +381,7 @@ def other_configs_leg(args):
             res[cfg] = {"metric": o["metric"], "value": o["value"], "unit": "frames/s", "ms_per_step": o["ms_per_step"],
                         "frames_per_step": o["config"].get("frames_per_step_per_gpu"), "steps": o["steps"],
                         "whole_path_tflops": o.get("whole_path_tflops"), "whole_path_frac": round((o.get("whole_path_tflops") or 0.0) / PEAK_F16_TFLOPS, 4),
-                        "roofline": {k: o["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "avg_launch_ms", "frames_per_launch")},
+                        "roofline": {k: o["roofline"].get(k) for k in ("bound", "scope", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "frames_per_launch") if k in o["roofline"]},
                         "parity": {k: par.get(k) for k in ("ciede2000_mean", "ciede2000_p99", "pixels_with_dE_below_1", "frames_checked")} if par else None,
                         "cpu_baseline": (o.get("cpu_baseline") or {}).get("value"), "workload": o["config"]["workload"],
                         "leg_seconds": round(time.time() - t0, 1)}
@@ -571,6 +585,16 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4),
                 "traffic": None, "kernel": kname, "launches_timed": int(launches.value), "frames_per_launch": round(fpl, 2),
                 "avg_launch_ms": round(avg_ms.value, 4), "flops_per_launch": flops_frame * fpl}
+    # HBM bytes per launch of that kernel from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this very command (tools/pmc_cfg.sh, tools/pmc_cfg_to_json.py),
+    # corrected as MI355X_MICROARCH.md prescribes; recorded at its own frames-per-launch and scaled linearly to this run's
+    for pf in (os.path.join(ROOT, "profiles", f"r5_{'c3' if ddcolor_only else 'c4'}_pmc.json"),):
+        if os.path.isfile(pf):
+            try:
+                rec = json.load(open(pf))
+                roofline["traffic"] = rec["traffic_bytes_per_launch"]
+                roofline["traffic_source"] = os.path.relpath(pf, ROOT) + " (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+            except (ValueError, KeyError):
+                pass
     tot_flops, tot_frames = st.total_flops, st.frames
     if side:
         st2 = dd_ctx.stats()
@@ -593,7 +617,7 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the same graph assembled from the oracle pieces on ONE 1080p frame of the clip: timed as the CPU baseline, compared with the GPU frame
         from oracle import ddcolor as D, imaging, pipeline, resample
-        threads = min(os.cpu_count() or 1, args.cpu_threads)
+        threads = cpu_threads(args)
         torch.set_num_threads(threads)
         got = keep[0].frame(0).numpy()
         fr = frames[0]
@@ -607,7 +631,7 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
         dt = time.time() - t0
         de = imaging.delta_e00_images(got, ref)
         d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
-        out["cpu_baseline"] = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+        out["cpu_baseline"] = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
                                "sample": f"1 frame of the 1080p clip through the oracle graph (fp32 torch models + numpy tail), {dt:.1f} s"}
         out["parity"] = {"ciede2000_mean": round(float(de.mean()), 4), "ciede2000_p99": round(float(np.percentile(de, 99)), 4),
                          "ciede2000_max": round(float(de.max()), 4), "pixels_with_dE_below_1": round(float((de < 1.0).mean()), 5),
@@ -729,18 +753,16 @@ def bench_c5(args, rank, local_rank, world, dist):
                       "key_encoder_lookahead": rnd.lookahead,
                       "parallelism": f"memory step sequential in time (key encoder {rnd.lookahead} frames ahead, concurrently on a second stream): replicas only, one clip per GPU x{world}"},
            "whole_path_tflops": round(total * gflop_frame * 1e9 / elapsed / 1e12 / world, 2),
-           # A ColorMNet frame is ~100 dependent launches of 5 - 40 us on a 14 x 28 grid (2 objects): no single launch dominates the TIME -- the largest
-           # classes are the 23 - 40 us convs of the decoder / value encoder (conv_pipe_kernel<1,2,4> / <2,4,4> / <1,4,4>: ~0.55 ms of a frame,
-           # profiles/r3_c5_kernels.txt) -- so the honest roofline figure of this config is the WHOLE-PATH rate.  The best-utilised
-           # launch (the look-ahead pass's fuse2.encode_enc at 16 frames per launch) is kept as a secondary field.
-           "roofline": {"bound": "mfma", "achieved": round(total * gflop_frame * 1e9 / elapsed / 1e12 / world, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(total * gflop_frame * 1e9 / elapsed / 1e12 / world / PEAK_F16_TFLOPS, 4), "traffic": None,
-                        "kernel": "whole frame: a latency-bound chain of ~100 small launches (time-dominant class: the 23 - 40 us decoder / value-encoder convs, "
-                                  "conv_pipe_kernel<1,2,4> / <2,4,4> / <1,4,4>); algorithmic FLOPs of a steady-state frame / wall time",
-                        "best_launch": {"kernel": f"conv_pipe_kernel ({tag_name}: 3x3 1536 -> 512 at 28x56, {fpl} frames per launch, look-ahead pass, timed while the "
-                                                  "memory step shares the chip)", "achieved": round(achieved, 2), "frac": round(achieved / PEAK_F16_TFLOPS, 4),
-                                        "launches_timed": int(launches.value), "frames_per_launch": fpl, "avg_launch_ms": round(avg_ms.value, 4),
-                                        "flops_per_launch": flops_launch}}}
+           "whole_path_frac": round(total * gflop_frame * 1e9 / elapsed / 1e12 / world / PEAK_F16_TFLOPS, 4),
+           # `roofline` has the same meaning on every config of this file: the best-utilised TIMED launch against the MFMA peak -- here the
+           # look-ahead pass's fuse2.encode_enc at 16 frames per launch.  It is NOT where a ColorMNet frame spends its time: a frame is a latency-bound
+           # chain of ~45 - 90 dependent launches of 5 - 40 us on a 14 x 28 grid (2 objects), no launch dominates, and the honest figure for the config
+           # is the whole-path rate above (`whole_path_tflops` / `whole_path_frac`); `scope` says which one this object is.
+           "roofline": {"bound": "mfma", "scope": "best-utilised timed launch (the frame as a whole is latency-bound: see whole_path_frac)",
+                        "achieved": round(achieved, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
+                        "kernel": f"conv_pipe_kernel ({tag_name}: 3x3 1536 -> 512 at 28x56, {fpl} frames per launch, look-ahead pass, timed while the memory step "
+                                  "shares the chip)",
+                        "launches_timed": int(launches.value), "frames_per_launch": fpl, "avg_launch_ms": round(avg_ms.value, 4), "flops_per_launch": flops_launch}}
     if rank == 0 and world == 1 and not args.no_extras:
         # the reference's own call shape: ONE colorize_frame per frame, nothing announced (DeviceImage in -> DeviceImage out: the calls only enqueue)
         dx1 = DeepExColorMNet(vid_length=10000, render_speed="medium", network=net)
@@ -782,7 +804,7 @@ def bench_c5(args, rank, local_rank, world, dist):
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU oracle over the first frames of the same clip (the exemplar arrives with frame 0): timed, and compared with the GPU's frames
         from oracle import colormnet_clip, imaging, pipeline, resample
-        threads = min(os.cpu_count() or 1, args.cpu_threads)
+        threads = cpu_threads(args)
         torch.set_num_threads(threads)
         K = 4
         dx2 = DeepExColorMNet(vid_length=10000, render_speed="medium", network=net)
@@ -796,7 +818,7 @@ def bench_c5(args, rank, local_rank, world, dist):
         des = [imaging.delta_e00_images(g_, r_) for g_, r_ in zip(gpu, refs)]
         worst = int(np.argmax([float(np.percentile(d_, 99)) for d_ in des]))
         de = np.concatenate([d_.reshape(-1) for d_ in des])
-        out["cpu_baseline"] = {"value": round(K / dt, 5), "unit": "frames/s", "cores": threads, "kind": "port",
+        out["cpu_baseline"] = {"value": round(K / dt, 5), "unit": "frames/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
                                "sample": f"the first {K} frames of the clip (exemplar with frame 0) through the oracle loop (fp32 torch network + numpy tail), {dt:.1f} s"}
         out["parity"] = {"ciede2000_mean": round(float(de.mean()), 4), "ciede2000_p99": round(float(np.percentile(de, 99)), 4),
                          "ciede2000_max": round(float(de.max()), 4), "pixels_with_dE_below_1": round(float((de < 1.0).mean()), 5),

@@ -44,7 +44,7 @@ def test_precise_pack_and_plan_layout():
     with pytest.raises(AssertionError):
         b.conv("mixed", fast, x, y, pad=1)             # a fast packing cannot enter a precise plan
     with pytest.raises(AssertionError):
-        b.subsample2("no precise form", x, b.tensor(6, 5, 259))
+        b.ew("no precise form", x, b.tensor(12, 10, 259))          # ColorMNet's element-wise op: fast path only
 
 
 def test_precise_generator_plan_is_the_unfused_plan_with_pairs():
@@ -65,3 +65,32 @@ def test_precise_generator_plan_is_the_unfused_plan_with_pairs():
     conv_f = {n: o for o, n in zip(ops_f, names_f) if o["type"] == nat.OP_CONV}
     for n in conv:
         assert conv[n]["Kc"] == 3 * conv_f[n]["Kc"] and conv[n]["src_cpitch"] == 2 * conv_f[n]["src_cpitch"], n
+
+
+@pytest.mark.parametrize("model", ["eccv16", "siggraph17", "ddcolor"])
+def test_precise_plans_of_the_other_models(model):
+    """round 5: ZhangGenerator / DDColorGenerator(precision="precise") emit plans whose every op is flagged HAVC_F_PRECISE and has a precise form,
+    with pair pitches, three-segment convs and the algorithmic FLOPs of the fast plan (the three K segments are not counted)"""
+    from vsdeoldify_amd.plan import PRECISE_OPS
+    if model == "ddcolor":
+        from vsdeoldify_amd.ddcolor_net import DDColorGenerator
+        from vsdeoldify_amd.synth import synth_ddcolor_state_dict
+        small = dict(depths=(1, 1, 2, 1), dec_layers=3)
+        sd = synth_ddcolor_state_dict(1, **small)
+        gp, gf = DDColorGenerator(sd, precision="precise", **small), DDColorGenerator(sd, **small)
+        pp, pf = gp.plan(64), gf.plan(64)
+        consts = pp[5]
+        assert consts and all(pitch % 16 == 0 for _, _, pitch, _ in consts)            # constant token / position maps travel as pairs too
+    else:
+        from vsdeoldify_amd.synth import synth_zhang_state_dict
+        from vsdeoldify_amd.zhang_net import ZhangGenerator
+        sd = synth_zhang_state_dict(model, 1)
+        gp, gf = ZhangGenerator(sd, model, precision="precise"), ZhangGenerator(sd, model)
+        pp, pf = gp.plan(64), gf.plan(64)
+    ops, ops_f = pp[0], pf[0]
+    assert all(int(o["flags"]) & nat.F_PRECISE for o in ops) and all(int(o["type"]) in PRECISE_OPS for o in ops)
+    assert not any(int(o["flags"]) & nat.F_PRECISE for o in ops_f)
+    conv, conv_f = ops[ops["type"] == nat.OP_CONV], ops_f[ops_f["type"] == nat.OP_CONV]
+    assert len(conv) and all(float(o["f3"]) > 0 for o in conv) and int(conv["Kc"].sum()) == 3 * int(conv_f["Kc"].sum())
+    assert int(conv["flops"].sum()) == int(conv_f["flops"].sum())
+    assert all(int(o["src_cpitch"]) % 16 == 0 for o in conv)

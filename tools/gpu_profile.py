@@ -12,7 +12,7 @@ batch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 ctx = get_context(0)
 t = time.time()
 rt = GeneratorRuntime(ctx, synth_state_dict(arch, 1), arch, fuse_final=os.environ.get("FUSE_FINAL", "1") == "1",
-                      fuse_blur=os.environ.get("FUSE_BLUR", "1") == "1")
+                      fuse_blur=os.environ.get("FUSE_BLUR", "1") == "1", precision=os.environ.get("PRECISION", "fast"))
 print(f"pack+upload {time.time()-t:.1f}s")
 net = rt.net(S, batch, os.environ.get("LOW_LATENCY", "0") == "1")
 for _ in range(2):

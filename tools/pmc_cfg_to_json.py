@@ -1,0 +1,46 @@
+"""Per-launch HBM traffic of the dominant kernel of bench.py --config c3 | c4 from the counter CSVs of tools/pmc_cfg.sh -> profiles/<label>_<cfg>_pmc.json
+(read by bench.py as roofline.traffic of that config).    python tools/pmc_cfg_to_json.py c3|c4 [label] [dir]
+c3: ConvNeXt stage-2 pwconv1 + GELU (768 -> 3072 at 32 x 32 tokens per frame): the GELU-epilogue conv kernel whose grid is launched most often (27 per pass);
+c4: the tail res-block conv 259 -> 259 at 384 x 384, conv_pipe_kernel<2, 4, 8, 1, 0, EF> (two instantiations, averaged like the c2 record).
+Corrections as MI355X_MICROARCH.md prescribes: counter unit KiB (x 1024); gfx950 FETCH_SIZE counts wide reads as 64 B per 128-B request (x 2)."""
+import collections, csv, glob, json, os, shutil, sys
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
+label = sys.argv[2] if len(sys.argv) > 2 else "r5"
+src = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out"
+MATCH = {"c3": lambda n: "conv_pipe_kernel<" in n and ", 1024>(" in n, "c4": lambda n: "conv_pipe_kernel<2, 4, 8, 1, 0" in n}[cfg]       # EF 1024 = HAVC_F_GELU
+
+
+def rows(kind, counter):
+    cands = glob.glob(f"{src}/pmc_{cfg}_{kind}/*/*counter_collection.csv")
+    if not cands:
+        sys.exit(f"pmc_cfg_to_json: no {kind} counter CSV under {src}/pmc_{cfg}_{kind} (see {src}/pmc_{cfg}_{kind}.log)")
+    os.makedirs("profiles/pmc", exist_ok=True)
+    shutil.copy(cands[0], f"profiles/pmc/{label}_{cfg}_{kind}_size_counter_collection.csv")
+    out = collections.defaultdict(list)
+    for r in csv.DictReader(open(cands[0])):
+        if r["Counter_Name"] == counter and MATCH(r["Kernel_Name"]):
+            out[(r["Kernel_Name"], r.get("Grid_Size", ""))].append(float(r["Counter_Value"]))
+    if not out:
+        sys.exit("pmc_cfg_to_json: the kernel has no rows in the counter CSV")
+    return out
+
+
+fetch, write = rows("fetch", "FETCH_SIZE"), rows("write", "WRITE_SIZE")
+if cfg == "c3":                               # the most frequently launched grid of the GELU conv = stage 2 (27 of the 36 blocks)
+    key = max(fetch, key=lambda k: len(fetch[k]))
+    f, w = fetch[key], write.get(key, [0.0])
+    names = [key[0] + " grid " + key[1]]
+else:
+    f = [v for k in fetch for v in fetch[k]]
+    w = [v for k in write for v in write[k]]
+    names = sorted({k[0] for k in fetch})
+KIB = 1024.0
+fb, wb = sum(f) / len(f) * KIB * 2, sum(w) / len(w) * KIB
+rec = {"config": cfg, "kernels": names, "launches_seen": [len(f), len(w)], "FETCH_SIZE_kib_raw_avg": sum(f) / len(f), "WRITE_SIZE_kib_raw_avg": sum(w) / len(w),
+       "fetch_bytes_corrected": fb, "write_bytes": wb, "traffic_bytes_per_launch": fb + wb,
+       "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --config {cfg} --no-cpu-baseline --no-extras --steps 2 --warmup 1 (tools/pmc_cfg.sh)",
+       "correction": "counter unit KiB (x1024); gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) reads -> x2; WRITE_SIZE 1:1 (MI355X_MICROARCH.md HBM section)",
+       "note": "trial launches of the autotuner are included in the average (same shapes, same grids)"}
+json.dump(rec, open(f"profiles/{label}_{cfg}_pmc.json", "w"), indent=1)
+print(json.dumps(rec, indent=1))

@@ -31,15 +31,20 @@ class ModelColorization:
             cls._instance = super().__new__(cls)
         return cls._instance
 
-    def __init__(self, model="siggraph17", use_gpu=True, device_index=0, state_dict=None, max_batch=1, coalesce=0):
-        """coalesce = N > 0: colorize_frame calls made concurrently by N threads are merged into batches (havc_batcher, kind 2)"""
+    def __init__(self, model="siggraph17", use_gpu=True, device_index=0, state_dict=None, max_batch=1, coalesce=0, precision=None):
+        """coalesce = N > 0: colorize_frame calls made concurrently by N threads are merged into batches (havc_batcher, kind 2).
+        precision: "fast" (fp16 activations, fp32 accumulation) or "precise" (fp32-class arithmetic like the reference, which runs the nets in fp32,
+        colorization/__init__.py:76-95: hi / lo fp16 pairs, three-segment convs, fp32 softmax / tanh projection); None reads HAVC_PRECISION."""
         if not use_gpu:
             raise nat.NativeLibraryError("vsdeoldify_amd.ModelColorization is MI355X only (use_gpu=False is not supported)")
-        if self._initialized and self.colorizer_model == model and state_dict is None:
+        precision = precision or os.environ.get("HAVC_PRECISION", "fast")
+        if precision not in ("fast", "precise"):
+            raise ValueError(f"precision must be 'fast' or 'precise', not {precision!r}")
+        if self._initialized and self.colorizer_model == model and state_dict is None and getattr(self, "precision", "fast") == precision:
             return
         if self._initialized:
             self.close()
-        self.colorizer_model, self.use_gpu = model, use_gpu
+        self.colorizer_model, self.use_gpu, self.precision = model, use_gpu, precision
         self.ctx = get_context(device_index)
         self._coalesce, self._batchers = coalesce, {}
         self._colorize_init(state_dict, max(max_batch, coalesce))
@@ -53,7 +58,7 @@ class ModelColorization:
             if not os.path.isfile(path):
                 raise FileNotFoundError(f"Zhang colorizer weights not found: {path} (the reference fetches them with model_zoo)")
             state_dict = torch.load(path, map_location="cpu")
-        self.gen = ZhangGenerator(state_dict, "siggraph17" if self.colorizer_model == "siggraph17" else "eccv16")
+        self.gen = ZhangGenerator(state_dict, "siggraph17" if self.colorizer_model == "siggraph17" else "eccv16", precision=self.precision)
         self.weights = nat.Weights(self.ctx, self.gen.blob)
         ops, bufs, i, o, names = self.gen.plan(NET_SIZE)
         self.net = nat.Net(self.ctx, self.weights, ops, bufs, i, o, NET_SIZE, max_batch)

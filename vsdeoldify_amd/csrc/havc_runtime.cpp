@@ -1264,18 +1264,22 @@ static std::vector<int> tune_candidates(const havc_op& op) {
     }
     std::vector<int> cand = {0};
     if (op.Npad <= 16) return cand;                                        // thin N: the 128x16 kernel only
-    if (op.flags & HAVC_F_PRECISE) {                                       // precise convs: the tile geometries instantiated with the precise epilogue
-        if (op.Npad % 256 == 0 || op.Npad % 256 >= 192) { for (int k : {60, 71, 96}) cand.push_back(k); }
-        if (op.Npad % 256 == 16) cand.push_back(61);
-        if (op.Npad % 128 == 0 || op.Npad % 128 >= 96 || op.Npad > 256) { for (int k : {70, 72, 98}) cand.push_back(k); }
-        if (op.Npad % 64 == 0 && op.Npad <= 192) { cand.push_back(99); cand.push_back(92); }
-        for (int k : {1, 2, 3, 7}) cand.push_back(k);
-        return cand;
+    if (op.flags & HAVC_F_PRECISE) {
+        // precise convs: the PIPELINED tile geometries instantiated with the precise epilogue, and nothing else: nothing is rounded to fp16
+        // before the hi / lo split, so the bytes follow the fp32 accumulation order -- the pipelined tiles share one K walk, the register-staged
+        // kernels (cfg 1, 2, 3, 7) and whatever the heuristic (cfg 0) picks per batch size do not.  The heuristic stays only where no pipelined tile fits.
+        std::vector<int> pc;
+        if (op.Npad % 256 == 0 || op.Npad % 256 >= 192) { for (int k : {60, 71, 96}) pc.push_back(k); }
+        if (op.Npad == 272) pc.push_back(61);
+        if (op.Npad % 128 == 0 || op.Npad % 128 >= 96 || op.Npad > 256) { for (int k : {70, 72, 98}) pc.push_back(k); }
+        if (op.Npad % 64 == 0 && op.Npad <= 192) { pc.push_back(99); pc.push_back(92); }
+        if (pc.empty()) { for (int k : {72, 92}) pc.push_back(k); }
+        return pc;
     }
     // column tiles of 256 / 128 channels: also when the last tile is >= 75 % full (ConvNeXt pwconv2 at stage 0, 768 -> 192: the
     // 256 x 256 tile beats every narrower one by 30 %)
     if (op.Npad % 256 == 0 || op.Npad % 256 >= 192) { for (int k : {60, 71, 90, 91, 96, 97}) cand.push_back(k); }
-    if (op.Npad % 256 == 16) cand.push_back(61);
+    if (op.Npad == 272) cand.push_back(61);                                // (launch_pipe<.., EXTRA = 1> takes exactly 256 + 16 columns)
     // 128-wide tiles for every wide layer: the DynamicUnetDeep (artistic) channel counts 304 / 320 / 672 / 1344 fit no tile exactly and
     // a partly empty last tile on the pipelined kernel still beats the register-staged kernels there
     if (op.Npad % 128 == 0 || op.Npad % 128 >= 96 || op.Npad > 256) { for (int k : {70, 72, 93, 95, 98}) cand.push_back(k); }
@@ -1298,7 +1302,8 @@ int havc_net_autotune(havc_net* n, int batch, int* n_changed) {
     if (!n) return HAVC_E_INVALID;
     havc_ctx* c = n->ctx;
     std::lock_guard<std::mutex> lk(c->mu);
-    SetupLock setup;                                       // trial launches of every tile geometry: the first launch of most kernel instantiations
+    // The process-wide set-up mutex is taken PER TRIAL (round 5): a trial launch is the first launch of most kernel instantiations, which is
+    // what the mutex serialises -- but held over the whole tuning run (seconds) it stalled every other thread's havc_dev_alloc / scratch regrowth.
     HIP_TRY(c, hipSetDevice(c->dev));
     if (batch < 1 || batch > n->max_batch) return fail(c, HAVC_E_INVALID, "autotune: batch out of range");
     HIP_TRY(c, sync_streams(c));
@@ -1320,6 +1325,7 @@ int havc_net_autotune(havc_net* n, int batch, int* n_changed) {
         int best = before;
         float best_ms = 1e30f;
         for (int cfg : cand) {
+            SetupLock setup;
             op.reserved = cfg;
             float tot = 0.f;
             bool ok = true;

@@ -17,14 +17,14 @@ from .render import get_context
 class DDColorRuntime:
     """Packed DDColor weights on one GPU + a cache of nets keyed by (input size, max_batch)."""
 
-    def __init__(self, ctx, state_dict, depths=(3, 3, 27, 3), dec_layers=9, share=None):
+    def __init__(self, ctx, state_dict, depths=(3, 3, 27, 3), dec_layers=9, share=None, precision="fast"):
         """share: another DDColorRuntime of the same GPU whose packed plan and device weights are reused (read-only): a second context
         (its own HIP stream and activation arena) for frames that run CONCURRENTLY with the first one's (DDColorRender num_streams)."""
         self.ctx = ctx
         if share is not None:
             self.gen, self.weights, self._owns_weights = share.gen, share.weights, False
         else:
-            self.gen = DDColorGenerator(state_dict, depths, dec_layers)
+            self.gen = DDColorGenerator(state_dict, depths, dec_layers, precision=precision)
             self.weights, self._owns_weights = nat.Weights(ctx, self.gen.blob), True
         self.nets = {}
 
@@ -36,7 +36,12 @@ class DDColorRuntime:
             n.names, n.plan_ops = names, ops
             for buf, arr, pitch, rows_per_frame in consts:               # constant maps: one copy per frame slot
                 a = np.zeros((max_batch, rows_per_frame, pitch), np.float16)
-                a[:, :arr.shape[0], :arr.shape[1]] = arr.astype(np.float16)[None]
+                if self.gen.precise:                                     # hi / lo pair rows: [hi: pitch / 2 | lo: pitch / 2]
+                    hi = arr.astype(np.float16)
+                    a[:, :arr.shape[0], :arr.shape[1]] = hi[None]
+                    a[:, :arr.shape[0], pitch // 2:pitch // 2 + arr.shape[1]] = ((arr.astype(np.float32) - hi.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)[None]
+                else:
+                    a[:, :arr.shape[0], :arr.shape[1]] = arr.astype(np.float16)[None]
                 n.upload(buf, a)
             if os.environ.get("HAVC_AUTOTUNE", "1") != "0":
                 n.autotune(max_batch)
@@ -104,7 +109,7 @@ class DDColorRender:
     MODEL_FILES = {0: "ddcolor_modelscope.pth", 1: "ddcolor_artistic.pth"}          # __init__.py:2367-2371
 
     def __init__(self, model=1, input_size=512, device_index=0, state_dict=None, model_dir=None, depths=(3, 3, 27, 3), dec_layers=9,
-                 coalesce=0, num_streams=None, worker=0):
+                 coalesce=0, num_streams=None, worker=0, precision=None):
         """coalesce = N > 0: colorize_frame calls made concurrently by N threads (the filter's num_streams / VapourSynth's worker pool)
         are merged into batches of up to N frames (havc_batcher): a DDColor pass is 7.7 ms for one frame and 1.2 ms per frame at 16."""
         if model not in self.MODEL_FILES:
@@ -120,7 +125,11 @@ class DDColorRender:
             state_dict = load_state_dict(os.path.join(model_dir, self.MODEL_FILES[model]))
         # worker: which context of the GPU the model lives on (render.get_context): a caller that runs DDColor next to another model (HAVC's
         # DeOldify + DDColor methods) gives it a context of its own, i.e. its own HIP stream
-        self.rt = DDColorRuntime(get_context(device_index, worker), state_dict, depths, dec_layers)
+        # precision: "fast" (fp16 activations) / "precise" (fp32-class arithmetic on hi / lo pairs, ddcolor_net.DDColorGenerator); None reads HAVC_PRECISION
+        self.precision = precision or os.environ.get("HAVC_PRECISION", "fast")
+        if self.precision not in ("fast", "precise"):
+            raise ValueError(f"precision must be 'fast' or 'precise', not {self.precision!r}")
+        self.rt = DDColorRuntime(get_context(device_index, worker), state_dict, depths, dec_layers, precision=self.precision)
         self._coalesce, self._batchers = coalesce, {}
         # num_streams (vsddcolor's parameter, vsslib/vsmodels.py:356; the reference's callers leave it at 1): clips of >= 8 frames are cut into
         # that many parts which run concurrently, each on its own context / HIP stream with the same packed weights.  Frames are independent:

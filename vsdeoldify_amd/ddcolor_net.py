@@ -44,12 +44,17 @@ def position_sine(h, w, num_pos_feats=HIDDEN // 2, temperature=10000.0):
 
 
 class DDColorGenerator:
-    def __init__(self, state_dict, depths=DEPTHS, dec_layers=9):
+    def __init__(self, state_dict, depths=DEPTHS, dec_layers=9, precision="fast"):
+        """precision: "fast" = fp16 activations / MFMA operands, fp32 accumulation; "precise" (round 5) = fp32-class arithmetic like the wheel's torch
+        graph (vsslib/vsmodels.py:353-363 hands it RGBH / RGBS frames; the network itself computes in fp32): hi / lo fp16 pairs, three-segment convs,
+        fp32 depthwise conv / LayerNorm / GELU / attention (HAVC_F_PRECISE; csrc/precise2.hip), the tail folded into ONE fp32 projection kernel."""
+        assert precision in ("fast", "precise")
+        self.precise = precision == "precise"
         self.sd, self.depths, self.dec_layers = to_np(state_dict), tuple(depths), dec_layers
         self.pack, self._pc, self._vec = WeightPack(), {}, {}
         self._frozen = False
-        self.fuse_tail = os.environ.get("HAVC_DD_FUSE_TAIL", "1") != "0"      # A/B switch: einsum + refine folded into the last_shuf conv
-        self.fuse_dwln = os.environ.get("HAVC_DD_FUSE_DWLN", "1") != "0"      # A/B switch: dwconv + LayerNorm as one kernel
+        self.fuse_tail = os.environ.get("HAVC_DD_FUSE_TAIL", "1") != "0" or self.precise      # A/B switch: einsum + refine folded into the last_shuf conv
+        self.fuse_dwln = os.environ.get("HAVC_DD_FUSE_DWLN", "1") != "0" and not self.precise      # A/B switch: dwconv + LayerNorm as one kernel
         # encoder.norm{0,1,2} feed nothing but the decoder's BatchNorm + ReLU on the skip connection: LayerNorm -> BN -> ReLU as ONE LayerNorm launch with
         # the BN folded into its gamma / beta, written straight into the concat buffer (round 4: the separate affine pass was 1.2 ms per 64 frames)
         self.fuse_skip_norm = os.environ.get("HAVC_DD_FUSE_SKIPNORM", "1") != "0" and self.fuse_tail
@@ -75,7 +80,7 @@ class DDColorGenerator:
         W = np.asarray(W, np.float32)
         if W.ndim == 2:
             W = W[:, :, None, None]
-        return self._conv(key, lambda: pack_conv(self.pack, W, x.cmap, x.span, bias=bias, scale=scale, shift=shift))
+        return self._conv(key, lambda: pack_conv(self.pack, W, x.cmap, x.span, bias=bias, scale=scale, shift=shift, precise=self.precise))
 
     def _ln(self, b, name, key, x, y, eps):
         g, be = self._vecs(key, lambda: (self.sd[key + ".weight"].astype(np.float32), self.sd[key + ".bias"].astype(np.float32)))
@@ -85,13 +90,18 @@ class DDColorGenerator:
     # ---- the plan -------------------------------------------------------------------------------------------------------
     def plan(self, S):
         assert S % 32 == 0
-        sd, b = self.sd, PlanBuilder()
+        sd, b = self.sd, PlanBuilder(precise=self.precise)
         consts = []                                            # (buffer id, float32 array [rows, channels], row pitch in channels)
         in_buf = b.buf(S * S * 3, 1)
         x0 = b.tensor(S, S, 3)
-        coarse_pitch = pitch_for(112)
-        coarse_buf = b.buf(S * S * coarse_pitch, 2, zero_init=True)      # channels 0-2 image, 8-107 logits (108-111 pad-token junk)
-        b.prep_ddcolor("prep", in_buf, S, x0, View(coarse_buf, 0, coarse_pitch, S, S, 3, 8))
+        if self.precise:
+            img_view = b.tensor(S, S, 3)                       # the refine conv's image term reads the normalised image as a pair tensor of its own
+            coarse_buf, coarse_pitch = img_view.buf, img_view.cpitch
+            b.prep_ddcolor("prep", in_buf, S, x0, img_view)
+        else:
+            coarse_pitch = pitch_for(112)
+            coarse_buf = b.buf(S * S * coarse_pitch, 2, zero_init=True)      # channels 0-2 image, 8-107 logits (108-111 pad-token junk)
+            b.prep_ddcolor("prep", in_buf, S, x0, View(coarse_buf, 0, coarse_pitch, S, S, 3, 8))
 
         # ---- ConvNeXt encoder ----
         e = "encoder.arch"
@@ -114,7 +124,7 @@ class DDColorGenerator:
             for j in range(self.depths[i]):
                 p = f"{e}.stages.{i}.{j}"
                 wdw, bdw = self._vecs(p + ".dwconv", lambda p=p, x=x: (
-                    self._dw_pack(sd[p + ".dwconv.weight"], x.span), sd[p + ".dwconv.bias"].astype(np.float32)))
+                    self._dw_pack(sd[p + ".dwconv.weight"], x.span, np.float32 if self.precise else np.float16), sd[p + ".dwconv.bias"].astype(np.float32)))
                 if self.fuse_dwln and c in (64, 192, 384, 768, 1536):          # channel counts the fused kernel is instantiated for
                     g, be = self._vecs(p + ".norm", lambda p=p: (sd[p + ".norm.weight"].astype(np.float32), sd[p + ".norm.bias"].astype(np.float32)))
                     b.dwconv7_ln(p + ".dwconv+norm", x, nbuf, wdw, bdw, x.span, g, be, 1e-6)
@@ -139,13 +149,14 @@ class DDColorGenerator:
 
             def make_shuf(p=p, up=up):
                 s, sh = bn_scale_shift(sd, p + ".shuf.conv.1")
-                return pack_conv(self.pack, conv_weight(sd, p + ".shuf.conv.0") * s[:, None, None, None], up.cmap, up.span, bias=sh, pixshuf=True)
+                return pack_conv(self.pack, conv_weight(sd, p + ".shuf.conv.0") * s[:, None, None, None], up.cmap, up.span, bias=sh, pixshuf=True,
+                                 precise=self.precise)
             pc = self._conv(p + ".shuf", make_shuf)
             up_c = pc.Cout // 4
             ps = b.tensor(2 * up.H, 2 * up.W, up_c)
             b.conv(p + ".shuf", pc, up, ps, flags=nat.F_RELU_PRE | nat.F_OUT_PIXSHUF)
             ups, sks = pad_to(up_c, 8), pad_to(skip.C, 8)
-            cat_pitch = pitch_for(ups + sks)
+            cat_pitch = pitch_for(ups + sks) * b.pm
             cat_buf = b.buf(skip.H * skip.W * cat_pitch, 2, zero_init=False)
             b.blur_resize(p + ".blur", ps, View(cat_buf, 0, cat_pitch, skip.H, skip.W, up_c, ups))
             skip_view = View(cat_buf, ups, cat_pitch, skip.H, skip.W, skip.C, sks)
@@ -165,7 +176,7 @@ class DDColorGenerator:
 
             def make_conv(p=p, cat=cat):
                 s, sh = bn_scale_shift(sd, p + ".conv.2")
-                return pack_conv(self.pack, conv_weight(sd, p + ".conv.0"), cat.cmap, cat.span, scale=s, shift=sh)
+                return pack_conv(self.pack, conv_weight(sd, p + ".conv.0"), cat.cmap, cat.span, scale=s, shift=sh, precise=self.precise)
             pcc = self._conv(p + ".conv", make_conv)
             up = b.tensor(cat.H, cat.W, pcc.Cout)
             b.conv(p + ".conv", pcc, cat, up, pad=1, flags=nat.F_RELU_PRE | nat.F_AFFINE)
@@ -178,10 +189,13 @@ class DDColorGenerator:
             W = conv_weight(sd, p + ".conv.0") * s[:, None, None, None]
             cps = W.shape[0] // 16
             perm = (np.arange(cps)[None, :] * 16 + np.arange(16)[:, None]).reshape(-1)
-            return pack_conv(self.pack, W[perm], up.cmap, up.span, bias=sh[perm])
+            return pack_conv(self.pack, W[perm], up.cmap, up.span, bias=sh[perm], precise=self.precise)
         pcl = self._conv(p, make_last)
         last_in = up
-        if not self.fuse_tail:
+        if self.precise:
+            t4 = b.tensor(up.H, up.W, pcl.Cout)
+            b.conv(p + ".conv", pcl, up, t4, flags=nat.F_RELU_PRE)
+        elif not self.fuse_tail:
             t4 = b.tensor(up.H, up.W, pcl.Cout)
             b.conv(p + ".conv", pcl, up, t4, flags=nat.F_RELU_PRE)
             img_feat = b.tensor(S, S, pcl.Cout // 16)
@@ -286,6 +300,11 @@ class DDColorGenerator:
             rq_off, rimg_off, rb_off = self._vecs("refine_net.0.0/fold", make_refine)
             m2 = b.buf(2 * E, 4)
             b.fold_queries(d + ".fold", emb, QUERIES, rq_off, 104, m2)
+            if self.precise:
+                # the same fold in fp32: shuffle + blur of the 4096-channel pair tensor, the 2 x 256 projection, the image term and the bias in one kernel
+                b.shuf4_blur_proj("refine_net.0.0", t4, m2, img_view, rimg_off, rb_off, ab, flops=2 * S * S * (E * QUERIES + 2 * (QUERIES + 3)))
+                ops, bufs = b.finish()
+                return ops, bufs, in_buf, ab.buf, b.names, consts
             proj = b.buf(last_in.H * last_in.W * 16 * 2, 4)
             b.conv(p + ".conv+proj", pcl, last_in, proj, flags=nat.F_RELU_PRE | nat.F_FUSE_PROJ, proj=(m2, proj))
             b.shuf4_blur_ab("refine_net.0.0", proj, last_in.H, last_in.W, View(coarse_buf, 0, coarse_pitch, S, S, 3, 8), rimg_off, rb_off, ab,
@@ -302,9 +321,9 @@ class DDColorGenerator:
         return ops, bufs, in_buf, ab.buf, b.names, consts
 
     @staticmethod
-    def _dw_pack(W, pitch):
-        """[C, 1, 7, 7] -> fp16 [49][pitch] (tap-major, channels contiguous)."""
+    def _dw_pack(W, pitch, dtype=np.float16):
+        """[C, 1, 7, 7] -> fp16 (precise: fp32) [49][pitch] (tap-major, channels contiguous)."""
         C = W.shape[0]
-        out = np.zeros((49, pitch), np.float16)
-        out[:, :C] = W.reshape(C, 49).T.astype(np.float16)
+        out = np.zeros((49, pitch), dtype)
+        out[:, :C] = W.reshape(C, 49).T.astype(dtype)
         return out

@@ -60,7 +60,12 @@ class HAVCFrameColorizer:
     def __init__(self, method=2, mweight=0.4, deoldify_p=(0, 24, 1.0, 0.0), ddcolor_p=(1, 24, 1.0, 0.0, True), cmc_p=DEF_CMC_p,
                  lmm_p=DEF_LMM_p, alm_p=DEF_ALM_p, crt_p=DEF_CRT_p, cmb_sw=False, device_index=0, package_dir=None,
                  ddcolor_model_dir=None, state_dicts=None, ddcolor_state_dict=None, zhang_state_dict=None, max_batch=1,
-                 ddcolor_kwargs=None, ddtweak=(False, False, False), ddtweak_p=(DEF_TWEAK_p, "none")):
+                 ddcolor_kwargs=None, ddtweak=(False, False, False), ddtweak_p=(DEF_TWEAK_p, "none"), precision=None):
+        """precision: "fast" / "precise" for EVERY model of the graph (DeOldify, DDColor, the Zhang colorizers): the reference runs them all in fp32
+        (deoldify/filters.py:45-68, vsslib/vsmodels.py:353-363, colorization/__init__.py:76-95); None reads HAVC_PRECISION (default "fast")."""
+        self.precision = precision or os.environ.get("HAVC_PRECISION", "fast")
+        if self.precision not in ("fast", "precise"):
+            raise HAVCError(f"HAVC: precision must be 'fast' or 'precise', not {self.precision!r}")
         # ---- __init__.py:2452-2462: method <-> merge weight normalisation ----
         merge_weight = 0.0 if method == 0 else (1.0 if method == 1 else mweight)
         if merge_weight == 0.0:
@@ -152,7 +157,7 @@ class HAVCFrameColorizer:
             from .render import ModelImageRender
             name, w = {0: ("video", 0), 1: ("stable", DEF_STABLE_WEIGHT), 2: ("artistic", DEF_ARTISTIC_WEIGHT)}.get(self.deoldify_model, ("video", 0))
             self._deoldify = ModelImageRender(self._package_dir, name, self.deoldify_rf, video_weight=w, device_index=self.device_index,
-                                              state_dicts=self._sds, max_batch=self.max_batch)
+                                              state_dicts=self._sds, max_batch=self.max_batch, precision=self.precision)
         return self._deoldify
 
     def _ddcolor_model(self, input_size):
@@ -161,6 +166,7 @@ class HAVCFrameColorizer:
             kw = dict(self._dd_kwargs)
             if self._side_by_side():
                 kw.setdefault("worker", ("havc-ddcolor", 0))
+            kw.setdefault("precision", self.precision)
             self._ddcolor = DDColorRender(self.ddcolor_model, input_size, self.device_index, state_dict=self._dd_sd, model_dir=self._dd_dir, **kw)
             self._dd_size = input_size
         return self._ddcolor
@@ -171,7 +177,8 @@ class HAVCFrameColorizer:
             return self._ddcolor_model(input_size).colorize_frames(sq, max_batch=self.max_batch)
         from .colorization import ModelColorization                                               # vsmodels.py:346-350
         if self._zhang is None:
-            self._zhang = ModelColorization("siggraph17" if self.ddcolor_model == 2 else "eccv16", True, self.device_index, state_dict=self._zh_sd)
+            self._zhang = ModelColorization("siggraph17" if self.ddcolor_model == 2 else "eccv16", True, self.device_index, state_dict=self._zh_sd,
+                                            precision=self.precision)
         return self._zhang.colorize_frames(sq)                                                    # host or device clip: havc_zhang_frames takes both
 
     def _side_by_side(self):
@@ -343,14 +350,15 @@ def HAVC_colorizer(clip, method=2, mweight=0.4, deoldify_p=(0, 24, 1.0, 0.0), dd
                    sc_threshold=0.0, sc_tht_offset=1, sc_min_freq=0, sc_tht_ssim=0.0, sc_normalize=False, sc_min_int=1, sc_tht_white=DEF_THT_WHITE,
                    sc_tht_black=DEF_THT_BLACK, device_index=0, torch_dir=None, debug_level=0, **harness):
     """vsdeoldify/__init__.py:2290-2298.  `harness` = keyword-only extras of this library: state_dicts / ddcolor_state_dict /
-    zhang_state_dict (seeded weights instead of files under torch_dir), ddcolor_model_dir, max_batch, ddcolor_kwargs."""
+    zhang_state_dict (seeded weights instead of files under torch_dir), ddcolor_model_dir, max_batch, ddcolor_kwargs, precision ("fast" / "precise")."""
     if clip is None or not (is_device(clip) or isinstance(clip, np.ndarray)):
         raise HAVCError("HAVC_colorizer: this is not a clip")                                     # __init__.py:2437-2438
     _refuse_vs_only(ddtweak, sc_threshold, sc_min_freq)
     cmc = list(cmc_p) if isinstance(cmc_p, (list, tuple)) else [cmc_p]
     flags = tuple(ddtweak) if isinstance(ddtweak, (list, tuple)) else (ddtweak, False, False)
     key = (method, mweight, tuple(deoldify_p), tuple(ddcolor_p), tuple(cmc), tuple(lmm_p), tuple(alm_p), tuple(crt_p), cmb_sw, device_index,
-           torch_dir, id(harness.get("state_dicts")), id(harness.get("ddcolor_state_dict")), harness.get("max_batch", 1), flags, repr(ddtweak_p))
+           torch_dir, id(harness.get("state_dicts")), id(harness.get("ddcolor_state_dict")), harness.get("max_batch", 1), flags, repr(ddtweak_p),
+           harness.get("precision") or os.environ.get("HAVC_PRECISION", "fast"))
     col = _colorizers.get(key)
     if col is None:
         col = HAVCFrameColorizer(method, mweight, deoldify_p, ddcolor_p, cmc, lmm_p, alm_p, crt_p, cmb_sw, device_index, package_dir=torch_dir,

@@ -221,10 +221,17 @@ def pack_conv(pack, W, cmap, Ci, bias=None, scale=None, shift=None, pixshuf=Fals
                       -1 if shift is None else pack.add(shift), Kc, Npad, Ci, Cout, Cin, KH, KW, C8a, pscale)
 
 
+# op types that exist in precise form (HAVC_F_PRECISE): the DeOldify generators (round 4: csrc/precise.hip), the Zhang colorizers and DDColor (round 5:
+# csrc/precise2.hip, csrc/zhang.hip); BILINEAR2 works on fp32 maps in both modes
+PRECISE_OPS = (nat.OP_CONV, nat.OP_MAXPOOL, nat.OP_BLUR_RESIZE, nat.OP_AFFINE, nat.OP_ATTENTION, nat.OP_PREP_RGB8, nat.OP_SUBSAMPLE2, nat.OP_PROJ2,
+               nat.OP_BILINEAR2, nat.OP_PREP_LAB_L, nat.OP_DWCONV7, nat.OP_LAYERNORM, nat.OP_MHA, nat.OP_PREP_DDCOLOR, nat.OP_FOLD_QUERIES,
+               nat.OP_SHUF4_BLUR_AB)
+
+
 class PlanBuilder:
     def __init__(self, precise=False):
         """precise: every tensor is a hi / lo pair of fp16 planes in one buffer (pixel row = [hi: P | lo: P], View.cpitch = 2 P) and every
-        op carries HAVC_F_PRECISE (include/havc_mi355.h); only the op types of the DeOldify generators exist in that form."""
+        op carries HAVC_F_PRECISE (include/havc_mi355.h); the op types of PRECISE_OPS exist in that form."""
         self.ops, self.bufs, self.names, self.precise = [], [], [], precise
         self.pm = 2 if precise else 1          # pitch multiplier
 
@@ -246,7 +253,7 @@ class PlanBuilder:
         for k, v in kw.items():
             op[k] = v
         if self.precise:
-            assert int(op["type"]) in (nat.OP_CONV, nat.OP_MAXPOOL, nat.OP_BLUR_RESIZE, nat.OP_AFFINE, nat.OP_ATTENTION, nat.OP_PREP_RGB8), name
+            assert int(op["type"]) in PRECISE_OPS, name
             op["flags"] |= nat.F_PRECISE
         if tag is None:
             tag = TAG_FIRST_FREE + len(self.names)
@@ -372,6 +379,14 @@ class PlanBuilder:
         assert y.H == 4 * Hi and y.W == 4 * Wi and img.H == y.H and img.W == y.W
         return self._op(name, type=nat.OP_SHUF4_BLUR_AB, src=proj_buf, src2=img.buf, res_coff=img.coff, res_cpitch=img.cpitch, dst=y.buf,
                         dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=Hi, Wi=Wi, Ci=2, Ho=y.H, Wo=y.W, Co=2, w_off=rimg_off, bias_off=bias_off, flops=flops)
+
+    def shuf4_blur_proj(self, name, x, m_buf, img, rimg_off, bias_off, y, flops=0):
+        """precise form of the DDColor tail (HAVC_OP_SHUF4_BLUR_AB with HAVC_F_PRECISE): x = the last_shuf conv's [Hi][Wi][16 * 256] pair tensor,
+        m_buf = the folded einsum + refine projection (fp32 [2][256] per frame, fold_queries): PixelShuffle(4) + blur + projection + image term -> y channels 0-1."""
+        assert self.precise and x.C == 16 * 256 and y.H == 4 * x.H and y.W == 4 * x.W and img.H == y.H and img.W == y.W
+        return self._op(name, type=nat.OP_SHUF4_BLUR_AB, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, src2=img.buf, res_coff=img.coff, res_cpitch=img.cpitch,
+                        aux0=m_buf, dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W, Ci=x.C, Ho=y.H, Wo=y.W, Co=2, w_off=rimg_off,
+                        bias_off=bias_off, flops=flops)
 
     def layernorm(self, name, x, y, gamma_off, beta_off, eps, relu=False):
         assert x.C == y.C and x.H * x.W == y.H * y.W

@@ -17,8 +17,11 @@ KROWS = {0: (1, 3), 1: (0, 2)}       # ConvTranspose kernel rows feeding output 
 
 
 class ZhangGenerator:
-    def __init__(self, state_dict, model="eccv16"):
-        assert model in ("eccv16", "siggraph17")
+    def __init__(self, state_dict, model="eccv16", precision="fast"):
+        """precision: "fast" = fp16 activations, fp32 accumulate; "precise" = the reference's fp32 arithmetic (colorization/__init__.py:76-95 runs the nets
+        in fp32) on hi / lo fp16 pairs: three-segment convs, fp32 softmax / tanh projection (HAVC_F_PRECISE, csrc/precise2.hip)."""
+        assert model in ("eccv16", "siggraph17") and precision in ("fast", "precise")
+        self.precise = precision == "precise"
         self.sd, self.model = to_np(state_dict), model
         self.pack, self._pc, self._vec = WeightPack(), {}, {}
         self._frozen = False
@@ -40,7 +43,7 @@ class ZhangGenerator:
             kw = {}
             if bn:
                 kw["scale"], kw["shift"] = bn_scale_shift(sd, bn)
-            return pack_conv(self.pack, sd[key + ".weight"].astype(np.float32), x.cmap, x.span, bias=sd[key + ".bias"], **kw)
+            return pack_conv(self.pack, sd[key + ".weight"].astype(np.float32), x.cmap, x.span, bias=sd[key + ".bias"], precise=self.precise, **kw)
         pc = self._cached(self._pc, key, make)
         k = pc.kh
         Ho = (x.H + 2 * pad - dil * (k - 1) - 1) // stride + 1
@@ -67,7 +70,7 @@ class ZhangGenerator:
             for px in (0, 1):
                 def make(py=py, px=px):
                     Wsub = WT[:, :, KROWS[py], :][:, :, :, KROWS[px]].transpose(1, 0, 2, 3)    # [Cout, Cin, a, b]
-                    return pack_conv(self.pack, np.ascontiguousarray(Wsub), x.cmap, x.span, bias=sd[key + ".bias"])
+                    return pack_conv(self.pack, np.ascontiguousarray(Wsub), x.cmap, x.span, bias=sd[key + ".bias"], precise=self.precise)
                 pc = self._cached(self._pc, f"{key}.p{py}{px}", make)
                 flags = (nat.F_RELU_PRE if relu_pre else 0) | (nat.F_RESIDUAL if res is not None else 0) | \
                         (nat.F_RELU_POST if relu_post else 0)
@@ -87,7 +90,7 @@ class ZhangGenerator:
     def plan(self, S=256):
         assert S % 8 == 0
         sd = self.sd
-        b = PlanBuilder()
+        b = PlanBuilder(precise=self.precise)
         in_buf = b.buf(S * S * 3, 1)
         out_buf = b.buf(S * S * 2, 4)
         x = b.tensor(S, S, 4 if self.model == "siggraph17" else 1, zero_init=False)
