@@ -194,6 +194,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the sustained / PCIe-inclusive / batch-1 legs")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the short c3 / c4 / c5 legs of the default run")
     ap.add_argument("--no-precise", action="store_true", help="skip the precise-mode leg (ModelImageRender(precision='precise'))")
+    ap.add_argument("--precision", default="fast", choices=["fast", "precise"],
+                    help="c3 / c4: build every model of the graph in this mode (HAVCFrameColorizer(precision=...)); the headline config has its own precise leg")
     ap.add_argument("--sustain-seconds", type=float, default=30.0)
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU-oracle baseline leg (0 = all host cores: os.cpu_count())")
     args = ap.parse_args()
@@ -364,29 +366,35 @@ def other_configs_leg(args):
     """c3 / c4 / c5 (BASELINE configs[2..4]) in child processes: {value, ms_per_step, whole_path_tflops, roofline frac, parity} per config"""
     import subprocess
     res = {}
-    for cfg in ("c3", "c4", "c5"):
-        # (c5's first windows carry the exemplar, the growth of the working memory and the first consolidation: its steady state needs a longer warm-up)
-        steps, warm = ("8", "4") if cfg == "c5" else ("3", "1")
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", steps, "--warmup", warm, "--no-extras", "--cpu-threads", str(args.cpu_threads)]
+
+    def child(cfg, extra, steps, warm):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", steps, "--warmup", warm, "--no-extras", "--cpu-threads", str(args.cpu_threads)] + extra
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
         t0 = time.time()
         try:
-            p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=420, cwd=ROOT)
             lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if p.returncode != 0 or not lines:
                 raise RuntimeError(f"rc {p.returncode}: {(p.stderr or p.stdout)[-300:]}")
             o = json.loads(lines[-1])
             par = o.get("parity") or {}
-            res[cfg] = {"metric": o["metric"], "value": o["value"], "unit": "frames/s", "ms_per_step": o["ms_per_step"],
-                        "frames_per_step": o["config"].get("frames_per_step_per_gpu"), "steps": o["steps"],
-                        "whole_path_tflops": o.get("whole_path_tflops"), "whole_path_frac": round((o.get("whole_path_tflops") or 0.0) / PEAK_F16_TFLOPS, 4),
-                        "roofline": {k: o["roofline"].get(k) for k in ("bound", "scope", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "frames_per_launch") if k in o["roofline"]},
-                        "parity": {k: par.get(k) for k in ("ciede2000_mean", "ciede2000_p99", "pixels_with_dE_below_1", "frames_checked")} if par else None,
-                        "cpu_baseline": (o.get("cpu_baseline") or {}).get("value"), "workload": o["config"]["workload"],
-                        "leg_seconds": round(time.time() - t0, 1)}
+            return {"metric": o["metric"], "value": o["value"], "unit": "frames/s", "ms_per_step": o["ms_per_step"], "dtype": o.get("dtype"),
+                    "frames_per_step": o["config"].get("frames_per_step_per_gpu"), "steps": o["steps"],
+                    "whole_path_tflops": o.get("whole_path_tflops"), "whole_path_frac": round((o.get("whole_path_tflops") or 0.0) / PEAK_F16_TFLOPS, 4),
+                    "roofline": {k: o["roofline"].get(k) for k in ("bound", "scope", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "frames_per_launch") if k in o["roofline"]},
+                    "parity": {k: par.get(k) for k in ("ciede2000_mean", "ciede2000_p99", "ciede2000_max", "pixels_with_dE_below_1", "meets_contract", "frames_checked")} if par else None,
+                    "cpu_baseline": (o.get("cpu_baseline") or {}).get("value"), "workload": o["config"]["workload"],
+                    "leg_seconds": round(time.time() - t0, 1)}
         except Exception as e:                                  # noqa: BLE001 -- a leg never costs the headline line
-            res[cfg] = {"error": f"{type(e).__name__}: {e}", "leg_seconds": round(time.time() - t0, 1)}
+            return {"error": f"{type(e).__name__}: {e}", "leg_seconds": round(time.time() - t0, 1)}
+    for cfg in ("c3", "c4", "c5"):
+        # (c5's first windows carry the exemplar, the growth of the working memory and the first consolidation: its steady state needs a longer warm-up)
+        steps, warm = ("8", "4") if cfg == "c5" else ("3", "1")
+        res[cfg] = child(cfg, [], steps, warm)
+        if cfg in ("c3", "c4") and not args.no_precise:
+            # the same graph with every model in precise mode (HAVCFrameColorizer(precision="precise"), round 5): 16 frames per step (pair activations)
+            res[cfg]["precise"] = child(cfg, ["--precision", "precise", "--batch", "16"], "2", "1")
     return res
 
 
@@ -468,7 +476,7 @@ def extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds):
     # ---- batch 1, one blocking call per frame: what a ModifyFrame selector gets ----
     from PIL import Image
     from vsdeoldify_amd.render import ModelImageRender
-    r1 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1)
+    r1 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1, low_latency=False)
     S = RENDER_FACTOR * 16
     img = Image.fromarray(np.ascontiguousarray(frames[0][:S, :S]))
     for _ in range(3):
@@ -479,9 +487,10 @@ def extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds):
         r1.get_transformed_image(img)
     dt = time.perf_counter() - t0
     res["batch1"] = {"value": round(k / dt, 2), "unit": "frames/s", "ms_per_call": round(dt / k * 1e3, 3),
-                     "how": "ModelImageRender('stable', rf=35).get_transformed_image(PIL 560x560), one blocking call per frame (H2D + 2 passes + D2H)"}
+                     "how": "ModelImageRender('stable', rf=35, low_latency=False).get_transformed_image(PIL 560x560), one blocking call per frame (H2D + 2 passes + D2H) "
+                            "on the batch-independent nets (the library default for such a render is the low-latency form: next leg)"}
     # ---- the same single caller with the low-latency nets (split-K convs for one frame per launch; fp32 summation order differs) ----
-    r2 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1, low_latency=True)
+    r2 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1)      # the default: low-latency nets
     for _ in range(3):
         r2.get_transformed_image(img)
     t0 = time.perf_counter()
@@ -489,7 +498,8 @@ def extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds):
         r2.get_transformed_image(img)
     dt = time.perf_counter() - t0
     res["batch1_low_latency"] = {"value": round(k / dt, 2), "unit": "frames/s", "ms_per_call": round(dt / k * 1e3, 3),
-                                 "how": "the same call on ModelImageRender(..., low_latency=True) / HAVC_LOW_LATENCY=1: nets for one frame per launch with split-K convs"}
+                                 "how": "the same call on the DEFAULT render of that shape (max_batch 1 => low-latency nets since round 5): one frame per launch, split-K convs "
+                                        "whose parts the last block of a tile adds inside the conv kernel"}
     # ---- the same per-frame call from 16 threads (VapourSynth's worker pool) through ONE coalescing render: havc_batcher ----
     import threading
     T, K = 16, 6
@@ -530,11 +540,11 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
     dd_defaults = dict(ddtweak=(False, False, False), ddtweak_p=(DEF_TWEAK_p, HUE_ADJUST))      # HAVC_colorizer's defaults (__init__.py:2292-2293)
     if ddcolor_only:
         col = HAVCFrameColorizer(method=1, ddcolor_p=(1, 32, 1.0, 0.0, True), device_index=local_rank,
-                                 ddcolor_state_dict=synth_ddcolor_state_dict(1), max_batch=args.batch, **dd_defaults)
+                                 ddcolor_state_dict=synth_ddcolor_state_dict(1), max_batch=args.batch, precision=args.precision, **dd_defaults)
     else:
         col = HAVCFrameColorizer(method=2, mweight=0.4, deoldify_p=(0, 24, 1.0, 0.0), ddcolor_p=(1, 24, 1.0, 0.0, True), device_index=local_rank,
                                  state_dicts={"video": synth_state_dict("wide", 1)}, ddcolor_state_dict=synth_ddcolor_state_dict(1),
-                                 max_batch=args.batch, **dd_defaults)
+                                 max_batch=args.batch, precision=args.precision, **dd_defaults)
     ctx = col.ctx
     frames = np.stack([synthetic_gray_frame(rank * args.batch + i, WIDTH, HEIGHT) for i in range(args.batch)])
     clip = DeviceImage.from_numpy(ctx, frames)
@@ -606,7 +616,7 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
                      "colorized frames/sec/GPU @1080p (HAVC DeOldify+DDColor merge, combine_method=2)", "value": round(total / elapsed, 3),
            "unit": "frames/s (sum over n_gpus)", "n_gpus": world, "value_per_gpu": round(total / elapsed / world, 3), "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f16", "data": "synthetic",
+           "dtype": "f16" if args.precision == "fast" else "f16x2 (hi / lo pairs, fp32 accumulate)", "precision": args.precision, "data": "synthetic",
            "config": {"workload": "DDColor modelsize=large, 512 input, 1080p clip (BASELINE.json configs[2])" if ddcolor_only else
                                   "HAVC DeOldify+DDColor merge (combine_method=2) 1080p, frame-sharded (BASELINE.json configs[3])",
                       "frames_per_step_per_gpu": args.batch, "deoldify": None if ddcolor_only else "video, rf=24 (384x384)",
@@ -633,10 +643,8 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
         d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
         out["cpu_baseline"] = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
                                "sample": f"1 frame of the 1080p clip through the oracle graph (fp32 torch models + numpy tail), {dt:.1f} s"}
-        out["parity"] = {"ciede2000_mean": round(float(de.mean()), 4), "ciede2000_p99": round(float(np.percentile(de, 99)), 4),
-                         "ciede2000_max": round(float(de.max()), 4), "pixels_with_dE_below_1": round(float((de < 1.0).mean()), 5),
-                         "bytes_within_2lsb": round(float((d <= 2).mean()), 5), "frames_checked": 1,
-                         "against": "oracle graph (CPU fp32); DDColor itself is parity-UNPINNED (external wheel, oracle/ddcolor.py)"}
+        out["parity"] = dict(_stats(de, d), frames_checked=1,
+                             against="oracle graph (CPU fp32); DDColor itself is parity-UNPINNED (external wheel, oracle/ddcolor.py)")
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -169,19 +169,32 @@ def test_fused_shuffle_blur_with_padded_channel_counts_deep(ctx):
     assert np.array_equal(outs[0], outs[1])
 
 
-def test_low_latency_split_k_plan_matches_the_default_plan(ctx, sds):
-    """ModelImageRender(low_latency=True): nets for one frame per call with split-K convs (both generators, i.e. both streams of the context).
-    Same arithmetic up to the fp32 summation order of the K parts (which moves some fp16 roundings of the stored activations): the final images
-    agree within 2 LSB everywhere and exactly on > 90 % of the bytes (measured 93 %), and both meet the tolerance against the oracle."""
+@pytest.mark.parametrize("seeds,rf", [((1, 2), 6), ((11, 12), 10), ((21, 22), 10), ((1, 2), 35)])
+def test_low_latency_split_k_plan_matches_the_batched_plan(ctx, seeds, rf, monkeypatch):
+    """The DEFAULT of a one-frame-per-call render (round 5; HAVC_LOW_LATENCY unset = on): nets with split-K convs whose parts the last block of a tile
+    adds in a fixed order (both generators, i.e. both streams of the context).  Same arithmetic up to the fp32 summation order of the K parts (which
+    moves some fp16 roundings of the stored activations): against the batch-independent nets the final images agree within 2 LSB everywhere and
+    exactly on > 90 % of the bytes, on three seeded weight sets and at the headline size (rf 35), and both meet the tolerance against the oracle."""
     from PIL import Image
-    rf, img = 6, make_frame(96, 9)
-    base = ModelImageRender(None, "stable", rf, 0.5, state_dicts=sds)
-    fast = ModelImageRender(None, "stable", rf, 0.5, state_dicts=sds, low_latency=True)
-    a = np.asarray(base.get_transformed_image(Image.fromarray(img)))
-    b = np.asarray(fast.get_transformed_image(Image.fromarray(img)))
-    net = fast._video.net(96, 1, True)
-    nsplit = sum(1 for o in net.ops if o["type"] == nat.OP_CONV and (int(o["flags"]) >> 16) & 15)
-    assert nsplit > 20 and net is not fast._video.net(96, 1)
-    d = np.abs(a.astype(int) - b.astype(int))
-    assert d.max() <= 2 and (d == 0).mean() > 0.90, (int(d.max()), float((d == 0).mean()))
-    check_final(b, pipeline.model_image_render(sds, "stable", img, rf, 0.5))
+    sds = {"video": synth_state_dict("wide", seeds[0]), "stable": synth_state_dict("wide", seeds[1])}
+    S = rf * 16
+    img = make_frame(S, 9)
+    base = ModelImageRender(None, "stable", rf, 0.5, state_dicts=sds, low_latency=False)
+    monkeypatch.delenv("HAVC_LOW_LATENCY", raising=False)
+    fast = ModelImageRender(None, "stable", rf, 0.5, state_dicts=sds)                # the library default
+    assert fast._low_latency and not base._low_latency
+    try:
+        a = np.asarray(base.get_transformed_image(Image.fromarray(img)))
+        b = np.asarray(fast.get_transformed_image(Image.fromarray(img)))
+        net = fast._video.net(S, 1, True)
+        nsplit = sum(1 for o in net.ops if o["type"] == nat.OP_CONV and (int(o["flags"]) >> 16) & 15)
+        assert nsplit > 20 and net is not base._video.net(S, 1)
+        d = np.abs(a.astype(int) - b.astype(int))
+        print(f"low-latency vs batched plan, seeds {seeds} rf {rf}: max |d| {int(d.max())} LSB, bytes equal {float((d == 0).mean()):.4f}")
+        assert d.max() <= 2 and (d == 0).mean() > 0.90, (int(d.max()), float((d == 0).mean()))
+        if rf <= 10:
+            check_final(b, pipeline.model_image_render(sds, "stable", img, rf, 0.5))
+    finally:
+        for r in (base, fast):
+            for rt in (r._video, r._second):
+                rt.close()

@@ -77,6 +77,7 @@ struct havc_ctx {
     // grow-only scratch (u8 staging + float resample rows): allocated once, reused every call
     void* scratch[14] = {nullptr};         // 0-3 staging / model i-o, 4-5 plane staging, 6 small, 7 resample rows, 8-11 pipelined host clip,
     size_t scratch_sz[14] = {0};           // 12 / 13 split-K partial sums of the launches on stream / stream2
+    int* sk_cnt[2] = {nullptr, nullptr};   // split-K arrival counters of the launches on stream / stream2 (HAVC_SK_COUNTERS ints each, all zero between launches)
     hipStream_t stream_h2d = nullptr, stream_d2h = nullptr;      // copy streams of havc_colorize_clip_host (created on first use)
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
     std::map<std::pair<int, int>, ResizeTable> resize_tables;
@@ -396,6 +397,9 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                 const size_t need = (size_t)a.splitk * batch * op.Ho * op.Wo * op.Npad * 4;
                 if (int rc2 = ensure_scratch(c, slot, need)) return rc2;
                 a.ws = (float*)c->scratch[slot];
+                // round 5: the last block of a tile reduces the parts and runs the epilogue itself (HAVC_SPLITK_FUSED=0: the separate reduce launch)
+                static const bool fused = [] { const char* e = getenv("HAVC_SPLITK_FUSED"); return e ? atoi(e) != 0 : true; }();
+                a.sk_cnt = fused ? c->sk_cnt[slot - 12] : nullptr;
             }
             {
                 const int oi = (int)(&op - n->ops.data());
@@ -936,6 +940,13 @@ int havc_create(havc_ctx** out, int device_id) {
         delete c;
         return fail(nullptr, HAVC_E_HIP, "failed to create stream/events");
     }
+    for (int k = 0; k < 2; ++k) {
+        if (hipMalloc(&c->sk_cnt[k], HAVC_SK_COUNTERS * sizeof(int)) != hipSuccess || hipMemset(c->sk_cnt[k], 0, HAVC_SK_COUNTERS * sizeof(int)) != hipSuccess) {
+            (void)hipGetLastError();
+            havc_destroy_unlocked(c);
+            return fail(nullptr, HAVC_E_HIP, "failed to allocate the split-K counters");
+        }
+    }
     static const bool eager = [] { const char* e = getenv("HAVC_EAGER_SETUP"); return e ? atoi(e) != 0 : true; }();
     if (eager) {
         preload_device_locked(device_id);
@@ -968,6 +979,8 @@ static void havc_destroy_unlocked(havc_ctx* c) {
     }
     for (int i = 0; i < 14; ++i)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
+    for (int k = 0; k < 2; ++k)
+        if (c->sk_cnt[k]) (void)hipFree(c->sk_cnt[k]);
     for (auto& kv : c->resize_tables) { (void)hipFree(kv.second.d_start); (void)hipFree(kv.second.d_w); }
     for (auto& p : c->tag_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     (void)hipEventDestroy(c->ev0);
