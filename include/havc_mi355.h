@@ -57,7 +57,10 @@ enum havc_op_type {
     HAVC_OP_BLUR_RESIZE = 3, /* replicate-pad(1,0,1,0) + avgpool2x2 s1 (+ nearest resize) into dst@coff  */
     HAVC_OP_AFFINE = 4,      /* y = act(x*scale+shift) per channel, into dst@coff (skip BN+ReLU, layers.1) */
     HAVC_OP_ATTENTION = 5,   /* fastai SelfAttention, flash form: out = gamma * softmax_i(f_i.g_j) h + x   */
-    HAVC_OP_PREP_RGB8 = 6,   /* u8 RGB -> PIL 'L' gray x3 -> /255 -> imagenet normalise -> fp16 C8         */
+    HAVC_OP_PREP_RGB8 = 6,   /* u8 RGB -> PIL 'L' gray x3 -> /255 -> imagenet normalise -> fp16 C8 (dst) and, when src2 >= 0, the same 8
+                                channels into src2 @ res_coff (the dense-merge slot of the tail tensor).  aux0 = number of pad channels BEHIND
+                                that slot which no op reads and the kernel may zero as well (>= 24 and a 64-byte aligned slot: the second
+                                destination is then written as whole 64-byte segments instead of 16-byte pieces: no read-modify-write) */
     HAVC_OP_COPY_CH = 7,     /* copy channel slice src@coff -> dst@coff (dense MergeLayer, layers.9)       */
     HAVC_OP_SUBSAMPLE2 = 8,  /* y[h][w] = x[2h][2w]  (siggraph17 `conv[:, :, ::2, ::2]`)                    */
     HAVC_OP_PROJ2 = 9,       /* per pixel C -> 2 projection in fp32: flags&1: softmax over C first (eccv16
@@ -144,8 +147,9 @@ enum havc_op_type {
                                      larger than the 256 MiB Infinity Cache that are not re-read soon (set by the runtime, HAVC_NT_STORE_MB) */
 #define HAVC_F_SPLITK(n) ((n) << 16) /* bits 16-19: split-K count n = 2..15 for convs with few output tiles and a long K (one frame of a small
                                      layer: 4 x 8 tiles on 256 CUs): the K range is cut into n parts (even stage boundaries), one block per
-                                     (tile, part) writes fp32 partial sums to a ctx scratch buffer, a second kernel adds them IN A FIXED
-                                     ORDER and runs the epilogue.  The count is part of the PLAN (chosen by the emitter from the shape), not
+                                     (tile, part) writes fp32 partial sums to a ctx scratch buffer; the LAST block of a tile to arrive (a per-tile
+                                     counter, release / acquire at agent scope) adds them IN A FIXED ORDER (0 .. n-1, its own included) and
+                                     runs the epilogue (round 5; HAVC_SPLITK_FUSED=0: a second kernel does, same bytes).  The count is part of the PLAN (chosen by the emitter from the shape), not
                                      of the tile autotuner: every tile configuration produces the same bytes for a given count.  Plain convs
                                      only (no PS_BLUR / FUSE_* / W_FROM_BUF / extra-column tile)                                      */
 #define HAVC_F_SPLITK_COUNT(flags) (((flags) >> 16) & 15)
@@ -157,10 +161,15 @@ enum havc_op_type {
                                      plain count) and the K table walks x_hi, x_hi, x_lo: the unchanged MFMA main loop accumulates
                                      2^11 (x_hi w_hi + x_hi w_lo + x_lo w_hi) in fp32 -- only the x_lo w_lo term (2^-22 relative) is
                                      dropped -- and the epilogue multiplies by f3 (2^-11 x the plan's per-conv weight pre-scale), does
-                                     bias / ReLU / affine / residual in fp32 and stores a hi / lo pair.  Valid on CONV (no PS_BLUR, FUSE_*,
-                                     OUT_TRANSPOSED, W_FROM_BUF, SPLITK, GELU), MAXPOOL, BLUR_RESIZE, AFFINE, PREP_RGB8 and ATTENTION
-                                     (fp32 VALU kernels; aux1 = NHWC value buffer, Kc = its pixel pitch).  3x the MFMA work, 2x the
-                                     activation bytes.                                                                          */
+                                     bias / ReLU / GELU (libm erff) / affine / residual in fp32 and stores a hi / lo pair.  Valid on CONV (no
+                                     PS_BLUR, FUSE_*, OUT_TRANSPOSED, W_FROM_BUF, SPLITK), MAXPOOL, BLUR_RESIZE, AFFINE, PREP_RGB8 and ATTENTION
+                                     (fp32 VALU kernels; aux1 = NHWC value buffer, Kc = its pixel pitch) and, since round 5 (the reference runs
+                                     EVERY model in fp32: colorization/__init__.py:76-95, vsslib/vsmodels.py:353-363), on the ops of the Zhang
+                                     colorizers and DDColor: SUBSAMPLE2, PROJ2, PREP_LAB_L, DWCONV7 (w_off then holds fp32 weights), LAYERNORM,
+                                     MHA, PREP_DDCOLOR, FOLD_QUERIES and SHUF4_BLUR_AB -- the latter in a form of its own: src = the last_shuf
+                                     conv's pair tensor [Hi][Wi][16 x 256], aux0 = the fp32 [2][256] projection of FOLD_QUERIES; the shuffle,
+                                     the blur, the projection, the image term and the bias run in ONE fp32 kernel (csrc/precise2.hip).
+                                     3x the MFMA work, 2x the activation bytes.                                                  */
 #define HAVC_F_FUSE_RGB8 0x100    /* the conv output is NOT stored: a following 1x1 conv to 3 channels (fp32 weights at
                                      scale_off [3][Npad], bias at shift_off [3]) + OUT_RGB8 maths run in the epilogue and
                                      write u8 RGB to buffer aux0 (layers.10.1 + layers.11 + layers.12 of the generator);

@@ -684,6 +684,11 @@ class ColorMNetNetwork:
                 ready = all(is_device(f) and (f.complete or getattr(f, "produced_on_lookahead", False)) for f in frames)
                 if hn is not self and not ready:
                     hn.stream.wait_stream(self.stream)
+                    # wait_stream orders the look-ahead stream behind THIS network's stream only: a frame still being written on a foreign context's
+                    # stream (another model's output handed over unsynchronised) is drained on the host, as DeepExColorMNet._announce does
+                    for pctx in {id(f.ctx): f.ctx for f in frames if is_device(f) and not f.complete and not getattr(f, "produced_on_lookahead", False)
+                                 and f.ctx is not self.ctx and f.ctx is not hn.ctx}.values():
+                        pctx.synchronize()
                 with torch.cuda.stream(hn.stream):
                     B = len(frames)
                     labs = torch.empty((B, 3, shape0[0], shape0[1]), dtype=torch.float32, device=self.device)

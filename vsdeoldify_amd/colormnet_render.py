@@ -225,7 +225,11 @@ class ColorMNetRender:
             lab, img = ahead[1], ahead[2][5]
             from .colormnet_fast import frame_pads
             pad = frame_pads(lab.shape[-2], lab.shape[-1])[0]
-        elif is_device(frame_i) and getattr(net, "async_lookahead", False) and self.first_mask_loaded and ref is None:
+        elif is_device(frame_i) and getattr(net, "async_lookahead", False) and self.first_mask_loaded and ref is None and \
+                (frame_i.ctx is net.ctx or getattr(frame_i, "produced_on_lookahead", False)):
+            # (only frames whose buffer belongs to the network's own context -- or to the look-ahead context that will read it: the read queued on
+            #  the look-ahead stream is then ordered before any reuse of the buffer, because that context's stream waits for the pass's `done` event
+            #  before the step continues; a frame of a FOREIGN context could be recycled by its owner while the read is still queued: ADVICE r4)
             # a frame nobody announced, handed over in HBM by a caller that does not block on the result: its key encoder still runs on the
             # look-ahead stream (one frame per pass), so that it overlaps the memory step of the PREVIOUS frame -- consecutive colorize_frame calls
             # pipeline on the GPU (212 -> ~300 frames/s for the reference's own call shape)
@@ -322,7 +326,7 @@ class DeepExColorMNet:
         from .device import is_device
         from .havc import spline64
         h, w = frame.shape[:2]
-        if _small is None and is_device(frame) and frame.complete and ref is None and self.render.first_mask_loaded:
+        if _small is None and is_device(frame) and frame.complete and ref is None and self.render.first_mask_loaded and frame.ctx is self.render.network.ctx:
             # a resident frame nobody announced: squashed on the look-ahead context, where its key encoder will run -- nothing of this frame's
             # preparation waits for the memory step of the previous one (ColorMNetRender._colorize_frame_fast)
             net = self.render.network
