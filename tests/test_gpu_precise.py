@@ -32,7 +32,12 @@ pytestmark = pytest.mark.gpu
 
 PRECISE_RAW = dict(equal=0.999, max_lsb=1)
 PRECISE_CLIP = dict(p99=1.0, frac_lt1=0.99)                 # the contract (BASELINE.json north_star)
-FAST_CLIP = dict(mean=0.35, p99=2.6, frac_lt1=0.84)         # fp16 path on ANY of the three weight sets (bench seeds: 0.12 / 1.25 / 0.97; seeds 11, 12: 0.24 / 2.27 / 0.87)
+# fp16 path, per weight set: measured worst frame on MI355X + 15 % (profiles/r4_pytest_gpu.txt: seeds (1, 2) mean 0.120 / p99 1.251 / below-1.0 0.9675;
+# (11, 12) 0.246 / 2.266 / 0.8641; (21, 22) 0.217 / 1.980 / 0.8936; the fraction's slack is 15 % of 1 - fraction).  These prove "no regression", not
+# "within the contract": the contract thresholds are PRECISE_CLIP, met by precision="precise" only.
+FAST_CLIP_BY_SEED = {(1, 2): dict(mean=0.138, p99=1.44, frac_lt1=0.9626), (11, 12): dict(mean=0.283, p99=2.61, frac_lt1=0.8437),
+                     (21, 22): dict(mean=0.250, p99=2.28, frac_lt1=0.8776)}
+FAST_CLIP = dict(mean=0.198, p99=2.23, frac_lt1=0.9144)      # pooled over the 8 frames x 3 weight sets: measured 0.1718 / 1.938 / 0.9256, + 15 %
 
 
 def close32(got, ref, what, rtol=2e-6, atol=1e-6):
@@ -192,8 +197,9 @@ def test_colorize_clip_1080p_8_frames_3_weight_sets_precise_meets_the_contract(c
                 if mode == "precise":
                     assert p99 < PRECISE_CLIP["p99"] and frac >= PRECISE_CLIP["frac_lt1"], (sv, ss, idx[k], p99, frac)
                 else:
-                    assert de.mean() < FAST_CLIP["mean"] and p99 < FAST_CLIP["p99"] and frac >= FAST_CLIP["frac_lt1"], (sv, ss, idx[k], float(de.mean()), p99, frac)
+                    lim_s = FAST_CLIP_BY_SEED[(sv, ss)]
+                    assert de.mean() < lim_s["mean"] and p99 < lim_s["p99"] and frac >= lim_s["frac_lt1"], (sv, ss, idx[k], float(de.mean()), p99, frac)
     for mode, lim in (("precise", PRECISE_CLIP), ("fast", FAST_CLIP)):
         de = np.concatenate(pooled[mode])
         print(f"pooled {mode}: mean {de.mean():.4f} p99 {np.percentile(de, 99):.3f} dE<1 {float((de < 1).mean()):.5f}")
-        assert np.percentile(de, 99) < lim["p99"] and (de < 1.0).mean() >= lim["frac_lt1"]
+        assert np.percentile(de, 99) < lim["p99"] and (de < 1.0).mean() >= lim["frac_lt1"] and (mode == "precise" or de.mean() < lim["mean"])

@@ -127,6 +127,7 @@ def test_gpu_model_colorization_frame(ctx, model, hw):
     ref = zhang.colorize_frame(tsd(sd), model, img)
     de = imaging.delta_e00_images(got, ref)
     d = np.abs(got.astype(int) - ref.astype(int))
+    print(f"zhang {model} {hw} fast: mean dE00 {de.mean():.4f} p99 {np.percentile(de, 99):.3f} bytes within 1 LSB {(d <= 1).mean():.4f} max |d| {d.max()}")
     assert got.shape == img.shape and de.mean() < 0.5 and np.percentile(de, 99) < 2.5 and (d <= 1).mean() >= 0.97, \
         (de.mean(), np.percentile(de, 99), (d <= 1).mean(), d.max())
     mc.close()
