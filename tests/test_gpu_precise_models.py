@@ -248,3 +248,35 @@ def test_precise_ddcolor_configs_meet_the_contract_at_full_size(ctx, config):
     p99, frac = float(np.percentile(de, 99)), float((de < 1.0).mean())
     print(f"{config} precise @1080p: mean dE00 {de.mean():.5f} p99 {p99:.4f} below 1.0: {frac:.5f} max {de.max():.2f}")
     assert got.shape == frame.shape and p99 < CONTRACT["p99"] and frac >= CONTRACT["frac_lt1"], (config, p99, frac)
+
+
+@pytest.mark.parametrize("C,hw", [(512, (35, 35)), (256, (9, 13)), (768, (12, 12))])
+def test_precise_attention_on_mfma_and_the_transposed_value_conv(ctx, C, hw):
+    """fastai SelfAttention (fastai/layers.py:81-96) with the P . H product on MFMA (three-term splitting, csrc/precise.hip pattn_apply_mfma_kernel): the value
+    map comes from a 1x1 conv whose precise epilogue stores it transposed as two planes [2][C][npitch]; vs float64.  N = 1225 / 117 / 144 keys (not
+    multiples of the 64-query / 32-key tiles), probabilities from ~1 down to e^-30 (scores scaled up on purpose)."""
+    H, W = hw
+    B, d, N = 2, C // 8, hw[0] * hw[1]
+    r = np.random.default_rng(C + H)
+    x = r.standard_normal((B, C, H, W)).astype(np.float32)
+    f = (r.standard_normal((B, d, H, W)) * 0.9).astype(np.float32)
+    g = (r.standard_normal((B, d, H, W)) * 0.9).astype(np.float32)
+    Wv = (r.standard_normal((C, C, 1, 1)) / np.sqrt(C) * 3).astype(np.float32)
+    pack, b = WeightPack(), PlanBuilder(precise=True)
+    xv, qk, av = b.tensor(H, W, C), b.tensor(H, W, 2 * d), b.tensor(H, W, C)
+    npitch = (N + 63) // 64 * 64
+    vT = b.buf(2 * C * npitch, 2, zero_init=True)
+    b.conv("value", pack_conv(pack, Wv, xv.cmap, xv.span, precise=True), xv, vT, flags=nat.F_OUT_TRANSPOSED, Co=C, aux0=npitch)
+    b.attention("attn", xv, qk, d, vT, npitch, av, 0.37, transposed=True)
+    out = gu.run_plan(ctx, pack, b, {xv.buf: gu.hl_pack(x, xv.cpitch), qk.buf: gu.hl_pack(np.concatenate([f, g], 1), qk.cpitch)},
+                      {av.buf: _shape(av, B), vT: ((B, 2, C, npitch), np.float16)}, B)
+    xt = torch.from_numpy(x).double()
+    h = F.conv2d(xt, torch.from_numpy(Wv).double()).reshape(B, C, N)
+    vt = out[vT]
+    got_h = vt[:, 0, :, :N].astype(np.float32) + vt[:, 1, :, :N].astype(np.float32) / 2048.0
+    close32(got_h, h.float().numpy(), "transposed value conv")
+    assert (vt[:, :, :, N:] == 0).all(), "columns beyond N must stay zero"
+    ft, gt = (torch.from_numpy(a).double().reshape(B, d, N) for a in (f, g))
+    beta = F.softmax(torch.bmm(ft.permute(0, 2, 1), gt), dim=1)
+    ref = 0.37 * torch.bmm(h, beta) + xt.reshape(B, C, N)
+    close32(gu.hl_unpack(out[av.buf], C), ref.float().reshape(B, C, H, W).numpy(), "self attention on MFMA", rtol=2e-5)

@@ -110,6 +110,16 @@ __device__ __forceinline__ void epilogue_frag_precise(const ConvArgs& p, const f
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) { half_t a, b; split_hl(v[r], a, b); oh[r] = a; ol[r] = b; }
+    if (p.flags & HAVC_F_OUT_TRANSPOSED) {                      // [2][Co][pix_pitch] per frame: hi plane, then lo plane (the precise attention's value operand)
+        const int b = m / HoWo;
+        const int64_t base = (int64_t)b * 2 * p.Co * p.pix_pitch + (m - b * HoWo);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            y[base + (int64_t)(n + r) * p.pix_pitch] = oh[r];
+            y[base + (int64_t)(p.Co + n + r) * p.pix_pitch] = ol[r];
+        }
+        return;
+    }
     half_t* d = y + mo * p.y_cpitch + p.y_coff + n;
     *reinterpret_cast<half4*>(d) = oh;
     *reinterpret_cast<half4*>(d + ylo) = ol;

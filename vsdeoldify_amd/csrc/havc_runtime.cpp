@@ -384,7 +384,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             if (a.splitk == 1) a.splitk = 0;
             a.pscale = 1.f;
             if (op.flags & HAVC_F_PRECISE) {
-                if ((op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_FUSE_PROJ | HAVC_F_OUT_TRANSPOSED | HAVC_F_W_FROM_BUF)) || a.splitk ||
+                if ((op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_FUSE_PROJ | HAVC_F_W_FROM_BUF)) || a.splitk ||
                     !(op.f3 > 0.f) || (op.src_cpitch & 15) || (!(op.flags & HAVC_F_OUT_RGB8) && (op.dst_cpitch & 15)))
                     return fail(c, HAVC_E_INVALID, "conv op: PRECISE needs a plain conv (no fused / transposed / split-K form), f3 = accumulator scale > 0, hi|lo pixel rows");
                 a.pscale = op.f3;
@@ -516,6 +516,20 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                 if (op.kh < 0 || op.kh >= (int)n->bufs.size() || n->bufdesc[op.kh].elem_bytes != 4 ||
                     (uint64_t)n->bufdesc[op.kh].elems_per_frame < (uint64_t)op.Hi * op.Wi * 2 || !attention_p_supported(op.aux0, op.Ci))
                     return fail(c, HAVC_E_INVALID, "attention op: PRECISE needs an fp32 [N][2] scratch buffer in kh, d <= 128, C % 128 == 0");
+                if (op.flags & HAVC_F_OUT_TRANSPOSED) {
+                    // round 5: the value map arrives TRANSPOSED ([2][C][Kc] fp16 per frame: hi plane, lo plane; written by the value conv's transposed precise
+                    // epilogue) and the P . H product runs on MFMA with the three-term splitting (csrc/precise.hip pattn_apply_mfma_kernel)
+                    if (!attention_pm_supported(op.aux0, op.Ci, op.Kc) || (uint64_t)n->bufdesc[op.aux1].elems_per_frame < (uint64_t)2 * op.Ci * op.Kc ||
+                        op.Kc < ((op.Hi * op.Wi + 31) & ~31))
+                        return fail(c, HAVC_E_INVALID, "attention op: PRECISE | OUT_TRANSPOSED needs C % 256 == 0 and a [2][C][Kc] value buffer, Kc % 32 == 0, Kc >= N");
+                    e = launch_attention_pm((const half_t*)bufptr(n, op.src2), op.res_cpitch, op.res_coff, op.res_coff + op.aux0, op.aux0,
+                                            n->bufdesc[op.src2].elems_per_frame, (const half_t*)bufptr(n, op.aux1), op.Kc, n->bufdesc[op.aux1].elems_per_frame,
+                                            (const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, n->bufdesc[op.src].elems_per_frame,
+                                            (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff, n->bufdesc[op.dst].elems_per_frame, (float*)bufptr(n, op.kh),
+                                            batch, op.Hi * op.Wi, op.Ci, op.f0, s);
+                    c->stats.launches += 1;
+                    break;
+                }
                 e = launch_attention_p((const half_t*)bufptr(n, op.src2), op.res_cpitch, op.res_coff, op.res_coff + op.aux0, op.aux0,
                                        n->bufdesc[op.src2].elems_per_frame, (const half_t*)bufptr(n, op.aux1), op.Kc, 0, n->bufdesc[op.aux1].elems_per_frame,
                                        (const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, n->bufdesc[op.src].elems_per_frame,

@@ -196,6 +196,10 @@ int launch_blur_resize_p(const half_t* x, half_t* y, int B, int Hi, int Wi, int 
 int launch_affine_p(const half_t* x, half_t* y, const float* scale, const float* shift, int relu, int64_t npix, int C, int x_cpitch, int x_coff, int y_cpitch,
                     int y_coff, hipStream_t s);
 bool attention_p_supported(int d, int C);
+bool attention_pm_supported(int d, int C, int npitch);
+int launch_attention_pm(const half_t* qk, int qk_cpitch, int f_coff, int g_coff, int d, int64_t qk_fs, const half_t* vT, int npitch, int64_t v_fs,
+                        const half_t* x, int x_cpitch, int x_coff, int64_t x_fs, half_t* out, int o_cpitch, int o_coff, int64_t o_fs, float* stats, int B, int N,
+                        int C, float gamma, hipStream_t s);
 // precise2.hip: the non-conv ops of DDColor and the Zhang colorizers on hi / lo pairs
 int launch_proj2_p(const half_t* x, int x_cpitch, int x_coff, int C, const float* w, const float* bias, int mode, float mul, float* out, int64_t npix,
                    hipStream_t s);

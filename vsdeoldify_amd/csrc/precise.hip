@@ -283,6 +283,124 @@ __global__ void __launch_bounds__(256) pattn_apply_kernel(const PAttnArgs a) {
     }
 }
 
+// ---- the apply pass on the matrix pipe (round 5) ----
+// pattn_apply_kernel spends 11.3 ms per 16 frames of the 560 x 560 generator on fp32 FMAs (39 TFLOP/s: 13 % of a precise pass).  The P . H product
+// (94 % of the attention's work) runs here on v_mfma_f32_16x16x32_f16 with the SAME three-term splitting the precise convolutions use, so it stays
+// fp32-class:   p' = 512 p = hi' + lo'' / 2048 (fp16 pair),  h = h_hi + h_lo' / 2048 (the value map's pair),
+//   acc = (64 hi') (32 h_hi) + hi' h_lo' + lo'' h_hi = 2048 (hi' h_hi + (hi' h_lo + lo h_hi))  =  2048 * 512 * p h  up to the lo x lo term (2^-22),
+// every product of two fp16 numbers exact in fp32, fp32 accumulation; the factors 64 / 32 / 512 are powers of two chosen so that nothing overflows
+// (64 * 512 p <= 32768, 32 |h| < 65504 for |h| < 2047) and hi' is a normal fp16 number down to p = 1.2e-7.  S = f . g and the softmax stay fp32
+// VALU exactly as in the kernels above (same statistics pass).  Operands: O^T[c][j] = sum_i H^T[c][i] P[i][j] -- A = the value map TRANSPOSED
+// ([C][npitch] planes, hi then lo, written by the value conv's transposed precise epilogue), B = P[query][key]; a lane of the accumulator owns 4
+// consecutive channels of one query.  Block = 64 queries x 256 channels x key tiles of 32, 4 waves (wave w: channels 64 w .. +63), ~70 KiB of LDS:
+// two blocks per CU cover each other's load latency.
+constexpr int PM_CC = 256;
+struct PAttnMArgs {
+    const half_t* qk; const half_t* vT; const half_t* x; half_t* out; const float* stats;
+    int qk_cp, f_co, g_co, d, npitch, x_cp, x_co, o_cp, o_co, N, C;
+    int64_t qk_fs, v_fs, x_fs, o_fs;     // frame strides (elements); v_fs covers both planes of a frame: [2][C][npitch]
+    float gamma;
+};
+
+__global__ void __launch_bounds__(256, 2) pattn_apply_mfma_kernel(const PAttnMArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smc[];
+    const int DP = a.d + 4;
+    float* Gs = reinterpret_cast<float*>(smc);
+    float* Fs = Gs + PA_TJ * DP;
+    char* P3 = reinterpret_cast<char*>(Fs + PA_TI * DP);                 // [3][64 queries][32 keys] fp16: 2048-scaled hi', hi', lo''
+    char* Hh = P3 + 3 * PA_TJ * 64;                                         // [256 channels][32 keys] fp16
+    char* Hl = Hh + PM_CC * 64;
+    const int j0 = blockIdx.x * PA_TJ, b = blockIdx.y, c0 = blockIdx.z * PM_CC, t = threadIdx.x;
+    const int sj = t & 63, ig = t >> 6, lane = t & 63, wave = t >> 6, lr = lane & 15, lg = lane >> 4;
+    const half_t* qk = a.qk + (int64_t)b * a.qk_fs;
+    const half_t* vh = a.vT + (int64_t)b * a.v_fs + (int64_t)c0 * a.npitch;
+    const half_t* vl = vh + (int64_t)a.C * a.npitch;
+    pa_load_rows(qk, a.qk_cp, a.g_co, j0, PA_TJ, a.N, a.d / 8, Gs, DP, t);
+    float m = 0.f, l = 1.f;
+    if (j0 + sj < a.N) {
+        const float* st = a.stats + ((int64_t)b * a.N + j0 + sj) * 2;
+        m = st[0];
+        l = st[1];
+    }
+    const float pl = 512.f / l;
+    float4v acc[4][4];
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[cf][q] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < a.N; i0 += PA_TI) {
+        __syncthreads();
+        pa_load_rows(qk, a.qk_cp, a.f_co, i0, PA_TI, a.N, a.d / 8, Fs, DP, t);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                        // 256 channel rows x 4 chunks of 8 keys per plane
+            const int q = t + k * 256, row = q >> 2, ch = q & 3;
+            *reinterpret_cast<half8*>(Hh + row * 64 + ch * 16) = *reinterpret_cast<const half8*>(vh + (int64_t)row * a.npitch + i0 + ch * 8);
+            *reinterpret_cast<half8*>(Hl + row * 64 + ch * 16) = *reinterpret_cast<const half8*>(vl + (int64_t)row * a.npitch + i0 + ch * 8);
+        }
+        __syncthreads();
+        {
+            float s[8];
+            pa_scores(Gs, Fs, DP, a.d, sj, ig, s);
+            half8 s0, s1, s2;
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) {
+                const float pv = (i0 + ig * 8 + ii < a.N) ? expf(s[ii] - m) * pl : 0.f;       // 512 p
+                const half_t hi = (half_t)pv;
+                s1[ii] = hi;
+                s0[ii] = (half_t)((float)hi * 64.f);
+                s2[ii] = (half_t)((pv - (float)hi) * 2048.f);
+            }
+            *reinterpret_cast<half8*>(P3 + (0 * PA_TJ + sj) * 64 + ig * 16) = s0;
+            *reinterpret_cast<half8*>(P3 + (1 * PA_TJ + sj) * 64 + ig * 16) = s1;
+            *reinterpret_cast<half8*>(P3 + (2 * PA_TJ + sj) * 64 + ig * 16) = s2;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int seg = 0; seg < 3; ++seg) {
+            half8 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const half8*>(P3 + (seg * PA_TJ + q * 16 + lr) * 64 + lg * 16);
+            const char* hp = (seg == 1) ? Hl : Hh;
+#pragma unroll
+            for (int cf = 0; cf < 4; ++cf) {
+                half8 av = *reinterpret_cast<const half8*>(hp + (wave * 64 + cf * 16 + lr) * 64 + lg * 16);
+                if (seg == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) av[e] = av[e] * (half_t)32.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[cf][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bq[q], acc[cf][q], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: out = gamma * o + x as a hi / lo pair; lane = query q * 16 + lr, channels c0 + wave * 64 + cf * 16 + lg * 4 .. +3
+    const half_t* xb = a.x + (int64_t)b * a.x_fs;
+    half_t* ob = a.out + (int64_t)b * a.o_fs;
+    const float sc = a.gamma * (1.f / (2048.f * 512.f));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q * 16 + lr;
+        if (j >= a.N) continue;
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+            const int c = c0 + wave * 64 + cf * 16 + lg * 4;
+            const half_t* xp = xb + (int64_t)j * a.x_cp + a.x_co + c;
+            const half4 xh = *reinterpret_cast<const half4*>(xp), xl = *reinterpret_cast<const half4*>(xp + (a.x_cp >> 1));
+            half4 oh, ol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = sc * acc[cf][q][r] + join_hl(xh[r], xl[r]);
+                half_t hh, ll;
+                split_hl(v, hh, ll);
+                oh[r] = hh; ol[r] = ll;
+            }
+            half_t* op = ob + (int64_t)j * a.o_cp + a.o_co + c;
+            *reinterpret_cast<half4*>(op) = oh;
+            *reinterpret_cast<half4*>(op + (a.o_cp >> 1)) = ol;
+        }
+    }
+}
+
 template <auto Kernel>
 void lds_optin() {                                         // > 64 KiB of dynamic LDS: once per kernel and device (eagerly: preload_precise)
     static std::atomic<uint64_t> done{0};
@@ -298,6 +416,7 @@ void lds_optin() {                                         // > 64 KiB of dynami
 
 void preload_precise() {
     lds_optin<pattn_stats_kernel>(); lds_optin<pattn_apply_kernel<4>>(); lds_optin<pattn_apply_kernel<2>>(); lds_optin<pattn_apply_kernel<1>>();
+    lds_optin<pattn_apply_mfma_kernel>();
     (void)hipGetLastError();
 }
 
@@ -351,5 +470,31 @@ int launch_attention_p(const half_t* qk, int qk_cpitch, int f_coff, int g_coff, 
     if (CC == 512) { lds_optin<pattn_apply_kernel<4>>(); hipLaunchKernelGGL(pattn_apply_kernel<4>, grid, dim3(256), lds_b, s, a); }
     else if (CC == 256) { lds_optin<pattn_apply_kernel<2>>(); hipLaunchKernelGGL(pattn_apply_kernel<2>, grid, dim3(256), lds_b, s, a); }
     else { lds_optin<pattn_apply_kernel<1>>(); hipLaunchKernelGGL(pattn_apply_kernel<1>, grid, dim3(256), lds_b, s, a); }
+    return (int)hipGetLastError();
+}
+
+bool attention_pm_supported(int d, int C, int npitch) { return d >= 8 && d <= 128 && (d & 7) == 0 && C >= PM_CC && (C % PM_CC) == 0 && npitch >= 32 && (npitch & 31) == 0; }
+
+// The same attention with the value map given TRANSPOSED as two planes per frame, [2][C][npitch] fp16 (hi plane, lo plane; npitch >= N rounded up to a
+// multiple of 32, columns beyond N zero): statistics pass as above, apply pass on MFMA (pattn_apply_mfma_kernel).
+int launch_attention_pm(const half_t* qk, int qk_cpitch, int f_coff, int g_coff, int d, int64_t qk_fs, const half_t* vT, int npitch, int64_t v_fs,
+                        const half_t* x, int x_cpitch, int x_coff, int64_t x_fs, half_t* out, int o_cpitch, int o_coff, int64_t o_fs, float* stats, int B, int N,
+                        int C, float gamma, hipStream_t s) {
+    if (!attention_pm_supported(d, C, npitch) || npitch < ((N + 31) & ~31)) return (int)hipErrorInvalidValue;
+    PAttnArgs a{};
+    a.qk = qk; a.stats = stats; a.qk_cp = qk_cpitch; a.f_co = f_coff; a.g_co = g_coff; a.d = d; a.B = B; a.N = N; a.C = C; a.qk_fs = qk_fs;
+    const int DP = d + 4, NJ = (N + PA_TJ - 1) / PA_TJ;
+    const int lds_a = (PA_TJ * DP + PA_TI * DP + 4 * 64 * 2) * 4;
+    lds_optin<pattn_stats_kernel>();
+    hipLaunchKernelGGL(pattn_stats_kernel, dim3(NJ, B), dim3(256), lds_a, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    PAttnMArgs m{};
+    m.qk = qk; m.vT = vT; m.x = x; m.out = out; m.stats = stats;
+    m.qk_cp = qk_cpitch; m.f_co = f_coff; m.g_co = g_coff; m.d = d; m.npitch = npitch; m.x_cp = x_cpitch; m.x_co = x_coff; m.o_cp = o_cpitch; m.o_co = o_coff;
+    m.N = N; m.C = C; m.qk_fs = qk_fs; m.v_fs = v_fs; m.x_fs = x_fs; m.o_fs = o_fs; m.gamma = gamma;
+    const int lds_b = (PA_TJ * DP + PA_TI * DP) * 4 + 3 * PA_TJ * 64 + 2 * PM_CC * 64;
+    lds_optin<pattn_apply_mfma_kernel>();
+    hipLaunchKernelGGL(pattn_apply_mfma_kernel, dim3(NJ, B, C / PM_CC), dim3(256), lds_b, s, m);
     return (int)hipGetLastError();
 }

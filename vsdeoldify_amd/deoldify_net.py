@@ -162,6 +162,15 @@ class DeoldifyGenerator:
         qk = b.tensor(x.H, x.W, 2 * d)
         b.conv(p + ".qk", pc_qk, x, qk)
         N = x.H * x.W
+        if self.precise and C % 256 == 0 and d % 8 == 0 and d <= 128 and os.environ.get("HAVC_PRECISE_ATTN_MFMA", "1") != "0":
+            # round 5: the value conv stores its map TRANSPOSED as two planes [2][C][npitch] (hi, lo) and the attention's P . H product runs on
+            # MFMA with the three-term splitting (11.3 -> ~3 ms per 16 frames at 560 x 560); S = f . g and the softmax stay fp32 VALU
+            npitch = pad_to(N, 64)
+            vT = b.buf(2 * C * npitch, 2, zero_init=True)
+            b.conv(p + ".value", pc_v, x, vT, flags=nat.F_OUT_TRANSPOSED, Co=C, aux0=npitch)
+            y = b.tensor(x.H, x.W, C)
+            b.attention(p, x, qk, d, vT, npitch, y, float(sd[p + ".gamma"].reshape(-1)[0]), transposed=True)
+            return y
         if self.precise:                       # fp32 attention kernels read the value map as an ordinary NHWC hi / lo tensor
             hv = b.tensor(x.H, x.W, C)
             b.conv(p + ".value", pc_v, x, hv)

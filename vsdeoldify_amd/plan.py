@@ -319,10 +319,13 @@ class PlanBuilder:
                         src_cpitch=x.cpitch, dst=y.buf, dst_coff=y.coff, dst_cpitch=y.cpitch, Hi=x.H, Wi=x.W,
                         Ci=x.span, Ho=y.H, Wo=y.W, Co=y.span, scale_off=scale_off, shift_off=shift_off)
 
-    def attention(self, name, x, qk, d, vT_buf, npitch, y, gamma):
-        """fast plans: vT_buf = transposed value buffer [C][npitch]; precise plans: vT_buf = the NHWC value buffer, npitch = its pixel pitch"""
+    def attention(self, name, x, qk, d, vT_buf, npitch, y, gamma, transposed=False):
+        """fast plans: vT_buf = transposed value buffer [C][npitch]; precise plans: vT_buf = the NHWC value buffer, npitch = its pixel pitch -- or, with
+        transposed=True (round 5), the value map as two transposed planes [2][C][npitch] (hi, lo): the P . H product then runs on MFMA"""
         N = x.H * x.W
         extra = dict(kh=self.buf(N * 2, 4)) if self.precise else {}          # precise: fp32 [N][2] softmax statistics per frame
+        if self.precise and transposed:
+            extra["flags"] = nat.F_OUT_TRANSPOSED
         return self._op(name, type=nat.OP_ATTENTION, **extra, src=x.buf, src_coff=x.coff, src_cpitch=x.cpitch, dst=y.buf,
                         dst_coff=y.coff, dst_cpitch=y.cpitch, src2=qk.buf, res_coff=qk.coff, res_cpitch=qk.cpitch,
                         Hi=x.H, Wi=x.W, Ci=x.C, Ho=x.H, Wo=x.W, Co=x.C, aux0=d, aux1=vT_buf, Kc=npitch, f0=gamma,
