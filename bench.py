@@ -114,7 +114,7 @@ def cpu_baseline_and_parity(cc_main, frames, threads, device_index, cc_precise=N
                        "note": "fp16 MFMA operands; floor / decomposition in profiles/r2_precision_study.txt" if m == "fast" else
                                "hi / lo fp16 pairs, three-segment convs, fp32 epilogues and attention (HAVC_F_PRECISE): what is left is the fp32 summation-order floor"})
         out[m] = parity
-    base = {"value": round(cpu_n / cpu_s, 5), "unit": "frames/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+    base = {"value": round(cpu_n / cpu_s, 5), "unit": "frames/s", "cores": threads, "host_cpus": os.cpu_count(), "threads_probe": _CPU_THREADS.get("probe"), "kind": "port",
             "sample": f"{cpu_n} frames of the 1080p clip (2 U-Net passes at 560x560 fp32 + Spline64/YUV tail each), {cpu_s:.1f} s"}
     return base, out["fast"], out.get("precise")
 
@@ -174,10 +174,32 @@ def off(p, nbytes):
     return ctypes.c_void_p(p.value + nbytes)
 
 
+_CPU_THREADS = {}
+
+
 def cpu_threads(args):
-    """threads of the CPU-oracle legs: all host cores unless --cpu-threads caps them"""
+    """Threads of the CPU-oracle legs.  --cpu-threads N pins them; 0 (default) = what is FASTEST on this host among 32, 64, half and all of
+    os.cpu_count() (SURVEY.md section 8d asks for all host cores; on a many-socket box torch's conv with every hardware thread can be slower than
+    with 32 -- the baseline must not be handicapped by that, so a 259-channel 3x3 conv at 280 x 280 is timed once per candidate, ~2 s in all).
+    The choice and os.cpu_count() are both printed in the cpu_baseline object (`cores`, `host_cpus`, `threads_probe`)."""
     n = os.cpu_count() or 1
-    return min(n, args.cpu_threads) if args.cpu_threads and args.cpu_threads > 0 else n
+    if args.cpu_threads and args.cpu_threads > 0:
+        return min(n, args.cpu_threads)
+    if "best" not in _CPU_THREADS:
+        import torch
+        import torch.nn.functional as F
+        x, w = torch.randn(1, 264, 280, 280), torch.randn(264, 264, 3, 3)
+        probe = {}
+        for th in sorted({min(n, 32), min(n, 64), max(1, n // 2), n}):
+            torch.set_num_threads(th)
+            F.conv2d(x, w, None, 1, 1)
+            t0 = time.time()
+            F.conv2d(x, w, None, 1, 1)
+            probe[th] = round(time.time() - t0, 4)
+        _CPU_THREADS["best"] = min(probe, key=probe.get)
+        _CPU_THREADS["probe"] = probe
+        print(f"bench: CPU thread probe (seconds per 259-channel conv at 280x280) {probe} -> {_CPU_THREADS['best']} threads of {n}", file=sys.stderr, flush=True)
+    return _CPU_THREADS["best"]
 
 
 def main():
@@ -333,14 +355,17 @@ def main():
     if multi is not None:
         out["multi_gpu"] = multi
     if rank == 0 and world == 1 and not args.no_extras:
+        _progress("extras (sustained / PCIe-inclusive / per-frame calls)")
         out.update(extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds))
     cc_precise = None
     if rank == 0 and world == 1 and not args.no_precise:
         try:
+            _progress("precise leg")
             out["precise"], cc_precise = precise_leg(args, sds, local_rank, frames, fbytes)
         except Exception as e:                          # never lose the headline line to the second mode
             out["precise"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        _progress("CPU oracle + parity")
         base, parity, parity_p = cpu_baseline_and_parity(cc, frames, cpu_threads(args), local_rank, cc_precise)
         out["cpu_baseline"] = base
         out["parity"] = parity
@@ -362,12 +387,17 @@ def main():
         print(json.dumps(out))
 
 
+def _progress(msg):
+    print(f"bench: [{time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def other_configs_leg(args):
     """c3 / c4 / c5 (BASELINE configs[2..4]) in child processes: {value, ms_per_step, whole_path_tflops, roofline frac, parity} per config"""
     import subprocess
     res = {}
 
     def child(cfg, extra, steps, warm):
+        _progress(f"child leg {cfg} {' '.join(extra)}")
         cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", steps, "--warmup", warm, "--no-extras", "--cpu-threads", str(args.cpu_threads)] + extra
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
@@ -476,7 +506,7 @@ def extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds):
     # ---- batch 1, one blocking call per frame: what a ModifyFrame selector gets ----
     from PIL import Image
     from vsdeoldify_amd.render import ModelImageRender
-    r1 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1, low_latency=False)
+    r1 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1)
     S = RENDER_FACTOR * 16
     img = Image.fromarray(np.ascontiguousarray(frames[0][:S, :S]))
     for _ in range(3):
@@ -487,10 +517,9 @@ def extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds):
         r1.get_transformed_image(img)
     dt = time.perf_counter() - t0
     res["batch1"] = {"value": round(k / dt, 2), "unit": "frames/s", "ms_per_call": round(dt / k * 1e3, 3),
-                     "how": "ModelImageRender('stable', rf=35, low_latency=False).get_transformed_image(PIL 560x560), one blocking call per frame (H2D + 2 passes + D2H) "
-                            "on the batch-independent nets (the library default for such a render is the low-latency form: next leg)"}
+                     "how": "ModelImageRender('stable', rf=35).get_transformed_image(PIL 560x560), one blocking call per frame (H2D + 2 passes + D2H)"}
     # ---- the same single caller with the low-latency nets (split-K convs for one frame per launch; fp32 summation order differs) ----
-    r2 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1)      # the default: low-latency nets
+    r2 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1, low_latency=True)
     for _ in range(3):
         r2.get_transformed_image(img)
     t0 = time.perf_counter()
@@ -498,8 +527,8 @@ def extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds):
         r2.get_transformed_image(img)
     dt = time.perf_counter() - t0
     res["batch1_low_latency"] = {"value": round(k / dt, 2), "unit": "frames/s", "ms_per_call": round(dt / k * 1e3, 3),
-                                 "how": "the same call on the DEFAULT render of that shape (max_batch 1 => low-latency nets since round 5): one frame per launch, split-K convs "
-                                        "whose parts the last block of a tile adds inside the conv kernel"}
+                                 "how": "the same call on ModelImageRender(..., low_latency=True) / HAVC_LOW_LATENCY=1: nets for one frame per launch with split-K convs "
+                                        "(opt-in: 3 LSB from the batched nets on isolated bytes at this size, tests/test_gpu_deoldify.py)"}
     # ---- the same per-frame call from 16 threads (VapourSynth's worker pool) through ONE coalescing render: havc_batcher ----
     import threading
     T, K = 16, 6
@@ -641,7 +670,7 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
         dt = time.time() - t0
         de = imaging.delta_e00_images(got, ref)
         d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
-        out["cpu_baseline"] = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+        out["cpu_baseline"] = {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": threads, "host_cpus": os.cpu_count(), "threads_probe": _CPU_THREADS.get("probe"), "kind": "port",
                                "sample": f"1 frame of the 1080p clip through the oracle graph (fp32 torch models + numpy tail), {dt:.1f} s"}
         out["parity"] = dict(_stats(de, d), frames_checked=1,
                              against="oracle graph (CPU fp32); DDColor itself is parity-UNPINNED (external wheel, oracle/ddcolor.py)")
@@ -826,7 +855,7 @@ def bench_c5(args, rank, local_rank, world, dist):
         des = [imaging.delta_e00_images(g_, r_) for g_, r_ in zip(gpu, refs)]
         worst = int(np.argmax([float(np.percentile(d_, 99)) for d_ in des]))
         de = np.concatenate([d_.reshape(-1) for d_ in des])
-        out["cpu_baseline"] = {"value": round(K / dt, 5), "unit": "frames/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+        out["cpu_baseline"] = {"value": round(K / dt, 5), "unit": "frames/s", "cores": threads, "host_cpus": os.cpu_count(), "threads_probe": _CPU_THREADS.get("probe"), "kind": "port",
                                "sample": f"the first {K} frames of the clip (exemplar with frame 0) through the oracle loop (fp32 torch network + numpy tail), {dt:.1f} s"}
         out["parity"] = {"ciede2000_mean": round(float(de.mean()), 4), "ciede2000_p99": round(float(np.percentile(de, 99)), 4),
                          "ciede2000_max": round(float(de.max()), 4), "pixels_with_dE_below_1": round(float((de < 1.0).mean()), 5),

@@ -384,7 +384,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             if (a.splitk == 1) a.splitk = 0;
             a.pscale = 1.f;
             if (op.flags & HAVC_F_PRECISE) {
-                if ((op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_FUSE_PROJ | HAVC_F_W_FROM_BUF)) || a.splitk ||
+                if ((op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_PROJ | HAVC_F_W_FROM_BUF)) || a.splitk ||
                     !(op.f3 > 0.f) || (op.src_cpitch & 15) || (!(op.flags & HAVC_F_OUT_RGB8) && (op.dst_cpitch & 15)))
                     return fail(c, HAVC_E_INVALID, "conv op: PRECISE needs a plain conv (no fused / transposed / split-K form), f3 = accumulator scale > 0, hi|lo pixel rows");
                 a.pscale = op.f3;
@@ -397,8 +397,11 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                 const size_t need = (size_t)a.splitk * batch * op.Ho * op.Wo * op.Npad * 4;
                 if (int rc2 = ensure_scratch(c, slot, need)) return rc2;
                 a.ws = (float*)c->scratch[slot];
-                // round 5: the last block of a tile reduces the parts and runs the epilogue itself (HAVC_SPLITK_FUSED=0: the separate reduce launch)
-                static const bool fused = [] { const char* e = getenv("HAVC_SPLITK_FUSED"); return e ? atoi(e) != 0 : true; }();
+                // round 5 experiment, OFF by default: HAVC_SPLITK_FUSED=1 lets the last block of a tile reduce the parts and run the epilogue itself (no second
+                // launch).  Same bytes -- but the agent-scope release every block needs in front of its arrival count writes back its XCD's L2, and a
+                // low-latency DeOldify frame went 6.2 -> 13.2 ms, ColorMNet 885 -> 590 frames/s (profiles/r5_splitk_fused_ab.txt): the separate
+                // 5 us reduce launch is the cheaper form on this part.
+                static const bool fused = [] { const char* e = getenv("HAVC_SPLITK_FUSED"); return e ? atoi(e) != 0 : false; }();
                 a.sk_cnt = fused ? c->sk_cnt[slot - 12] : nullptr;
             }
             {

@@ -57,7 +57,8 @@ class DeoldifyGenerator:
         assert arch in RESNET and precision in ("fast", "precise")
         self.precise = precision == "precise"
         if self.precise:
-            fuse_final = fuse_blur = False
+            fuse_blur = False                  # (the fused shuffle + blur epilogue keeps its tile image in LDS as fp16: pairs would need 256 KiB)
+            fuse_final = fuse_final and os.environ.get("HAVC_PRECISE_FUSE_FINAL", "1") != "0"      # round 5: layers.11 + SigmoidRange + u8 in the precise epilogue
         self.sd, self.arch, self.fuse_final, self.fuse_blur = to_np(state_dict), arch, fuse_final, fuse_blur
         self.pack, self._pc, self._vec = WeightPack(), {}, {}
         self._frozen = False
