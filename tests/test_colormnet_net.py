@@ -529,7 +529,8 @@ def test_gpu_render_matches_the_reference_render_class(name):
     for t in range(len(want)):
         de = imaging.delta_e00_images(got[t], want[t])
         worst = max(worst, (float(de.mean()), float(np.percentile(de, 99))))
-        assert got[t].shape == want[t].shape and de.mean() < 0.5 and np.percentile(de, 99) < 2.5, (name, t, float(de.mean()), float(np.percentile(de, 99)), float(de.max()))
+        # measured worst frame per scenario on MI355X (round 5: keep 0.211 / 1.129, vivid 0.153 / 0.919, propagate 0.122 / 0.621, capped 0.198 / 1.028) + 15 %
+        assert got[t].shape == want[t].shape and de.mean() < 0.245 and np.percentile(de, 99) < 1.30, (name, t, float(de.mean()), float(np.percentile(de, 99)), float(de.max()))
     print(f"{name}: worst frame mean dE00 %.3f, p99 %.3f" % worst)
 
 
@@ -595,7 +596,7 @@ def test_gpu_colorize_batch_frames_with_lookahead_matches_the_reference_render_c
     assert not rnd._ahead and rnd.network._armed is None
     for t in range(len(want)):
         de = imaging.delta_e00_images(got[t], want[t])
-        assert de.mean() < 0.5 and np.percentile(de, 99) < 2.5, (name, t, float(de.mean()), float(np.percentile(de, 99)))
+        assert de.mean() < 0.3 and np.percentile(de, 99) < 1.6, (name, t, float(de.mean()), float(np.percentile(de, 99)))     # (the look-ahead pass's split-K order moves a few pixels)
     plain = run_render_scenario(name, gpu_network())
     d = np.abs(got.astype(np.int32) - plain.astype(np.int32))
     assert (d <= 2).mean() > 0.999, (int(d.max()), float((d <= 2).mean()))

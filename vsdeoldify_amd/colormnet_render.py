@@ -347,6 +347,7 @@ class DeepExColorMNet:
         if _slot is not None and is_device(small) and not (ph or pw) and self.render.first_mask_loaded:
             self.render.out_slot = _slot
             col = self.render.colorize_frame(self.t, small)
+            self.render.out_slot = None                                      # (a path that did not consume the slot must not find it on a later frame)
             self.t += 1
             if col is _slot:
                 return col
