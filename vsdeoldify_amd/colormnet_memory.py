@@ -234,40 +234,50 @@ class MemoryManager:
                 self.long_mem.update_usage(usage[:, :long_size].flatten())
         return out.view(objs, self.CV, h, w)
 
-    # ---- per-frame write + long-term clean-up (memory_manager.py:152-193) ----
-    def add_memory(self, key, shrinkage, value, objects, selection=None):
-        """key [1,CK,H,W], shrinkage [1,1,H,W], value [1,objects,CV,H,W], objects: list of 1-based object ids"""
-        if self.H is None or self.reset_config:
-            self.reset_config = False
-            self.H, self.W = key.shape[-2:]
-            self.HW = self.H * self.W
-            if self.enable_long_term:
-                self.min_work_elements = self.min_mt_frames * self.HW
-                self.max_work_elements = self.max_mt_frames * self.HW
-        key = key.flatten(start_dim=2)
-        shrinkage = shrinkage.flatten(start_dim=2)
-        value = value[0].flatten(start_dim=2)
-        self.CK, self.CV = key.shape[1], value.shape[1]
-        if selection is not None:
-            selection = selection.flatten(start_dim=2)
-        self.work_mem.add(key, value, shrinkage, selection, objects)
+    # ---- per-frame write + long-term clean-up (behaviour of memory_manager.py:152-193; the interface InferenceCore drives) ----
+    def _bind_geometry(self, hw):
+        """the first memorised frame (or the first one after a reset) fixes the key grid; the long-term bounds are frame counts turned into elements"""
+        self.reset_config = False
+        self.H, self.W = int(hw[0]), int(hw[1])
+        self.HW = self.H * self.W
         if self.enable_long_term:
-            try:                                                   # memory_manager.py:183-193: a failing clean-up is swallowed, the clip goes on
-                if self.work_mem.size >= self.max_work_elements:
-                    if self.long_mem.size >= (self.max_long_elements - self.num_prototypes):
-                        self.long_mem.remove_obsolete_features(self.max_long_elements - self.num_prototypes)
-                    self.compress_features()
-            except Exception:
+            self.min_work_elements, self.max_work_elements = (frames * self.HW for frames in (self.min_mt_frames, self.max_mt_frames))
+
+    def _maintain_long_term(self):
+        """working memory full -> make room in the long-term store if it is nearly full, then consolidate; a failure leaves the memory as it is"""
+        if self.work_mem.size < self.max_work_elements:
+            return
+        room = self.max_long_elements - self.num_prototypes
+        if self.long_mem.size >= room:
+            self.long_mem.remove_obsolete_features(room)
+        self.compress_features()
+
+    def add_memory(self, key, shrinkage, value, objects, selection=None):
+        """key [1, CK, H, W], shrinkage [1, 1, H, W], value [1, objects, CV, H, W], selection [1, CK, H, W] or None; objects: 1-based ids"""
+        if self.H is None or self.reset_config:
+            self._bind_geometry(key.shape[-2:])
+        rows = {name: (t if t is None else t.flatten(start_dim=2)) for name, t in
+                (("key", key), ("shrinkage", shrinkage), ("value", value[0]), ("selection", selection))}
+        self.CK, self.CV = rows["key"].shape[1], rows["value"].shape[1]
+        self.work_mem.add(rows["key"], rows["value"], rows["shrinkage"], rows["selection"], objects)
+        if self.enable_long_term:
+            try:
+                self._maintain_long_term()
+            except Exception:              # the reference swallows a failing clean-up and goes on with the clip (memory_manager.py:183-193)
                 pass
 
     def create_hidden_state(self, n, sample_key):
-        import torch
-        h, w = sample_key.shape[-2:]
+        """make the hidden state cover n objects on sample_key's grid: created as zeros, or grown by zero planes for objects that joined later"""
+        import torch.nn.functional as F
+        grid = tuple(sample_key.shape[-2:])
         if self.hidden is None:
-            self.hidden = torch.zeros((1, n, self.hidden_dim, h, w), device=sample_key.device)
-        elif self.hidden.shape[1] != n:
-            self.hidden = torch.cat([self.hidden, torch.zeros((1, n - self.hidden.shape[1], self.hidden_dim, h, w), device=sample_key.device)], 1)
-        assert self.hidden.shape[1] == n
+            self.hidden = sample_key.new_zeros((1, n, self.hidden_dim) + grid, dtype=sample_key.dtype if sample_key.is_floating_point() else None)
+        else:
+            missing = n - self.hidden.shape[1]
+            if missing:                    # (a negative count fails in F.pad's own shape check, like the reference's torch.zeros would)
+                self.hidden = F.pad(self.hidden, (0, 0, 0, 0, 0, 0, 0, missing))
+        if self.hidden.shape[1] != n:
+            raise AssertionError("hidden state / object count mismatch")
 
     def set_hidden(self, hidden):
         self.hidden = hidden
