@@ -47,7 +47,7 @@ METRIC = "colorized frames/sec/GPU @1080p (DeOldify stable rf=35); CIEDE2000 vs 
 RENDER_FACTOR, WIDTH, HEIGHT = 35, 1920, 1080
 PEAK_F16_TFLOPS = 2500.0            # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 TAG_TAIL_RES = 1
-PMC_FILES = [os.path.join("profiles", "r4_tail_conv_pmc.json"), os.path.join("profiles", "r3_tail_conv_pmc.json"), os.path.join("profiles", "r2_tail_conv_pmc.json")]   # newest first
+PMC_FILES = [os.path.join("profiles", "r5_tail_conv_pmc.json"), os.path.join("profiles", "r4_tail_conv_pmc.json"), os.path.join("profiles", "r3_tail_conv_pmc.json"), os.path.join("profiles", "r2_tail_conv_pmc.json")]   # newest first
 
 
 PARITY_SEEDS = ((1, 2), (11, 12), (21, 22))     # (video, stable) weight seeds: the bench weights first
