@@ -26,6 +26,10 @@ offline), activations fp16 with fp32 MFMA accumulation.
                  ModifyFrame selector sees (vsslib/vsmodels.py:219-230)
   cpu_baseline / parity   the CPU oracle on one frame of the same clip, and the GPU frame against it
 
+Wall time of the default run (`python bench.py`, one MI355X box, round 5): about 4 minutes -- the five child legs (c3, c3 precise, c4, c4 precise, c5) 85 s, the
+headline's warm-up + timed steps 10 s, the sustained / PCIe / per-frame-call legs 55 s, the precise leg 15 s, the CPU oracle on 8 frames 45 s.  --no-other-configs,
+--no-extras, --no-precise and --no-cpu-baseline each drop their part; the JSON line says which legs ran.
+
 Multi-GPU: frames are independent — every rank colours its own shard on its own GPU with a
 full weight replica, no data-path collective; RCCL is used only for the barrier / max-over-ranks timing.
 Rank 0 prints ONE JSON line.
@@ -87,8 +91,8 @@ def cpu_baseline_and_parity(cc_main, frames, threads, device_index, cc_precise=N
                 continue            # (packing a precise generator pair takes a minute of host time: the bench checks the precise path on its own
                                     #  weights; all three weight sets are the -m gpu test's job, tests/test_gpu_precise.py)
             main = cc_main if m == "fast" else cc_precise
-            cc = main if (sv, ss) == PARITY_SEEDS[0] else ClipColorizer("stable", RENDER_FACTOR, 0.5, device_index=device_index, state_dicts=sds, max_batch=2,
-                                                                        precision=m)
+            cc = main if ((sv, ss) == PARITY_SEEDS[0] and main is not None) else ClipColorizer("stable", RENDER_FACTOR, 0.5, device_index=device_index,
+                                                                                               state_dicts=sds, max_batch=2, precision=m)
             got[m] = np.concatenate([cc.colorize(frames[i:i + 1]) for i in idx])
             if cc is not main:
                 for r in (cc.render._video, cc.render._second):
@@ -119,14 +123,15 @@ def cpu_baseline_and_parity(cc_main, frames, threads, device_index, cc_precise=N
     return base, out["fast"], out.get("precise")
 
 
-def precise_leg(args, sds, device_index, frames, fbytes):
+def precise_leg(args, sds, device_index, frames, fbytes, batch=None):
     """The fp32-class mode: the same step on the same clip with ModelImageRender(precision="precise") -- hi / lo fp16
     activation pairs, three K segments per conv on the same MFMA kernels (3x the matrix work), fp32 epilogues and attention.  What it measures
     against the oracle is in the leg's `parity` object (p99 0.000, >= 99.97 % of the pixels below 1.0, `meets_contract`; the residual maximum of
-    2.5 - 3.6 is a uint8 truncation flip on isolated pixels).  16 frames per step (activations are twice as large).  Returns (leg dict, ClipColorizer)."""
+    2.5 - 3.6 is a uint8 truncation flip on isolated pixels).  `batch` frames per step (activations are twice as large: 32 frames = 141 GB of
+    arenas, which fit once the fast nets' 141 GB are released; 16 otherwise).  Returns (leg dict, ClipColorizer)."""
     from vsdeoldify_amd import _native as nat
     from vsdeoldify_amd.clip import ClipColorizer
-    batch = min(16, args.batch)
+    batch = min(batch or 16, args.batch)
     cc = ClipColorizer("stable", RENDER_FACTOR, 0.5, device_index=device_index, state_dicts=sds, max_batch=batch, precision="precise")
     ctx = cc.ctx
     n = len(frames) // batch * batch
@@ -151,6 +156,13 @@ def precise_leg(args, sds, device_index, frames, fbytes):
         avg_ms, launches = ctypes.c_double(), ctypes.c_int64()
         nat.check(ctx.lib.havc_tag_timing_read(ctx.h, ctypes.byref(avg_ms), ctypes.byref(launches)), ctx.h)
         nat.check(ctx.lib.havc_tag_timing_enable(ctx.h, TAG_TAIL_RES, 0), ctx.h)
+    except Exception:
+        for r_ in (cc.render._video, cc.render._second):      # a failed attempt (out of memory at 32 frames per step) must not keep its arenas
+            try:
+                r_.close()
+            except Exception:                                  # noqa: BLE001
+                pass
+        raise
     finally:
         ctx.dev_free(d_src)
         ctx.dev_free(d_dst)
@@ -364,11 +376,21 @@ def main():
         out.update(extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds))
     cc_precise = None
     if rank == 0 and world == 1 and not args.no_precise:
+        # the fast nets (64 frames x 2 generators = 141 GB of activation arenas) are done: release them so that the precise nets can run 32 frames
+        # per step as well (the parity leg below builds small fast nets of its own)
         try:
-            _progress("precise leg")
-            out["precise"], cc_precise = precise_leg(args, sds, local_rank, frames, fbytes)
-        except Exception as e:                          # never lose the headline line to the second mode
-            out["precise"] = {"error": f"{type(e).__name__}: {e}"}
+            for r_ in (cc.render._video, cc.render._second):
+                r_.close()
+            cc = None
+        except Exception:                               # noqa: BLE001
+            pass
+        for pb in (32, 16):
+            try:
+                _progress(f"precise leg ({pb} frames per step)")
+                out["precise"], cc_precise = precise_leg(args, sds, local_rank, frames, fbytes, batch=pb)
+                break
+            except Exception as e:                      # never lose the headline line to the second mode (32 frames may not fit next to other arenas)
+                out["precise"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         _progress("CPU oracle + parity")
         base, parity, parity_p = cpu_baseline_and_parity(cc, frames, cpu_threads(args), local_rank, cc_precise)

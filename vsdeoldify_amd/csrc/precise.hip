@@ -8,6 +8,7 @@
 // All kernels are HBM-bound except the attention, which is fp32 VALU (the N x N map of fastai's SelfAttention never leaves the CU).
 #include "conv_common.h"
 #include <atomic>
+#include <cstdlib>
 
 namespace {
 
@@ -401,6 +402,190 @@ __global__ void __launch_bounds__(256, 2) pattn_apply_mfma_kernel(const PAttnMAr
     }
 }
 
+// ---- S = f . g on the matrix pipe as well (round 5, second step) ----
+// With P . H on MFMA the two fp32-VALU evaluations of S (statistics pass + apply pass: 2 x 2 N^2 d FLOP) were half of what was left of the attention.
+// f and g are fp16 pairs of the same NHWC buffer, channels contiguous: a pixel's 8-channel chunk IS a 16x16x32 operand fragment (row = pixel, K = channel),
+// no transposition.  Three-term splitting with the scales on both sides:  acc = (32 f_hi)(64 g_hi) + f_hi g_lo' + f_lo' g_hi = 2048 (f . g)  (|f| < 2047,
+// |g| < 1023).  D[key][query]: a lane owns 4 consecutive keys of one query -- its online-softmax state in the statistics kernel, an 8-byte piece of the
+// P operand in the apply kernel.  Wave w of a block owns queries 16 w .. 16 w + 15; its g fragments stay in registers for the whole block.
+template <int D32>
+struct PGFrag { half8 hi64[D32], lo[D32], hi[D32]; };
+
+template <int D32>
+__device__ __forceinline__ void pm_load_g(const half_t* qk, int qk_cp, int g_co, int row, PGFrag<D32>& g, int lg) {
+    const half_t* base = qk + (int64_t)row * qk_cp + g_co + lg * 8;
+#pragma unroll
+    for (int kk = 0; kk < D32; ++kk) {
+        g.hi[kk] = *reinterpret_cast<const half8*>(base + kk * 32);
+        g.lo[kk] = *reinterpret_cast<const half8*>(base + (qk_cp >> 1) + kk * 32);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g.hi64[kk][e] = g.hi[kk][e] * (half_t)64.f;
+    }
+}
+
+// s[kf][r] = f(key i0 + kf * 16 + lg * 4 + r) . g(query of this lane's column); keys >= N give 0 (the caller masks them)
+template <int D32>
+__device__ __forceinline__ void pm_scores(const half_t* qk, int qk_cp, int f_co, int i0, int N, const PGFrag<D32>& g, int lr, int lg, float s[2][4]) {
+#pragma unroll
+    for (int kf = 0; kf < 2; ++kf) {
+        const int row = i0 + kf * 16 + lr;
+        const bool ok = row < N;
+        const half_t* base = qk + (int64_t)(ok ? row : 0) * qk_cp + f_co + lg * 8;
+        float4v acc = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < D32; ++kk) {
+            half8 fh = *reinterpret_cast<const half8*>(base + kk * 32), fl = *reinterpret_cast<const half8*>(base + (qk_cp >> 1) + kk * 32);
+            if (!ok) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) fh[e] = fl[e] = (half_t)0.f;
+            }
+            half8 f32;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f32[e] = fh[e] * (half_t)32.f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(f32, g.hi64[kk], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fh, g.lo[kk], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(fl, g.hi[kk], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[kf][r] = acc[r] * (1.f / 2048.f);
+    }
+}
+
+template <int D32>
+__global__ void __launch_bounds__(256) pattn_stats_mfma_kernel(const PAttnArgs a) {
+    const int j0 = blockIdx.x * PA_TJ, b = blockIdx.y, t = threadIdx.x, lane = t & 63, wave = t >> 6, lr = lane & 15, lg = lane >> 4;
+    const half_t* qk = a.qk + (int64_t)b * a.qk_fs;
+    const int jq = j0 + wave * 16 + lr;
+    PGFrag<D32> g;
+    pm_load_g<D32>(qk, a.qk_cp, a.g_co, jq < a.N ? jq : a.N - 1, g, lg);
+    float m = -3.0e38f, l = 0.f;
+    for (int i0 = 0; i0 < a.N; i0 += PA_TI) {
+        float s[2][4];
+        pm_scores<D32>(qk, a.qk_cp, a.f_co, i0, a.N, g, lr, lg, s);
+#pragma unroll
+        for (int kf = 0; kf < 2; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (i0 + kf * 16 + lg * 4 + r >= a.N) continue;
+                const float v = s[kf][r];
+                if (v > m) { l = l * expf(m - v) + 1.f; m = v; }
+                else l += expf(v - m);
+            }
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {               // the four key groups (lg) of a query
+        const float m2 = __shfl_xor(m, off), l2 = __shfl_xor(l, off);
+        const float M = fmaxf(m, m2);
+        l = l * expf(m - M) + l2 * expf(m2 - M);
+        m = M;
+    }
+    if (lg == 0 && jq < a.N) {
+        float* st = a.stats + ((int64_t)b * a.N + jq) * 2;
+        st[0] = m;
+        st[1] = l;
+    }
+}
+
+template <int D32>
+__global__ void __launch_bounds__(256, 2) pattn_apply_mfma2_kernel(const PAttnMArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smc[];
+    char* P3 = smc;                                                        // [3][64 queries][32 keys] fp16: 64-scaled hi', hi', lo''
+    char* Hh = P3 + 3 * PA_TJ * 64;                                         // [256 channels][32 keys] fp16
+    char* Hl = Hh + PM_CC * 64;
+    const int j0 = blockIdx.x * PA_TJ, b = blockIdx.y, c0 = blockIdx.z * PM_CC, t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6, lr = lane & 15, lg = lane >> 4;
+    const half_t* qk = a.qk + (int64_t)b * a.qk_fs;
+    const half_t* vh = a.vT + (int64_t)b * a.v_fs + (int64_t)c0 * a.npitch;
+    const half_t* vl = vh + (int64_t)a.C * a.npitch;
+    const int jq = j0 + wave * 16 + lr;
+    PGFrag<D32> g;
+    pm_load_g<D32>(qk, a.qk_cp, a.g_co, jq < a.N ? jq : a.N - 1, g, lg);
+    float m = 0.f, l = 1.f;
+    if (jq < a.N) {
+        const float* st = a.stats + ((int64_t)b * a.N + jq) * 2;
+        m = st[0];
+        l = st[1];
+    }
+    const float pl = 512.f / l;
+    float4v acc[4][4];
+#pragma unroll
+    for (int cf = 0; cf < 4; ++cf)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[cf][q] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int i0 = 0; i0 < a.N; i0 += PA_TI) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                                        // 256 channel rows x 4 chunks of 8 keys per plane
+            const int q = t + k * 256, row = q >> 2, ch = q & 3;
+            *reinterpret_cast<half8*>(Hh + row * 64 + ch * 16) = *reinterpret_cast<const half8*>(vh + (int64_t)row * a.npitch + i0 + ch * 8);
+            *reinterpret_cast<half8*>(Hl + row * 64 + ch * 16) = *reinterpret_cast<const half8*>(vl + (int64_t)row * a.npitch + i0 + ch * 8);
+        }
+        {
+            float s[2][4];
+            pm_scores<D32>(qk, a.qk_cp, a.f_co, i0, a.N, g, lr, lg, s);
+#pragma unroll
+            for (int kf = 0; kf < 2; ++kf) {
+                half4 s0, s1, s2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pv = (i0 + kf * 16 + lg * 4 + r < a.N) ? expf(s[kf][r] - m) * pl : 0.f;       // 512 p
+                    const half_t hi = (half_t)pv;
+                    s1[r] = hi;
+                    s0[r] = (half_t)((float)hi * 64.f);
+                    s2[r] = (half_t)((pv - (float)hi) * 2048.f);
+                }
+                const int off = (wave * 16 + lr) * 64 + (kf * 16 + lg * 4) * 2;
+                *reinterpret_cast<half4*>(P3 + 0 * PA_TJ * 64 + off) = s0;
+                *reinterpret_cast<half4*>(P3 + 1 * PA_TJ * 64 + off) = s1;
+                *reinterpret_cast<half4*>(P3 + 2 * PA_TJ * 64 + off) = s2;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int seg = 0; seg < 3; ++seg) {
+            half8 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = *reinterpret_cast<const half8*>(P3 + (seg * PA_TJ + q * 16 + lr) * 64 + lg * 16);
+            const char* hp = (seg == 1) ? Hl : Hh;
+#pragma unroll
+            for (int cf = 0; cf < 4; ++cf) {
+                half8 av = *reinterpret_cast<const half8*>(hp + (wave * 64 + cf * 16 + lr) * 64 + lg * 16);
+                if (seg == 0) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) av[e] = av[e] * (half_t)32.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[cf][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bq[q], acc[cf][q], 0, 0, 0);
+            }
+        }
+    }
+    const half_t* xb = a.x + (int64_t)b * a.x_fs;
+    half_t* ob = a.out + (int64_t)b * a.o_fs;
+    const float sc = a.gamma * (1.f / (2048.f * 512.f));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int j = j0 + q * 16 + lr;
+        if (j >= a.N) continue;
+#pragma unroll
+        for (int cf = 0; cf < 4; ++cf) {
+            const int c = c0 + wave * 64 + cf * 16 + lg * 4;
+            const half_t* xp = xb + (int64_t)j * a.x_cp + a.x_co + c;
+            const half4 xh = *reinterpret_cast<const half4*>(xp), xl = *reinterpret_cast<const half4*>(xp + (a.x_cp >> 1));
+            half4 oh, ol;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = sc * acc[cf][q][r] + join_hl(xh[r], xl[r]);
+                half_t hh, ll;
+                split_hl(v, hh, ll);
+                oh[r] = hh; ol[r] = ll;
+            }
+            half_t* op = ob + (int64_t)j * a.o_cp + a.o_co + c;
+            *reinterpret_cast<half4*>(op) = oh;
+            *reinterpret_cast<half4*>(op + (a.o_cp >> 1)) = ol;
+        }
+    }
+}
+
 template <auto Kernel>
 void lds_optin() {                                         // > 64 KiB of dynamic LDS: once per kernel and device (eagerly: preload_precise)
     static std::atomic<uint64_t> done{0};
@@ -484,15 +669,28 @@ int launch_attention_pm(const half_t* qk, int qk_cpitch, int f_coff, int g_coff,
     PAttnArgs a{};
     a.qk = qk; a.stats = stats; a.qk_cp = qk_cpitch; a.f_co = f_coff; a.g_co = g_coff; a.d = d; a.B = B; a.N = N; a.C = C; a.qk_fs = qk_fs;
     const int DP = d + 4, NJ = (N + PA_TJ - 1) / PA_TJ;
-    const int lds_a = (PA_TJ * DP + PA_TI * DP + 4 * 64 * 2) * 4;
-    lds_optin<pattn_stats_kernel>();
-    hipLaunchKernelGGL(pattn_stats_kernel, dim3(NJ, B), dim3(256), lds_a, s, a);
+    static const bool s_mfma = [] { const char* e = getenv("HAVC_PRECISE_ATTN_S_MFMA"); return e ? atoi(e) != 0 : true; }();      // A/B: 0 = S on the fp32 VALU
+    const bool smf = s_mfma && (d == 64 || d == 96) && (qk_cpitch & 15) == 0 && (f_coff & 7) == 0 && (g_coff & 7) == 0;
+    if (smf) {
+        if (d == 64) hipLaunchKernelGGL(pattn_stats_mfma_kernel<2>, dim3(NJ, B), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(pattn_stats_mfma_kernel<3>, dim3(NJ, B), dim3(256), 0, s, a);
+    } else {
+        const int lds_a = (PA_TJ * DP + PA_TI * DP + 4 * 64 * 2) * 4;
+        lds_optin<pattn_stats_kernel>();
+        hipLaunchKernelGGL(pattn_stats_kernel, dim3(NJ, B), dim3(256), lds_a, s, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     PAttnMArgs m{};
     m.qk = qk; m.vT = vT; m.x = x; m.out = out; m.stats = stats;
     m.qk_cp = qk_cpitch; m.f_co = f_coff; m.g_co = g_coff; m.d = d; m.npitch = npitch; m.x_cp = x_cpitch; m.x_co = x_coff; m.o_cp = o_cpitch; m.o_co = o_coff;
     m.N = N; m.C = C; m.qk_fs = qk_fs; m.v_fs = v_fs; m.x_fs = x_fs; m.o_fs = o_fs; m.gamma = gamma;
+    if (smf) {
+        const int lds_c = 3 * PA_TJ * 64 + 2 * PM_CC * 64;              // 44 KiB: no opt-in needed
+        if (d == 64) hipLaunchKernelGGL(pattn_apply_mfma2_kernel<2>, dim3(NJ, B, C / PM_CC), dim3(256), lds_c, s, m);
+        else hipLaunchKernelGGL(pattn_apply_mfma2_kernel<3>, dim3(NJ, B, C / PM_CC), dim3(256), lds_c, s, m);
+        return (int)hipGetLastError();
+    }
     const int lds_b = (PA_TJ * DP + PA_TI * DP) * 4 + 3 * PA_TJ * 64 + 2 * PM_CC * 64;
     lds_optin<pattn_apply_mfma_kernel>();
     hipLaunchKernelGGL(pattn_apply_mfma_kernel, dim3(NJ, B, C / PM_CC), dim3(256), lds_b, s, m);
