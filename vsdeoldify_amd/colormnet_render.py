@@ -309,7 +309,7 @@ class DeepExColorMNet:
 
     def _squash(self, img, ctx=None):
         from .havc import spline64
-        h, w = img.shape[:2]
+        h, w = img.shape[-3], img.shape[-2]                                  # (a frame, or a window of frames [n, h, w, 3] without borders)
         ph, pw = self._borders(h, w)
         if ph or pw:
             from .device import is_device
@@ -380,7 +380,16 @@ class DeepExColorMNet:
                     net.lookahead_wait_for_main()
                 else:
                     pctx.synchronize()
-        smalls = [self._small(f, la_ctx) for f in new]
+        if la_ctx is not None and len(new) > 1 and self._window_is_contiguous(new):
+            # a resident clip: ONE Spline64 squash for the whole window (two launches instead of two per frame), on the look-ahead stream
+            from .device import DeviceImage
+            h, w = new[0].shape[:2]
+            src = DeviceImage(new[0].ctx, (len(new), h, w, 3), ptr=new[0].ptr, owner=new[0])
+            src._keep = new
+            batch, pads = self._squash(src, la_ctx)
+            smalls = [(batch.frame(j), pads) for j in range(len(new))]
+        else:
+            smalls = [self._small(f, la_ctx) for f in new]
         if la_ctx is not None:
             from .device import is_device as _isdev
             for sm, _ in smalls:
