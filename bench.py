@@ -224,7 +224,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=None, help="frames per step per GPU (default: 64 for the headline config and c3, 32 for c4 / c5)")
+    ap.add_argument("--batch", type=int, default=None, help="frames per step per GPU (default: 64 for the headline config and c4, 128 for c3, 32 for c5)")
     ap.add_argument("--clip-frames", type=int, default=None, help="distinct synthetic frames resident per GPU (default: one step's worth)")
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"],
                     help="c2 = BASELINE configs[1] (headline), c3 = configs[2] (DDColor large, input 512), c4 = configs[3] (DeOldify+DDColor merge), "
@@ -241,7 +241,9 @@ def main():
     if args.batch is None:              # 64 frames per step fill the small encoder / decoder layers better than 32 (+2 %, same-box A/B; 105 GB of activations)
         # c3 (DDColor): 64 frames = 65 536 tokens at the 768-channel stage -> 768 tiles of 256 x 256 for pwconv2 = exactly 3 per CU; at 32 frames
         # 384 tiles = 1.5 per CU and the GEMM runs at 75 % (profiles/r4_ddcolor_batch_sweep.txt: 1.09 -> 1.01 ms per frame of GPU ops)
-        args.batch = 64 if args.config in ("c2", "c3") else 32
+        # round 5, same-box A/B (gpurun_out/r5h): c3 at 128 frames per step 1 266 vs 1 230 frames/s at 64 (+2.9 %), c4 at 64: 879 vs 860 at 32 (+2.2 %),
+        # the headline at 96: 359.3 vs 357.3 at 64 (+0.6 %: left at 64); HAVC_TWO_STREAMS=0 at 64 frames: 348.0 (the two streams still buy 2.6 %)
+        args.batch = {"c2": 64, "c3": 128, "c4": 64}.get(args.config, 32)
     if args.clip_frames is None:
         args.clip_frames = args.batch
 
@@ -657,8 +659,9 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
         if os.path.isfile(pf):
             try:
                 rec = json.load(open(pf))
-                roofline["traffic"] = rec["traffic_bytes_per_launch"]
-                roofline["traffic_source"] = os.path.relpath(pf, ROOT) + " (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+                if abs(float(rec.get("frames_per_launch", 0)) - fpl) < 0.5:       # a record taken at another frames-per-launch is not this run's traffic
+                    roofline["traffic"] = rec["traffic_bytes_per_launch"]
+                    roofline["traffic_source"] = os.path.relpath(pf, ROOT) + " (separate --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
             except (ValueError, KeyError):
                 pass
     tot_flops, tot_frames = st.total_flops, st.frames

@@ -1,5 +1,5 @@
 """Per-launch HBM traffic of the dominant kernel of bench.py --config c3 | c4 from the counter CSVs of tools/pmc_cfg.sh -> profiles/<label>_<cfg>_pmc.json
-(read by bench.py as roofline.traffic of that config).    python tools/pmc_cfg_to_json.py c3|c4 [label] [dir]
+(read by bench.py as roofline.traffic of that config).    python tools/pmc_cfg_to_json.py c3|c4 [label] [dir] [frames per launch of the dominant kernel]
 c3: ConvNeXt stage-2 pwconv1 + GELU (768 -> 3072 at 32 x 32 tokens per frame): the GELU-epilogue conv kernel whose grid is launched most often (27 per pass);
 c4: the tail res-block conv 259 -> 259 at 384 x 384, conv_pipe_kernel<2, 4, 8, 1, 0, EF> (two instantiations, averaged like the c2 record).
 Corrections as MI355X_MICROARCH.md prescribes: counter unit KiB (x 1024); gfx950 FETCH_SIZE counts wide reads as 64 B per 128-B request (x 2)."""
@@ -8,6 +8,7 @@ import collections, csv, glob, json, os, shutil, sys
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
 label = sys.argv[2] if len(sys.argv) > 2 else "r5"
 src = sys.argv[3] if len(sys.argv) > 3 else "gpurun_out"
+fpl = float(sys.argv[4]) if len(sys.argv) > 4 else {"c3": 128.0, "c4": 32.0}[cfg]      # bench.py defaults: c3 128 frames per launch; c4 64 frames per step = 2 tail launches of 32
 MATCH = {"c3": lambda n: "conv_pipe_kernel<" in n and ", 1024>(" in n, "c4": lambda n: "conv_pipe_kernel<2, 4, 8, 1, 0" in n}[cfg]       # EF 1024 = HAVC_F_GELU
 
 
@@ -37,7 +38,7 @@ else:
     names = sorted({k[0] for k in fetch})
 KIB = 1024.0
 fb, wb = sum(f) / len(f) * KIB * 2, sum(w) / len(w) * KIB
-rec = {"config": cfg, "kernels": names, "launches_seen": [len(f), len(w)], "FETCH_SIZE_kib_raw_avg": sum(f) / len(f), "WRITE_SIZE_kib_raw_avg": sum(w) / len(w),
+rec = {"config": cfg, "frames_per_launch": fpl, "kernels": names, "launches_seen": [len(f), len(w)], "FETCH_SIZE_kib_raw_avg": sum(f) / len(f), "WRITE_SIZE_kib_raw_avg": sum(w) / len(w),
        "fetch_bytes_corrected": fb, "write_bytes": wb, "traffic_bytes_per_launch": fb + wb,
        "command": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --config {cfg} --no-cpu-baseline --no-extras --steps 2 --warmup 1 (tools/pmc_cfg.sh)",
        "correction": "counter unit KiB (x1024); gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide (16 B/lane) reads -> x2; WRITE_SIZE 1:1 (MI355X_MICROARCH.md HBM section)",
