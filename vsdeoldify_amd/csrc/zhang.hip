@@ -5,6 +5,7 @@
 //   truncates x*255, so fp32 colour math would flip LSBs for no speed gain.
 //   pil_resize_*: Pillow ImagingResample 8bpc (libImaging/Resample.c), integer coefficients from the host: bit-exact.
 #include "kernels.h"
+#include <mutex>
 
 static inline int grid_for(int64_t work) {
     int64_t b = (work + 255) / 256;
@@ -12,15 +13,26 @@ static inline int grid_for(int64_t work) {
 }
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+static int ensure_gray_lut(hipStream_t s);      // (defined next to gray_lut_kernel)
 
 __device__ __forceinline__ double srgb_to_linear(double c) { return c > 0.04045 ? pow((c + 0.055) / 1.055, 2.4) : c / 12.92; }
 
 __device__ __forceinline__ double lab_f(double t) { return t > 0.008856 ? cbrt(t) : 7.787 * t + 16.0 / 116.0; }
 
-__device__ __forceinline__ double rgb_to_L(int r, int g, int b) {
+__device__ __forceinline__ double rgb_to_L_full(int r, int g, int b) {
     const double R = srgb_to_linear(r / 255.0), G = srgb_to_linear(g / 255.0), B = srgb_to_linear(b / 255.0);
     const double y = 0.212671 * R + 0.715160 * G + 0.072169 * B;        // / 1.0 (D65 Yn)
     return 116.0 * lab_f(y) - 16.0;
+}
+
+// Gray pixels (R = G = B: every frame of the HAVC flows after convert_format_RGB24 of a B&W source, and the bench clips) take L from a 256-entry table that
+// gray_lut_kernel fills ONCE per device with this very function: the same bits as the per-pixel path, without its three fp64 pow and one cbrt per pixel
+// (round 5: DDColor's prep kernel was 1.7 ms per 128 frames at 512 x 512).  g_gray_dd: prep_ddcolor's three normalised values of Lab(L, 0, 0) -> RGB.
+__device__ double g_gray_L[256];
+__device__ float g_gray_dd[256][4];
+__device__ __forceinline__ double rgb_to_L(int r, int g, int b) {
+    if (r == g && g == b) return g_gray_L[r];
+    return rgb_to_L_full(r, g, b);
 }
 
 // model input: u8 RGB -> (float32(L) - 50) / 100 in channel 0 of an 8-channel fp16 pixel (channels 1..7 zero:
@@ -49,6 +61,7 @@ __global__ void prep_lab_l_kernel(const uint8_t* __restrict__ rgb, half_t* __res
 }
 
 int launch_prep_lab_l(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff, int64_t npix, hipStream_t s, int y_lo) {
+    if (int le = ensure_gray_lut(s)) return le;
     hipLaunchKernelGGL(prep_lab_l_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, y, y_cpitch, y_coff, npix, y_lo);
     return (int)hipGetLastError();
 }
@@ -105,6 +118,7 @@ __global__ void zhang_post_kernel(const uint8_t* __restrict__ orig, const float2
 
 int launch_zhang_post(const uint8_t* orig, const float* ab, int abH, int abW, uint8_t* out, int n_frames, int w, int h,
                       hipStream_t s) {
+    if (int le = ensure_gray_lut(s)) return le;
     // rgb_from_xyz = inv(xyz_from_rgb) exactly as skimage computes it (scipy.linalg.inv of the 3x3 sRGB matrix)
     static const double M[9] = {3.240481343200526, -1.5371515162713185, -0.4985363261688878,
                                 -0.9692549499965682, 1.8759900014898907, 0.04155592655829284,
@@ -129,19 +143,54 @@ __device__ __forceinline__ void lab_to_rgb01(double L, double a, double bb, doub
     g = fmin(fmax(linear_to_srgb(kRgbFromXyz[3] * X + kRgbFromXyz[4] * Y + kRgbFromXyz[5] * Z), 0.0), 1.0);
     b = fmin(fmax(linear_to_srgb(kRgbFromXyz[6] * X + kRgbFromXyz[7] * Y + kRgbFromXyz[8] * Z), 0.0), 1.0);
 }
+__global__ void gray_lut_kernel() {
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    const int k = threadIdx.x;
+    const double L = rgb_to_L_full(k, k, k);
+    g_gray_L[k] = L;
+    double c[3];
+    lab_to_rgb01(L, 0.0, 0.0, c[0], c[1], c[2]);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) g_gray_dd[k][e] = ((float)c[e] - mean[e]) / stdv[e];
+    g_gray_dd[k][3] = 0.f;
+}
+// filled once per device, synchronously, before the first kernel that reads it (under a mutex: contexts of one device may get here from several threads)
+static int ensure_gray_lut(hipStream_t s) {
+    static std::mutex mu;
+    static uint64_t done = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    std::lock_guard<std::mutex> lk(mu);
+    if (done & bit) return 0;
+    hipLaunchKernelGGL(gray_lut_kernel, dim3(1), dim3(256), 0, s);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return (int)e;
+    done |= bit;
+    return 0;
+}
+
 __global__ void prep_ddcolor_kernel(const uint8_t* __restrict__ rgb, half_t* __restrict__ y, int y_cpitch, int y_coff, half_t* __restrict__ y2,
                                     int y2_cpitch, int y2_coff, int64_t npix, int precise) {
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < npix; i += (int64_t)gridDim.x * blockDim.x) {
-        const double L = rgb_to_L(rgb[i * 3], rgb[i * 3 + 1], rgb[i * 3 + 2]);
-        double c[3];
-        lab_to_rgb01(L, 0.0, 0.0, c[0], c[1], c[2]);
+        const int pr = rgb[i * 3], pg = rgb[i * 3 + 1], pb = rgb[i * 3 + 2];
+        float nv[3];
+        if (pr == pg && pg == pb) {
+            nv[0] = g_gray_dd[pr][0]; nv[1] = g_gray_dd[pr][1]; nv[2] = g_gray_dd[pr][2];
+        } else {
+            double c[3];
+            lab_to_rgb01(rgb_to_L_full(pr, pg, pb), 0.0, 0.0, c[0], c[1], c[2]);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) nv[e] = ((float)c[e] - mean[e]) / stdv[e];
+        }
         half8 o, ol;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = ol[e] = (half_t)0.f;
 #pragma unroll
         for (int e = 0; e < 3; ++e) {
-            const float v = ((float)c[e] - mean[e]) / stdv[e];
+            const float v = nv[e];
             o[e] = (half_t)v;
             if (precise) { half_t a, b; split_pair(v, a, b); o[e] = a; ol[e] = b; }
         }
@@ -156,6 +205,7 @@ __global__ void prep_ddcolor_kernel(const uint8_t* __restrict__ rgb, half_t* __r
 }
 int launch_prep_ddcolor(const uint8_t* rgb, half_t* y, int y_cpitch, int y_coff, half_t* y2, int y2_cpitch, int y2_coff, int64_t npix,
                         hipStream_t s, int precise) {
+    if (int le = ensure_gray_lut(s)) return le;
     hipLaunchKernelGGL(prep_ddcolor_kernel, dim3(grid_for(npix)), dim3(256), 0, s, rgb, y, y_cpitch, y_coff, y2, y2_cpitch, y2_coff, npix, precise);
     return (int)hipGetLastError();
 }
@@ -206,6 +256,7 @@ __global__ void ddcolor_post_kernel(const uint8_t* __restrict__ orig, const half
 }
 int launch_ddcolor_post(const uint8_t* orig, const half_t* ab, int ab_cpitch, int ab_coff, int abH, int abW, uint8_t* out_u8, void* out_planes,
                         int planes_half, int n_frames, int w, int h, hipStream_t s, int ab_lo) {
+    if (int le = ensure_gray_lut(s)) return le;
     hipLaunchKernelGGL(ddcolor_post_kernel, dim3(grid_for((int64_t)n_frames * w * h)), dim3(256), 0, s, orig, ab, ab_cpitch, ab_coff, abH, abW, out_u8,
                        out_planes, planes_half, n_frames, w, h, (float)abH / (float)h, (float)abW / (float)w, ab_lo);
     return (int)hipGetLastError();
