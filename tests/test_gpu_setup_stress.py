@@ -1,7 +1,10 @@
 """-m gpu: concurrent model set-up from several host threads.  The reference's glue builds models from whichever VapourSynth
 worker thread asks first (vsslib/vsmodels.py:196-233); the library serialises set-up work behind one process-wide mutex and loads code objects /
 opts in to big LDS / sizes the queues' scratch eagerly at havc_create (csrc/havc_runtime.cpp).  The stress runs in a CHILD process under a
-timeout (a GPU hang must fail the test, not take the session with it): tools/setup_stress.py."""
+timeout (a GPU hang must fail the test, not take the session with it): tools/setup_stress.py.
+What this test shows, and what it does not: that concurrent set-up WORKS and gives the single-threaded bytes.  It does not show that the mutex /
+eager set-up are what makes it work -- the same workload also passes with both switched off (profiles/r4_setup_stress_unprotected.txt), and the one
+round-3 hang was never reproduced; the protections are a precaution."""
 import json
 import os
 import subprocess
