@@ -94,8 +94,10 @@ class DDColorGenerator:
         consts = []                                            # (buffer id, float32 array [rows, channels], row pitch in channels)
         in_buf = b.buf(S * S * 3, 1)
         x0 = b.tensor(S, S, 3)
-        if self.precise:
-            img_view = b.tensor(S, S, 3)                       # the refine conv's image term reads the normalised image as a pair tensor of its own
+        if self.precise or self.fuse_tail:
+            # the refine conv's image term reads the normalised image from a compact 8-channel tensor of its own (the fused tail never materialises the
+            # logits, so the 112-channel coarse buffer would hold nothing else: 16 contiguous bytes per pixel instead of 6 bytes at a 256-byte pitch)
+            img_view = b.tensor(S, S, 3)
             coarse_buf, coarse_pitch = img_view.buf, img_view.cpitch
             b.prep_ddcolor("prep", in_buf, S, x0, img_view)
         else:
