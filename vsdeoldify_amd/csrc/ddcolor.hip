@@ -530,8 +530,16 @@ __global__ void shuf4_blur_ab_kernel(const float* __restrict__ proj, const half_
         const float a = (v00.x + v01.x + v10.x + v11.x) * 0.25f + (rimg[0] * i0 + rimg[1] * i1 + rimg[2] * i2) + bias[0];
         const float bb = (v00.y + v01.y + v10.y + v11.y) * 0.25f + (rimg[3] * i0 + rimg[4] * i1 + rimg[5] * i2) + bias[1];
         half_t* yp = y + i * y_cpitch + y_coff;
-        yp[0] = (half_t)a;
-        yp[1] = (half_t)bb;
+        if ((y_coff & 7) == 0) {                            // the ab map is an 8-channel chunk with six zero pads: one 16-byte store (no partial-line writes)
+            half8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)0.f;
+            o[0] = (half_t)a; o[1] = (half_t)bb;
+            *reinterpret_cast<half8*>(yp) = o;
+        } else {
+            yp[0] = (half_t)a;
+            yp[1] = (half_t)bb;
+        }
     }
 }
 int launch_shuf4_blur_ab(const float* proj, const half_t* img, int img_cpitch, int img_coff, const float* rimg, const float* bias, half_t* y,
