@@ -476,6 +476,13 @@ int havc_colormnet_lab_to_rgb(havc_ctx* ctx, const float* l_plane, const float* 
  *                         ctx's SECOND stream, forked behind the main stream: the memory read runs next to it.  agg [H*W][2 CV], attn [225][H*W],
  *                         short_out [2 CV][H*W]: caller-owned device scratch / output; agg_buf / short_buf: the plan's buffer ids they are bound to
  *   havc_cmn_join_add     main stream waits for that, then readout += short_out (inference_core.py `_read`)
+ *   havc_cmn_side_begin / _end / _wait   (round 5) the READ of the next frame under the decoder of this one: between begin and end, havc_cmn_short_term,
+ *                         havc_memory_read_banked and havc_cmn_join_add are enqueued on the ctx's second stream (begin orders that stream behind the main
+ *                         stream's work so far); havc_cmn_side_wait makes the main stream wait for the section and, with apply_usage != 0, launches the usage
+ *                         update the section's memory read owes (a read that ran ahead leaves the counters alone: with apply_usage = 0 it is dropped
+ *                         without a trace when the caller steps another frame than the announced one).  The read of frame t+1 depends on the memory
+ *                         banks and on t+1's key, not on frame t's decoder (inference_core.py:119-230: memory and last_ti_key / last_ti_value change on
+ *                         memory frames only), so on the frames between two memory frames it runs next to segment(t) (colormnet_fast.py)
  *   havc_cmn_value_in     encode_value's input [2][5][pixels] from the padded image [3][pixels] and the ab planes [2][pixels] (network.py:87-101)
  *   havc_dev_copy_2d      device -> device rows with pitches (appending a frame's key / value columns to the banks), enqueued on the ctx stream
  *   havc_net_bind_many / havc_net_enqueue_slices   several havc_net_bind / havc_net_enqueue_ops in one call */
@@ -488,6 +495,9 @@ int havc_memory_read_banked(havc_ctx* ctx, const float* mk, const float* ms, con
 int havc_cmn_short_term(havc_ctx* ctx, havc_net* net, int first_op, int n_ops, int agg_buf, int short_buf, const float* q, const float* k, const float* v,
                         const float* rel_w, const float* rel_b, float* agg, float* attn, float* short_out, int C, int CV, int H, int W, int max_dis);
 int havc_cmn_join_add(havc_ctx* ctx, float* readout, const float* short_out, int64_t n);
+int havc_cmn_side_begin(havc_ctx* ctx);
+int havc_cmn_side_end(havc_ctx* ctx);
+int havc_cmn_side_wait(havc_ctx* ctx, int apply_usage);
 int havc_cmn_value_in(havc_ctx* ctx, const float* image, const float* planes, float* value_in, int64_t pixels);
 int havc_dev_copy_2d(havc_ctx* ctx, void* d_dst, size_t dst_pitch, const void* d_src, size_t src_pitch, size_t width_bytes, size_t rows);
 int havc_net_bind_many(havc_net* net, int count, const int32_t* bufs, void* const* device_ptrs);

@@ -657,3 +657,62 @@ def test_gpu_fast_step_long_clip_with_consolidation_and_lookahead():
     c, sc = run(True, 8)                                                      # + key look-ahead (split-K counts of the batched pass: fp32 summation order)
     d = np.abs(a.astype(int) - c.astype(int))
     assert sc == sa and (d <= 2).mean() > 0.999, (sc, int(d.max()), float((d <= 2).mean()))
+    # round 5: with the look-ahead the READ of frame t+1 runs under the decoder of frame t between memory frames (colormnet_fast.READ_AHEAD):
+    # the same kernels on the same numbers, on another stream -- identical frames and memory sizes with it switched off
+    import vsdeoldify_amd.colormnet_fast as cf
+    assert cf.READ_AHEAD
+    cf.READ_AHEAD = False
+    try:
+        c0, sc0 = run(True, 8)
+    finally:
+        cf.READ_AHEAD = True
+    assert sc0 == sc and np.array_equal(c, c0), (sc0, sc, int(np.abs(c.astype(int) - c0.astype(int)).max()), float((c != c0).mean()))
+
+
+@pytest.mark.gpu
+def test_gpu_read_ahead_runs_and_a_caller_leaving_the_announced_order_drops_it():
+    """The read enqueued ahead of its frame must (1) really happen on plain frames between memory frames, (2) leave NO trace (usage counters) when the
+    caller then steps another frame than the announced one: frames and memory identical to the same call sequence with READ_AHEAD off."""
+    import vsdeoldify_amd.colormnet_fast as cf
+    from vsdeoldify_amd.colormnet_render import ColorMNetRender
+    from vsdeoldify_amd.device import DeviceImage
+    net = gpu_network()
+    r = np.random.default_rng(9)
+    base = REN["frames"][0].astype(np.float32)
+    frames = [np.stack([np.clip(base + 5 * np.cos(t / 2.0) + r.normal(0, 2, base.shape), 0, 255).astype(np.uint8)] * 3, -1) for t in range(14)]
+    ref = REN["refs"][0]
+
+    def run():
+        rnd = ColorMNetRender(image_size=-1, vid_length=100, encode_mode=1, max_memory_frames=500, reset_on_ref_update=False, network=net, lookahead=8)
+        rnd.set_config("mem_every", 3)
+        rnd.set_config("enable_long_term_count_usage", True)
+        dev = [DeviceImage.from_numpy(net.ctx, f) for f in frames]
+        outs = []
+        rnd.prefetch(dev[:8])
+        for t in range(6):                                                    # frames 0 .. 5 in the announced order, 6 and 7 announced as plain too
+            rnd.set_ref_frame(DeviceImage.from_numpy(net.ctx, ref) if t == 0 else None, False)
+            rnd.next_is_plain = True
+            outs.append(rnd.colorize_frame(t, dev[t]).numpy())
+        hits = getattr(rnd.processor, "reads_ahead", 0)
+        pending = getattr(rnd.processor, "_ahead_read", None) is not None
+        for t in (10, 11, 12):                                                # ... but the caller jumps: frame 6's read, if it ran ahead, is dropped
+            rnd.set_ref_frame(None, False)
+            outs.append(rnd.colorize_frame(t, dev[t]).numpy())
+        import torch
+        torch.cuda.synchronize()
+        mem = rnd.processor.memory
+        use = mem.work_mem.get_usage().float().cpu().numpy() if mem.work_mem.count_usage else None
+        return np.stack(outs), hits, pending, use
+
+    a, hits, pending, use_a = run()
+    assert hits >= 3, hits                                                    # mem_every = 3: two of three frames are followed by a read-ahead
+    cf.READ_AHEAD = False
+    try:
+        b, hits_b, pending_b, use_b = run()
+    finally:
+        cf.READ_AHEAD = True
+    assert hits_b == 0 and not pending_b
+    assert np.array_equal(a, b), (int(np.abs(a.astype(int) - b.astype(int)).max()), float((a != b).mean()))
+    if use_a is not None:
+        assert np.array_equal(use_a, use_b)
+    print(f"read-ahead: {hits} reads ran ahead, one pending at the jump: {pending}")

@@ -18,10 +18,16 @@ Here the same state machine runs on PRE-SIZED device buffers through the fast-st
 Same arithmetic, same order of the memory elements, same bytes as the line-by-line classes (tests/test_colormnet_net.py runs the four recorded
 scenarios of the reference's own ColorMNetRender through both).  HAVC_CMN_FAST=0 selects the line-by-line classes.  GPU only: no backend hook."""
 import ctypes as C
+import os
 
 from . import _native as nat
 from .colormnet_core import DIVIDE_BY, InferenceCore
 from .colormnet_memory import KeyValueMemoryStore, MemoryManager
+
+
+# the read of frame t+1 (short-term attention + memory read) enqueued under the decoder of frame t on the frames between two memory frames
+# (FastInferenceCore._read); HAVC_CMN_READ_AHEAD=0 keeps every read in front of its own decoder (A/B runs; same bytes either way)
+READ_AHEAD = os.environ.get("HAVC_CMN_READ_AHEAD", "1") != "0"
 
 
 def _ptr(t, col=0):
@@ -276,21 +282,58 @@ class FastInferenceCore(InferenceCore):
         self.last_mem_ti = 0
         if not self.deep_update_sync:
             self.last_deep_update_ti = -self.deep_update_every
+        self.drop_read_ahead()                                 # a read in flight on the second stream belongs to the memory being dropped
         self.memory = FastMemoryManager(self.config, self.network)
 
     # ---- the two pieces every frame is made of ----
-    def _read(self, key, selection, feats, normal, with_short_term=True):
+    def hint_next(self, entry):
+        """the frame AFTER the one about to be stepped is a plain propagation frame (no exemplar, no processor reset) whose look-ahead entry
+        (colormnet_net.prefetch_frames) is `entry`: its read may run under this frame's decoder (READ_AHEAD)"""
+        self._next = entry
+
+    def drop_read_ahead(self):
+        """forget a read enqueued ahead of its frame (the memory is being replaced): the main stream waits for it, its usage update never happens"""
+        if getattr(self, "_ahead_read", None) is not None:
+            nat.check(self.network.ctx.lib.havc_cmn_side_wait(self.network.ctx.h, 0), self.network.ctx.h)
+        self._ahead_read = self._next = None
+
+    def _issue_read(self, B, key, selection, readout, with_short_term):
+        net = self.network
+        if with_short_term:                                    # forked onto the second stream: runs next to the memory read
+            net.short_term_fork(B, key, self.last_ti_key, self.last_ti_value)
+        self.memory.match_memory_into(key, selection, readout)
+        if with_short_term:
+            net.short_term_join(B, readout)
+
+    def _read(self, key, selection, feats, normal, with_short_term=True, is_mem=True):
         net = self.network
         f = feats[0]
         B = net.fast_buffers(*f.shape)
-        if with_short_term:                                    # forked onto the second stream: runs next to the memory read
-            net.short_term_fork(B, key, self.last_ti_key, self.last_ti_value)
-        self.memory.match_memory_into(key, selection, B.readout)
-        if with_short_term:
-            net.short_term_join(B)
+        ahead, self._ahead_read = getattr(self, "_ahead_read", None), None
+        hit = ahead is not None and ahead[0] is key and with_short_term
+        if ahead is not None:                                  # (a miss: the caller stepped another frame than the hinted one -- the read is dropped, its
+            nat.check(net.ctx.lib.havc_cmn_side_wait(net.ctx.h, 1 if hit else 0), net.ctx.h)      #  usage update never happens)
+        if hit:
+            readout = ahead[1]
+        else:
+            readout = B.readout
+            self._issue_read(B, key, selection, readout, with_short_term)
+        nxt, self._next = getattr(self, "_next", None), None
+        if READ_AHEAD and nxt is not None and not is_mem and self.last_ti_key is not None and nxt[3].shape == f.shape:
+            # The read of frame t+1 needs t+1's key (look-ahead pass) and the banks / last memory frame, which this frame does not change (it is
+            # not a memory frame): enqueue it on the second stream now, under this frame's decoder (inference_core.py:119-230 reads, then segments)
+            net.wait_prefetched(nxt)
+            other = B.readout2 if readout is B.readout else B.readout
+            nat.check(net.ctx.lib.havc_cmn_side_begin(net.ctx.h), net.ctx.h)
+            try:
+                self._issue_read(B, nxt[0], nxt[2], other, True)
+            finally:
+                nat.check(net.ctx.lib.havc_cmn_side_end(net.ctx.h), net.ctx.h)
+            self._ahead_read = (nxt[0], other)
+            self.reads_ahead = getattr(self, "reads_ahead", 0) + 1
         hidden_in = self.memory.get_hidden()
         hidden_out = B.other_hidden(hidden_in) if normal else None
-        net.segment_fast(B, f, hidden_in, hidden_out)
+        net.segment_fast(B, f, hidden_in, hidden_out, readout)
         if normal:
             self.memory.set_hidden(hidden_out)
         return B.prob                                          # [2, H, W] padded ab planes
@@ -324,7 +367,8 @@ class FastInferenceCore(InferenceCore):
         is_mem, deep, normal = self._schedule(mask is not None, end)
         need_segment = self.curr_ti > 0 and self._labels_differ(valid_labels)
         key, shrinkage, selection, f16, f8, f4 = self.network.encode_key(image, need_ek=(self.enable_long_term or need_segment), need_sk=is_mem)
-        planes = self._read(key, selection, (f16, f8, f4), normal) if need_segment else None
+        planes = self._read(key, selection, (f16, f8, f4), normal, is_mem=is_mem) if need_segment else None
+        self._next = None
         if mask is not None:
             planes = self._pad_like(mask, pad).contiguous()
             self.memory.create_hidden_state(2, key)
@@ -357,7 +401,8 @@ class FastInferenceCore(InferenceCore):
             except Exception:                                  # inference_core.py:172-180 swallows a failing add here; so does the drop-in
                 pass
         if need_segment:
-            planes = self._read(key, selection, (f16, f8, f4), normal, with_short_term=not exemplar)
+            planes = self._read(key, selection, (f16, f8, f4), normal, with_short_term=not exemplar, is_mem=is_mem)
+        self._next = None
         if msk_ab is not None and flag_FirstframeIsExemplar:
             planes = self._pad_like(msk_ab, pad).contiguous()
         if is_mem:

@@ -484,6 +484,7 @@ class _FastBuffers:
         with network.on_stream():
             new = lambda *shape: torch.empty(shape, dtype=torch.float32, device=network.device)
             self.readout, self.short, self.agg, self.attn = new(2 * CV, hw), new(2 * CV, hw), new(hw, 2 * CV), new(ws2, hw)
+            self.readout2 = new(2 * CV, hw)                     # the read of the NEXT frame lands here while the decoder reads `readout` (and vice versa)
             self.prob, self.value_in, self.value = new(2, H, W), new(2, 5, H, W), new(2, CV, hw)
             self.hidden = [new(1, 2, HD, self.h, self.w), new(1, 2, HD, self.h, self.w)]
             self.last_key, self.last_value = new(1, CK, self.h, self.w), new(1, 2, CV, self.h, self.w)
@@ -864,13 +865,15 @@ class ColorMNetNetwork:
                                                    p(self.rel_w), p(self.rel_b), p(B.agg), p(B.attn), p(B.short), self.key_dim, 2 * self.value_dim, B.h, B.w,
                                                    MAX_DIS), self.ctx.h)
 
-    def short_term_join(self, B):
+    def short_term_join(self, B, readout=None):
         import ctypes as C
-        nat.check(self.ctx.lib.havc_cmn_join_add(self.ctx.h, C.c_void_p(B.readout.data_ptr()), C.c_void_p(B.short.data_ptr()), B.readout.numel()), self.ctx.h)
+        readout = B.readout if readout is None else readout
+        nat.check(self.ctx.lib.havc_cmn_join_add(self.ctx.h, C.c_void_p(readout.data_ptr()), C.c_void_p(B.short.data_ptr()), readout.numel()), self.ctx.h)
 
-    def segment_fast(self, B, f, hidden_in, hidden_out):
-        """Decoder (+ HiddenUpdater when hidden_out is given) on B.readout -> B.prob (network.py:137-145)"""
-        binds = [("g16", f.g16), ("g8", f.g8), ("g4", f.g4), ("readout", B.readout), ("hidden", hidden_in), ("prob", B.prob),
+    def segment_fast(self, B, f, hidden_in, hidden_out, readout=None):
+        """Decoder (+ HiddenUpdater when hidden_out is given) on the readout (B.readout unless given) -> B.prob (network.py:137-145)"""
+        readout = B.readout if readout is None else readout
+        binds = [("g16", f.g16), ("g8", f.g8), ("g4", f.g4), ("readout", readout), ("hidden", hidden_in), ("prob", B.prob),
                  ("skip8", f.skip8), ("skip4", f.skip4)]
         slices = ([] if f.skip8 is not None else ["skip"]) + ["segment"]
         if hidden_out is not None:

@@ -96,6 +96,9 @@ class ColorMNetRender:
         self.processor = self._new_processor()
 
     def _new_processor(self):
+        old = getattr(self, "processor", None)
+        if old is not None and hasattr(old, "drop_read_ahead"):
+            old.drop_read_ahead()                                       # a read enqueued for a frame the old memory will never see
         if self._fast:
             from .colormnet_fast import FastInferenceCore
             return FastInferenceCore(self.network, self.config, device_index=self.device_index)
@@ -124,6 +127,7 @@ class ColorMNetRender:
                     self.prefetch(frame_list[:L])
                 self.prefetch(frame_list[i + L:i + 2 * L])              # the window AFTER this one: its pass overlaps this window's frame steps
             self.set_ref_frame(ref_i, frame_propagate)
+            self.next_is_plain = i + 1 < len(frame_list) and ref_list[i + 1] is None
             out.append(self.colorize_frame(i, frame_i))
         return out
 
@@ -256,6 +260,11 @@ class ColorMNetRender:
         is_last = self.vid_length == self.total_colored_frames - 1
         if ahead:
             net.expect_prefetched(ahead[2])
+        plain_next, self.next_is_plain = getattr(self, "next_is_plain", False), False
+        if plain_next and ahead and self._ahead and self.frame_count < self.max_memory_frames and hasattr(self.processor, "hint_next"):
+            # the caller promised that the NEXT call is the next announced frame without a reference image, and it will not reset the memory: its
+            # read (memory + short-term attention) may run under this frame's decoder (FastInferenceCore._read)
+            self.processor.hint_next(self._ahead[0][2])
         if self.config["FirstFrameIsNotExemplar"]:
             prob = self.processor.step_AnyExemplar_padded(img, pad, ref_img, msk_ab, labels, end=is_last)
         else:
@@ -324,10 +333,11 @@ class DeepExColorMNet:
         small, pads = self._squash(frame, ctx)
         return (small if is_device(small) else Image.fromarray(small)), pads
 
-    def colorize_frame(self, frame, ref=None, _small=None, _slot=None):
+    def colorize_frame(self, frame, ref=None, _small=None, _slot=None, _next_plain=False):
         """frame: u8 [h, w, 3] (ndarray or DeviceImage); ref: the reference image for THIS frame (same size as the clip) or None.
         _slot (colorize_frames): a frame of a window-sized low-resolution buffer -- the coloured small frame is written there and RETURNED without the
-        Spline64 pass back to the clip size, which the caller then runs once for the whole window."""
+        Spline64 pass back to the clip size, which the caller then runs once for the whole window.  _next_plain (colorize_frames): the next call is the
+        next announced frame and carries no reference image (ColorMNetRender._colorize_frame_fast may start its read early)."""
         from .device import is_device
         from .havc import spline64
         h, w = frame.shape[:2]
@@ -344,6 +354,7 @@ class DeepExColorMNet:
             rs, _ = self._squash(ref)
             ref = rs if is_device(rs) else np.asarray(rs)
         self.render.set_ref_frame(ref, self.propagate)
+        self.render.next_is_plain = bool(_next_plain)
         if _slot is not None and is_device(small) and not (ph or pw) and self.render.first_mask_loaded:
             self.render.out_slot = _slot
             col = self.render.colorize_frame(self.t, small)
@@ -423,7 +434,9 @@ class DeepExColorMNet:
             cols = []
             for j, f in enumerate(win):
                 ent = self._announced.pop(id(f), None)
-                cols.append(self.colorize_frame(f, refs.get(i0 + j), _small=ent[1] if ent else None, _slot=slots.frame(j) if batched else None))
+                nxt = i0 + j + 1
+                cols.append(self.colorize_frame(f, refs.get(i0 + j), _small=ent[1] if ent else None, _slot=slots.frame(j) if batched else None,
+                                                _next_plain=nxt < len(frames) and nxt not in refs))
             if batched and all(c is not None and getattr(c, "_owner", None) is slots for c in cols):
                 from .havc import spline64
                 h, w = win[0].shape[:2]

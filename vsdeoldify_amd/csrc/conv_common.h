@@ -7,21 +7,20 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-// GELU in its exact form 0.5 v (1 + erf(v / sqrt 2)) (nn.GELU() of the ConvNeXt block).  erf by Abramowitz & Stegun 7.1.26
-// (|error| < 1.5e-7 + the 1-ulp v_rcp / v_exp): three orders below the fp16 rounding of the stored result, and a third of the
-// instructions of libm's two-branch erff -- the epilogue of pwconv1 evaluates 0.4 G of these per frame.  One definition for every
-// conv kernel, so all tile configurations keep producing the same bytes.  The reciprocal is the bare v_rcp_f32: __frcp_rn expands
-// to the correctly rounded division sequence (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup: 10 of the 23 VALU
-// instructions per value until round 4, when the ConvNeXt pwconv1 epilogue turned out to spend 20 % of the GEMM's time here).
+// GELU v Phi(v) of the ConvNeXt block / the ViT MLP (nn.GELU(), exact form) for results that are ROUNDED TO fp16: Phi(v) as a logistic function of an odd
+// polynomial, Phi(v) = 1 / (1 + exp(-u)), u = v P(min(v^2, 36)) with a degree-3 P fitted (minimax over |v| <= 12, tools/fit_gelu.py) to
+// logit Phi: |v Phi(v) - approximation| < 1.2e-5 everywhere -- a fifth of half an fp16 ulp at |result| >= 0.06, exact 0.5 v at v -> 0, v / 0 beyond the clamp
+// (exp2 overflows to inf, v_rcp(inf) = 0).  10 VALU instructions with two transcendentals (v_exp, v_rcp) per value against 16 of the Abramowitz-Stegun
+// erf it replaces (round 4): the epilogue of DDColor's pwconv1 evaluates 0.4 G of these per frame and no other wave's MFMAs hide them (one block per CU).
+// One definition for every conv kernel, so all tile configurations keep producing the same bytes.  The precise mode uses libm's erff (epilogue_frag_precise).
 __device__ __forceinline__ float gelu_erf(float v) {
-    const float x = fabsf(v) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-x * x);
-    return 0.5f * v * (1.0f + copysignf(e, v));
+    const float L2E = 1.44269504088896341f;
+    const float v2 = fminf(v * v, 36.0f);
+    float p = fmaf(-1.72152684e-05f * -L2E, v2, -5.10199108e-04f * -L2E);
+    p = fmaf(p, v2, 7.34616312e-02f * -L2E);
+    p = fmaf(p, v2, 1.59538024f * -L2E);
+    const float e = __builtin_amdgcn_exp2f(p * v);               // exp(-u)
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // output pixel index of GEMM row m (identity unless the conv scatters with an output step: ConvTranspose parity convs)

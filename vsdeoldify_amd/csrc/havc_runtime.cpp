@@ -63,7 +63,9 @@ struct havc_ctx {
     int dev = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // the second generator of a stable/artistic render runs here, concurrently
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_main_done = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_main_done = nullptr, ev_side = nullptr;
+    bool side = false;                    // between havc_cmn_side_begin / _end: the ColorMNet read (short-term attention, memory read, join) is enqueued on stream2
+    struct { float* use = nullptr; float* life = nullptr; int from = 0, N = 0, HW = 0, top_k = 0; } side_usage;   // its usage update, owed until havc_cmn_side_wait
     hipStream_t cur = nullptr;            // stream the plan executor launches on (stream or stream2)
     bool two_streams = true;              // HAVC_TWO_STREAMS=0 serialises the two generators (A/B measurements)
     bool range_check = false;             // HAVC_RANGE_CHECK / havc_range_check_enable: scan every op's destination for inf / NaN / abs-max
@@ -953,6 +955,7 @@ int havc_create(havc_ctx** out, int device_id) {
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_main_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
         return fail(nullptr, HAVC_E_HIP, "failed to create stream/events");
@@ -1006,6 +1009,7 @@ static void havc_destroy_unlocked(havc_ctx* c) {
     (void)hipEventDestroy(c->ev_fork);
     (void)hipEventDestroy(c->ev_join);
     (void)hipEventDestroy(c->ev_main_done);
+    (void)hipEventDestroy(c->ev_side);
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -2389,22 +2393,30 @@ int havc_memory_read_banked(havc_ctx* c, const float* mk, const float* ms, const
     int rc;
     const size_t lst = (size_t)top_k * HW, cand = lst * (mem_topk_splits(N) > 1 ? mem_topk_splits(N) : 0);
     if ((rc = ensure_scratch(c, 8, (size_t)N * HW * 4)) || (rc = ensure_scratch(c, 9, (lst + cand) * 4)) || (rc = ensure_scratch(c, 10, (lst + cand) * 4))) return rc;
+    const hipStream_t st = c->side ? c->stream2 : c->stream;       // a read-ahead (havc_cmn_side_begin) runs next to the previous frame's decoder
     static const bool wave_topk = [] { const char* e = getenv("HAVC_TOPK_WAVE"); return !e || atoi(e) != 0; }();
     int e;
     if (wave_topk && mem_topk_select_supported(N)) {
-        e = launch_mem_similarity_t(mk, ms, qk, qe, (float*)c->scratch[8], 1, CK, N, HW, c->stream, pitch);
-        if (!e) e = launch_mem_topk_select_readout((const float*)c->scratch[8], mv, (int*)c->scratch[9], (float*)c->scratch[10], out, 1, CV, N, HW, top_k, c->stream, pitch);
+        e = launch_mem_similarity_t(mk, ms, qk, qe, (float*)c->scratch[8], 1, CK, N, HW, st, pitch);
+        if (!e) e = launch_mem_topk_select_readout((const float*)c->scratch[8], mv, (int*)c->scratch[9], (float*)c->scratch[10], out, 1, CV, N, HW, top_k, st, pitch);
     } else {
-        e = launch_mem_similarity(mk, ms, qk, qe, (float*)c->scratch[8], 1, CK, N, HW, c->stream, pitch);
+        e = launch_mem_similarity(mk, ms, qk, qe, (float*)c->scratch[8], 1, CK, N, HW, st, pitch);
         if (!e) e = launch_mem_topk_readout((const float*)c->scratch[8], mv, (int*)c->scratch[9], (float*)c->scratch[10], (float*)c->scratch[10] + lst,
-                                            (int*)c->scratch[9] + lst, out, 1, CV, N, HW, top_k, c->stream, pitch);
+                                            (int*)c->scratch[9] + lst, out, 1, CV, N, HW, top_k, st, pitch);
     }
     c->stats.launches += 3;
     if (!e && use_count) {
         if ((rc = ensure_scratch(c, 11, (size_t)N * 8))) return rc;
-        e = launch_mem_usage_update((const int*)c->scratch[9], (const float*)c->scratch[10], (unsigned long long*)c->scratch[11], use_count, life_count,
-                                    usage_from, N, HW, top_k, c->stream);
-        c->stats.launches += 2;
+        if (c->side) {
+            // a read that runs ahead must not touch the counters before its frame is really stepped (a caller may leave the announced order): the
+            // top-k lists stay in scratch 9 / 10 until the next read, havc_cmn_side_wait(apply = 1) launches the update from them on the main stream
+            c->side_usage.use = use_count; c->side_usage.life = life_count; c->side_usage.from = usage_from;
+            c->side_usage.N = N; c->side_usage.HW = HW; c->side_usage.top_k = top_k;
+        } else {
+            e = launch_mem_usage_update((const int*)c->scratch[9], (const float*)c->scratch[10], (unsigned long long*)c->scratch[11], use_count, life_count,
+                                        usage_from, N, HW, top_k, st);
+            c->stats.launches += 2;
+        }
     }
     if (e) return hip_fail(c, (hipError_t)e, "memory_read_banked");
     return HAVC_OK;
@@ -2419,8 +2431,10 @@ int havc_cmn_short_term(havc_ctx* c, havc_net* net, int first_op, int n_ops, int
     HIP_TRY(c, hipSetDevice(c->dev));
     // fork: stream2 starts behind everything the main stream holds so far (the producers of q / k / v), runs the local attention and the plan's
     // `short` slice there, and records the join event havc_cmn_join_add waits for -- the main stream is free for the memory read meanwhile
-    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    if (!c->side) {                                                // (a read-ahead is on stream2 from its first launch on)
+        HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    }
     int e = launch_local_correlation(q, k, attn, 1, C, H, W, max_dis, 1, 1.0f / sqrtf((float)C), c->stream2);
     if (!e) e = launch_local_softmax(attn, q, rel_w, rel_b, 1, C, H, W, max_dis, 1, c->stream2);
     if (!e) e = launch_local_agg(attn, v, agg, 1, CV, H, W, max_dis, 1, c->stream2);
@@ -2441,10 +2455,50 @@ int havc_cmn_join_add(havc_ctx* c, float* readout, const float* short_out, int64
     if (!c || !readout || !short_out || n < 1) return fail(c, HAVC_E_INVALID, "cmn_join_add: bad args");
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(c, hipSetDevice(c->dev));
-    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
-    int e = launch_vec_add(readout, short_out, n, c->stream);
+    const hipStream_t st = c->side ? c->stream2 : c->stream;
+    if (!c->side) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    int e = launch_vec_add(readout, short_out, n, st);
     c->stats.launches++;
     if (e) return hip_fail(c, (hipError_t)e, "cmn_join_add");
+    return HAVC_OK;
+}
+
+int havc_cmn_side_begin(havc_ctx* c) {
+    if (!c) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->side) return fail(c, HAVC_E_INVALID, "cmn_side_begin: already inside a side section");
+    if (c->side_usage.use) return fail(c, HAVC_E_INVALID, "cmn_side_begin: the previous section has not been waited for");
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));             // behind everything the main stream holds: the previous read, the banks, the look-ahead keys it waited for
+    HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    c->side = true;
+    return HAVC_OK;
+}
+
+int havc_cmn_side_end(havc_ctx* c) {
+    if (!c) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->side) return fail(c, HAVC_E_INVALID, "cmn_side_end: no side section open");
+    c->side = false;
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipEventRecord(c->ev_side, c->stream2));
+    return HAVC_OK;
+}
+
+int havc_cmn_side_wait(havc_ctx* c, int apply_usage) {
+    if (!c) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->side) return fail(c, HAVC_E_INVALID, "cmn_side_wait: inside a side section");
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side, 0));
+    auto u = c->side_usage;
+    c->side_usage = {};
+    if (apply_usage && u.use) {
+        int e = launch_mem_usage_update((const int*)c->scratch[9], (const float*)c->scratch[10], (unsigned long long*)c->scratch[11], u.use, u.life, u.from,
+                                        u.N, u.HW, u.top_k, c->stream);
+        c->stats.launches += 2;
+        if (e) return hip_fail(c, (hipError_t)e, "cmn_side_wait: usage update");
+    }
     return HAVC_OK;
 }
 
