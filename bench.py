@@ -790,6 +790,7 @@ def bench_c5(args, rank, local_rank, world, dist):
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    issued = time.perf_counter() - t0                               # the host has enqueued every frame (the calls only enqueue); the GPU may still be working
     sync_all()
     elapsed = time.perf_counter() - t0
     avg_ms, launches = ctypes.c_double(), ctypes.c_int64()
@@ -817,7 +818,8 @@ def bench_c5(args, rank, local_rank, world, dist):
                       "weights": "seeded synthetic (ResNet50 + DINOv2 ViT-S/14 key encoder, ResNet18 value encoder, decoder; DINOv2 branch parity-UNPINNED)",
                       "algorithmic_gflop_per_frame": round(gflop_frame, 2), "mem_every": 5, "device_resident": True,
                       "working_memory_elements": int(mem.work_mem.size), "long_term_elements": int(mem.long_mem.size) if mem.long_mem.engaged() else 0,
-                      "key_encoder_lookahead": rnd.lookahead,
+                      "key_encoder_lookahead": rnd.lookahead, "read_ahead": bool(getattr(rnd.processor, "reads_ahead", 0)),
+                      "host_enqueue_share_of_wall": round(issued / elapsed, 3),
                       "parallelism": f"memory step sequential in time (key encoder {rnd.lookahead} frames ahead, concurrently on a second stream): replicas only, one clip per GPU x{world}"},
            "whole_path_tflops": round(total * gflop_frame * 1e9 / elapsed / 1e12 / world, 2),
            "whole_path_frac": round(total * gflop_frame * 1e9 / elapsed / 1e12 / world / PEAK_F16_TFLOPS, 4),

@@ -224,6 +224,11 @@ typedef struct havc_stats {
 /* ---- context (replaces: device.set(DeviceId(device_index)), deoldify/_device.py:21-30;
  *      vsdeoldify/__init__.py:2487).  device_id = HIP ordinal as seen by this process. ---- */
 int havc_create(havc_ctx** out, int device_id);
+/* level < 0: the ctx's two streams are re-created at the LOWEST priority of the device (hipDeviceGetStreamPriorityRange), > 0: at the highest, 0: default.
+ * For a context whose work should fill the CUs another context leaves idle without delaying it: ColorMNet's batched look-ahead pass (16 frames of the key
+ * encoder) next to the frame-by-frame memory step, whose small dependent launches are latency-bound.  Call it before any stream handle of the ctx is
+ * handed out (havc_stream); both streams are drained first. */
+int havc_ctx_set_stream_priority(havc_ctx* ctx, int level);
 void havc_destroy(havc_ctx* ctx);
 const char* havc_last_error(const havc_ctx* ctx);      /* ctx may be NULL: last creation error            */
 int havc_device_count(void);
@@ -478,7 +483,8 @@ int havc_colormnet_lab_to_rgb(havc_ctx* ctx, const float* l_plane, const float* 
  *   havc_cmn_join_add     main stream waits for that, then readout += short_out (inference_core.py `_read`)
  *   havc_cmn_side_begin / _end / _wait   (round 5) the READ of the next frame under the decoder of this one: between begin and end, havc_cmn_short_term,
  *                         havc_memory_read_banked and havc_cmn_join_add are enqueued on the ctx's second stream (begin orders that stream behind the main
- *                         stream's work so far); havc_cmn_side_wait makes the main stream wait for the section and, with apply_usage != 0, launches the usage
+ *                         stream's work so far -- or, after havc_cmn_side_mark, behind its work up to the mark: the host enqueues this frame's decoder between
+ *                         mark and begin, so the main stream never idles while the host issues the section); havc_cmn_side_wait makes the main stream wait for the section and, with apply_usage != 0, launches the usage
  *                         update the section's memory read owes (a read that ran ahead leaves the counters alone: with apply_usage = 0 it is dropped
  *                         without a trace when the caller steps another frame than the announced one).  The read of frame t+1 depends on the memory
  *                         banks and on t+1's key, not on frame t's decoder (inference_core.py:119-230: memory and last_ti_key / last_ti_value change on
@@ -495,6 +501,7 @@ int havc_memory_read_banked(havc_ctx* ctx, const float* mk, const float* ms, con
 int havc_cmn_short_term(havc_ctx* ctx, havc_net* net, int first_op, int n_ops, int agg_buf, int short_buf, const float* q, const float* k, const float* v,
                         const float* rel_w, const float* rel_b, float* agg, float* attn, float* short_out, int C, int CV, int H, int W, int max_dis);
 int havc_cmn_join_add(havc_ctx* ctx, float* readout, const float* short_out, int64_t n);
+int havc_cmn_side_mark(havc_ctx* ctx);
 int havc_cmn_side_begin(havc_ctx* ctx);
 int havc_cmn_side_end(havc_ctx* ctx);
 int havc_cmn_side_wait(havc_ctx* ctx, int apply_usage);

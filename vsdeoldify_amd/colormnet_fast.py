@@ -319,10 +319,20 @@ class FastInferenceCore(InferenceCore):
             readout = B.readout
             self._issue_read(B, key, selection, readout, with_short_term)
         nxt, self._next = getattr(self, "_next", None), None
-        if READ_AHEAD and nxt is not None and not is_mem and self.last_ti_key is not None and nxt[3].shape == f.shape:
+        ahead_ok = READ_AHEAD and nxt is not None and not is_mem and self.last_ti_key is not None and nxt[3].shape == f.shape
+        if ahead_ok:
             # The read of frame t+1 needs t+1's key (look-ahead pass) and the banks / last memory frame, which this frame does not change (it is
-            # not a memory frame): enqueue it on the second stream now, under this frame's decoder (inference_core.py:119-230 reads, then segments)
+            # not a memory frame): it goes onto the second stream, under this frame's decoder (inference_core.py:119-230 reads, then segments).
+            # The second stream starts behind the main stream's work UP TO HERE (mark); the decoder is enqueued first, so that the main stream does
+            # not sit idle while the host issues the ~12 launches of the read.
             net.wait_prefetched(nxt)
+            nat.check(net.ctx.lib.havc_cmn_side_mark(net.ctx.h), net.ctx.h)
+        hidden_in = self.memory.get_hidden()
+        hidden_out = B.other_hidden(hidden_in) if normal else None
+        net.segment_fast(B, f, hidden_in, hidden_out, readout)
+        if normal:
+            self.memory.set_hidden(hidden_out)
+        if ahead_ok:
             other = B.readout2 if readout is B.readout else B.readout
             nat.check(net.ctx.lib.havc_cmn_side_begin(net.ctx.h), net.ctx.h)
             try:
@@ -331,11 +341,6 @@ class FastInferenceCore(InferenceCore):
                 nat.check(net.ctx.lib.havc_cmn_side_end(net.ctx.h), net.ctx.h)
             self._ahead_read = (nxt[0], other)
             self.reads_ahead = getattr(self, "reads_ahead", 0) + 1
-        hidden_in = self.memory.get_hidden()
-        hidden_out = B.other_hidden(hidden_in) if normal else None
-        net.segment_fast(B, f, hidden_in, hidden_out, readout)
-        if normal:
-            self.memory.set_hidden(hidden_out)
         return B.prob                                          # [2, H, W] padded ab planes
 
     def _memorise(self, image, key, shrinkage, selection, f16, planes, deep):

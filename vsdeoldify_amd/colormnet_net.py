@@ -606,6 +606,13 @@ class ColorMNetNetwork:
         """the network object the look-ahead pass runs on: another context (its own HIP stream and activation arena) of the same GPU, same packed
         weights.  The pass for the NEXT frames then overlaps the frame-by-frame memory step, whose small launches leave most CUs idle."""
         if self._helper is None:
+            from .render import get_context
+            hctx = get_context(self.ctx.device_id, ("lookahead", self.worker))
+            if os.environ.get("HAVC_CMN_LOOKAHEAD_PRIORITY", "low") == "low" and not getattr(hctx, "_low_priority", False):
+                # the batched pass fills whatever CUs the memory step's small dependent launches leave idle: at the lowest stream priority the
+                # dispatcher serves the memory step's queue first whenever both have a block ready (before any stream handle of hctx is handed out)
+                nat.check(hctx.lib.havc_ctx_set_stream_priority(hctx.h, -1), hctx.h)
+                hctx._low_priority = True
             self._helper = ColorMNetNetwork(None, device_index=self.ctx.device_id, autotune=self.autotune, worker=("lookahead", self.worker), share=self)
         return self._helper
 

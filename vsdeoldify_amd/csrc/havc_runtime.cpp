@@ -63,7 +63,8 @@ struct havc_ctx {
     int dev = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;        // the second generator of a stable/artistic render runs here, concurrently
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_main_done = nullptr, ev_side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_main_done = nullptr, ev_side = nullptr, ev_mark = nullptr;
+    bool marked = false;                  // havc_cmn_side_mark recorded ev_mark: the next side section starts behind THAT point of the main stream
     bool side = false;                    // between havc_cmn_side_begin / _end: the ColorMNet read (short-term attention, memory read, join) is enqueued on stream2
     struct { float* use = nullptr; float* life = nullptr; int from = 0, N = 0, HW = 0, top_k = 0; } side_usage;   // its usage update, owed until havc_cmn_side_wait
     hipStream_t cur = nullptr;            // stream the plan executor launches on (stream or stream2)
@@ -956,6 +957,7 @@ int havc_create(havc_ctx** out, int device_id) {
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_main_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_mark, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
         delete c;
         return fail(nullptr, HAVC_E_HIP, "failed to create stream/events");
@@ -1010,6 +1012,7 @@ static void havc_destroy_unlocked(havc_ctx* c) {
     (void)hipEventDestroy(c->ev_join);
     (void)hipEventDestroy(c->ev_main_done);
     (void)hipEventDestroy(c->ev_side);
+    (void)hipEventDestroy(c->ev_mark);
     (void)hipStreamDestroy(c->stream2);
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -2463,15 +2466,50 @@ int havc_cmn_join_add(havc_ctx* c, float* readout, const float* short_out, int64
     return HAVC_OK;
 }
 
+int havc_cmn_side_mark(havc_ctx* c) {
+    if (!c) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->side) return fail(c, HAVC_E_INVALID, "cmn_side_mark: inside a side section");
+    HIP_TRY(c, hipSetDevice(c->dev));
+    HIP_TRY(c, hipEventRecord(c->ev_mark, c->stream));             // everything the main stream holds NOW: the previous read, the banks, the look-ahead keys it waited for
+    c->marked = true;
+    return HAVC_OK;
+}
+
 int havc_cmn_side_begin(havc_ctx* c) {
     if (!c) return HAVC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->side) return fail(c, HAVC_E_INVALID, "cmn_side_begin: already inside a side section");
     if (c->side_usage.use) return fail(c, HAVC_E_INVALID, "cmn_side_begin: the previous section has not been waited for");
     HIP_TRY(c, hipSetDevice(c->dev));
-    HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));             // behind everything the main stream holds: the previous read, the banks, the look-ahead keys it waited for
-    HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
+    // behind the main stream's work up to the last havc_cmn_side_mark (what was enqueued after it -- this frame's decoder -- runs NEXT to the section), or,
+    // without a mark, behind everything it holds
+    if (!c->marked) HIP_TRY(c, hipEventRecord(c->ev_mark, c->stream));
+    c->marked = false;
+    HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_mark, 0));
     c->side = true;
+    return HAVC_OK;
+}
+
+int havc_ctx_set_stream_priority(havc_ctx* c, int level) {
+    if (!c) return HAVC_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->side) return fail(c, HAVC_E_INVALID, "set_stream_priority: inside a side section");
+    HIP_TRY(c, hipSetDevice(c->dev));
+    int least = 0, greatest = 0;
+    HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
+    const int prio = level < 0 ? least : level > 0 ? greatest : 0;
+    HIP_TRY(c, sync_streams(c));
+    hipStream_t a = nullptr, b = nullptr;
+    if (hipStreamCreateWithPriority(&a, hipStreamNonBlocking, prio) != hipSuccess || hipStreamCreateWithPriority(&b, hipStreamNonBlocking, prio) != hipSuccess) {
+        (void)hipGetLastError();
+        if (a) (void)hipStreamDestroy(a);
+        return fail(c, HAVC_E_HIP, "set_stream_priority: hipStreamCreateWithPriority failed");
+    }
+    (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->stream2);
+    c->stream = a;
+    c->stream2 = b;
     return HAVC_OK;
 }
 
