@@ -787,12 +787,25 @@ def bench_c5(args, rank, local_rank, world, dist):
     ctx.reset_stats()
     nat.check(tctx.lib.havc_tag_timing_enable(tctx.h, int(op["tag"]), 1), tctx.h)
     sync_all()
+    prof = None
+    if os.environ.get("HAVC_BENCH_CPROFILE"):                       # tools/c5_host_profile.py: where the HOST spends the timed frames
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     issued = time.perf_counter() - t0                               # the host has enqueued every frame (the calls only enqueue); the GPU may still be working
     sync_all()
     elapsed = time.perf_counter() - t0
+    if prof is not None:
+        import io
+        import pstats
+        prof.disable()
+        for key in ("tottime", "cumulative"):
+            buf = io.StringIO()
+            pstats.Stats(prof, stream=buf).strip_dirs().sort_stats(key).print_stats(40)
+            print(buf.getvalue()[:8000], file=sys.stderr)
     avg_ms, launches = ctypes.c_double(), ctypes.c_int64()
     tctx.synchronize()
     nat.check(tctx.lib.havc_tag_timing_read(tctx.h, ctypes.byref(avg_ms), ctypes.byref(launches)), tctx.h)

@@ -229,6 +229,10 @@ int havc_create(havc_ctx** out, int device_id);
  * encoder) next to the frame-by-frame memory step, whose small dependent launches are latency-bound.  Call it before any stream handle of the ctx is
  * handed out (havc_stream); both streams are drained first. */
 int havc_ctx_set_stream_priority(havc_ctx* ctx, int level);
+/* the ctx's two streams are re-created with a CU mask of n_cus compute units (hipExtStreamCreateWithCUMask; the first n bits = n / 8 CUs of every XCD):
+ * the batched look-ahead pass of ColorMNet then cannot occupy the whole chip, and the memory step's small dependent launches (another context, all CUs)
+ * always find free CUs.  Same calling rules as havc_ctx_set_stream_priority. */
+int havc_ctx_set_stream_cus(havc_ctx* ctx, int n_cus);
 void havc_destroy(havc_ctx* ctx);
 const char* havc_last_error(const havc_ctx* ctx);      /* ctx may be NULL: last creation error            */
 int havc_device_count(void);
@@ -498,6 +502,9 @@ int havc_cmn_frame_out(havc_ctx* ctx, const float* l_plane, const float* ab_padd
                        int pad_left, int pad_top);
 int havc_memory_read_banked(havc_ctx* ctx, const float* mk, const float* ms, const float* qk, const float* qe, const float* mv, float* out,
                             float* use_count, float* life_count, int usage_from, int CK, int CV, int N, int64_t pitch, int HW, int top_k);
+/* sizes the scratch of havc_memory_read_banked for every N <= N_max once (the banks' capacity): a memory that grows frame by frame would otherwise regrow
+ * it a few times per clip, each time behind a device synchronisation (round 5: two such stalls of ~24 ms sat inside a 190 ms measurement) */
+int havc_memory_read_reserve(havc_ctx* ctx, int N_max, int HW, int top_k);
 int havc_cmn_short_term(havc_ctx* ctx, havc_net* net, int first_op, int n_ops, int agg_buf, int short_buf, const float* q, const float* k, const float* v,
                         const float* rel_w, const float* rel_b, float* agg, float* attn, float* short_out, int C, int CV, int H, int W, int max_dis);
 int havc_cmn_join_add(havc_ctx* ctx, float* readout, const float* short_out, int64_t n);

@@ -148,11 +148,13 @@ SYMBOLS = [
     ("havc_cmn_frame_in", _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     ("havc_cmn_frame_out", _I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I]),
     ("havc_memory_read_banked", _I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, C.c_int64, _I, _I]),
+    ("havc_memory_read_reserve", _I, [_P, _I, _I, _I]),
     ("havc_cmn_short_term", _I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I]),
     ("havc_cmn_join_add", _I, [_P, _P, _P, C.c_int64]),
     ("havc_cmn_side_mark", _I, [_P]),
     ("havc_cmn_side_begin", _I, [_P]),
     ("havc_ctx_set_stream_priority", _I, [_P, _I]),
+    ("havc_ctx_set_stream_cus", _I, [_P, _I]),
     ("havc_cmn_side_end", _I, [_P]),
     ("havc_cmn_side_wait", _I, [_P, _I]),
     ("havc_cmn_value_in", _I, [_P, _P, _P, _P, C.c_int64]),

@@ -74,6 +74,7 @@ class BankedStore:
         self.n = 0
         self.objects = None
         self.version = 0
+        self.on_grow = None                                    # called after the banks' capacity changed (the manager re-reserves the read's scratch)
 
     # ---- region ----
     def _range(self):
@@ -128,6 +129,8 @@ class BankedStore:
         if self.kind == "work":
             if self.n + n > b.cap_work:
                 b.grow_work(self.n + n)
+                if self.on_grow is not None:
+                    self.on_grow()
             col = b.cap_long + self.n
         else:
             if self.n + n > b.cap_long:
@@ -231,8 +234,16 @@ class FastMemoryManager(MemoryManager):
             cap_long, cap_work = 0, 16 * hw
         self._banks = Banks(key.device, CK, objs, CV, cap_long, cap_work, has_selection=self.enable_long_term)
         self.work_mem = BankedStore(self._banks, self.ctx, "work", count_usage=self.enable_long_term)
+        self.work_mem.on_grow = self._reserve_read
         if self.enable_long_term:
             self.long_mem = BankedStore(self._banks, self.ctx, "long", count_usage=self.enable_long_term_usage)
+        self._hw = hw
+        self._reserve_read()
+
+    def _reserve_read(self):
+        """the read's scratch (similarity map, top-k lists, usage accumulators) sized for the banks' capacity NOW: growing it with the memory costs a
+        device synchronisation per regrowth, in the middle of a clip"""
+        nat.check(self.ctx.lib.havc_memory_read_reserve(self.ctx.h, int(self._banks.cap), int(self._hw), int(self.top_k)), self.ctx.h)
 
     def add_memory(self, key, shrinkage, value, objects, selection=None):
         if self._banks is None:

@@ -608,11 +608,17 @@ class ColorMNetNetwork:
         if self._helper is None:
             from .render import get_context
             hctx = get_context(self.ctx.device_id, ("lookahead", self.worker))
-            if os.environ.get("HAVC_CMN_LOOKAHEAD_PRIORITY", "low") == "low" and not getattr(hctx, "_low_priority", False):
-                # the batched pass fills whatever CUs the memory step's small dependent launches leave idle: at the lowest stream priority the
-                # dispatcher serves the memory step's queue first whenever both have a block ready (before any stream handle of hctx is handed out)
+            if os.environ.get("HAVC_CMN_LOOKAHEAD_PRIORITY", "0") == "low" and not getattr(hctx, "_low_priority", False):
+                # A/B switch, OFF: the look-ahead streams at the lowest stream priority.  The dispatcher then serves the memory step's queue first
+                # whenever both have a block ready -- and the batched pass, which the NEXT window cannot start without, starves: c5 1 031 -> 612
+                # frames/s (tools/sessions/r5_run14.sh).  (Before any stream handle of hctx is handed out.)
                 nat.check(hctx.lib.havc_ctx_set_stream_priority(hctx.h, -1), hctx.h)
                 hctx._low_priority = True
+            cus = int(os.environ.get("HAVC_CMN_LOOKAHEAD_CUS", "0"))
+            if cus > 0 and not getattr(hctx, "_cu_masked", False):
+                # the batched pass on `cus` of the 256 CUs: the rest stay free for the memory step's small dependent launches
+                nat.check(hctx.lib.havc_ctx_set_stream_cus(hctx.h, cus), hctx.h)
+                hctx._cu_masked = True
             self._helper = ColorMNetNetwork(None, device_index=self.ctx.device_id, autotune=self.autotune, worker=("lookahead", self.worker), share=self)
         return self._helper
 

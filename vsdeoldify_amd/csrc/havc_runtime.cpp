@@ -2425,6 +2425,48 @@ int havc_memory_read_banked(havc_ctx* c, const float* mk, const float* ms, const
     return HAVC_OK;
 }
 
+int havc_ctx_set_stream_cus(havc_ctx* c, int n_cus) {
+    if (!c || n_cus < 1) return fail(c, HAVC_E_INVALID, "set_stream_cus: n_cus >= 1");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->side) return fail(c, HAVC_E_INVALID, "set_stream_cus: inside a side section");
+    HIP_TRY(c, hipSetDevice(c->dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(c, hipGetDeviceProperties(&prop, c->dev));
+    const int total = prop.multiProcessorCount;
+    if (n_cus > total) n_cus = total;
+    // bit i of the mask = CU i in the driver's enumeration, which deals consecutive bits round-robin over the XCDs: the first n bits are n / 8 CUs of every XCD
+    std::vector<uint32_t> mask((total + 31) / 32, 0u);
+    for (int i = 0; i < n_cus; ++i) mask[i >> 5] |= 1u << (i & 31);
+    HIP_TRY(c, sync_streams(c));
+    hipStream_t a = nullptr, b = nullptr;
+    if (hipExtStreamCreateWithCUMask(&a, (uint32_t)mask.size(), mask.data()) != hipSuccess ||
+        hipExtStreamCreateWithCUMask(&b, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        if (a) (void)hipStreamDestroy(a);
+        return fail(c, HAVC_E_HIP, "set_stream_cus: hipExtStreamCreateWithCUMask failed");
+    }
+    (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->stream2);
+    c->stream = a;
+    c->stream2 = b;
+    return HAVC_OK;
+}
+
+int havc_memory_read_reserve(havc_ctx* c, int N_max, int HW, int top_k) {
+    if (!c || N_max < 1 || HW < 1 || top_k < 1 || top_k > 64) return fail(c, HAVC_E_INVALID, "memory_read_reserve: bad args");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIP_TRY(c, hipSetDevice(c->dev));
+    // the largest request havc_memory_read_banked can make for N <= N_max: the candidate lists of the two-level selection peak at the largest slice count
+    size_t splits = 1;
+    for (int n = 64; n <= N_max + 63; n += 64) splits = std::max(splits, (size_t)mem_topk_splits(std::min(n, N_max)));
+    const size_t lst = (size_t)top_k * HW, cand = lst * (splits > 1 ? splits : 0);
+    int rc;
+    if ((rc = ensure_scratch(c, 8, (size_t)N_max * HW * 4)) || (rc = ensure_scratch(c, 9, (lst + cand) * 4)) || (rc = ensure_scratch(c, 10, (lst + cand) * 4)) ||
+        (rc = ensure_scratch(c, 11, (size_t)N_max * 8)))
+        return rc;
+    return HAVC_OK;
+}
+
 int havc_cmn_short_term(havc_ctx* c, havc_net* net, int first_op, int n_ops, int agg_buf, int short_buf, const float* q, const float* k, const float* v,
                         const float* rel_w, const float* rel_b, float* agg, float* attn, float* short_out, int C, int CV, int H, int W, int max_dis) {
     if (!c || !net || net->ctx != c || !q || !k || !v || !rel_w || !rel_b || !agg || !attn || !short_out || C < 1 || CV < 1 || H < 1 || W < 1 || max_dis < 0 ||
