@@ -1,0 +1,26 @@
+"""CPU experiment (round 5): is a TWO-term precise conv enough?  See DESIGN.md section 3.  Weights rounded to fp16, activations fp32, through the whole configs[1] oracle pipeline."""
+import sys, time, numpy as np
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
+from oracle import imaging, pipeline
+from vsdeoldify_amd.synth import synth_state_dict
+from vsdeoldify_amd.clip import synthetic_gray_frame
+import torch
+torch.set_num_threads(8)
+def rounded(sd):
+    out = {}
+    for k, v in sd.items():
+        a = np.asarray(v)
+        if a.ndim == 4 and a.dtype == np.float32:       # conv weights
+            out[k] = a.astype(np.float16).astype(np.float32)
+        else:
+            out[k] = v
+    return out
+for sv, ss in ((11, 12), (1, 2)):
+    sds = {"video": synth_state_dict("wide", sv), "stable": synth_state_dict("wide", ss)}
+    sdr = {k: rounded(v) for k, v in sds.items()}
+    fr = synthetic_gray_frame(0, 1920, 1080)
+    t0 = time.time()
+    ref = pipeline.colorize_frame_fullsize(sds, "stable", fr, 35, 0.5)
+    got = pipeline.colorize_frame_fullsize(sdr, "stable", fr, 35, 0.5)
+    de = imaging.delta_e00_images(got, ref)
+    print(f"seeds {sv},{ss}: weights rounded to fp16, activations fp32: mean {de.mean():.4f} p99 {np.percentile(de,99):.3f} max {de.max():.2f} dE<1 {(de<1).mean():.5f}  ({time.time()-t0:.0f} s)", flush=True)
