@@ -86,6 +86,9 @@ class ColorMNetRender:
         # frames per batched key-encoder pass when the caller announces frames ahead (colorize_batch_frames / prefetch); 1 = off
         self.lookahead = int(os.environ.get("HAVC_CMN_LOOKAHEAD", "16")) if lookahead is None else int(lookahead)
         self._ahead = collections.deque()
+        # set by a caller that knows its frame list (colorize_batch_frames, DeepExColorMNet.colorize_frames) right before a colorize_frame call: the NEXT call
+        # is the next announced frame and brings no reference image -- the fast step may then start that frame's read early (colormnet_fast.hint_next)
+        self.next_is_plain = False
         self.device_index, self._memory_backend = device_index, memory_backend          # memory_backend: CPU tests of the state machine only
         self.network = network if network is not None else _load_network(self.project_dir, state_dict, device_index)
         self.config = default_config(vid_length, self.max_memory_frames, propagate)
