@@ -113,6 +113,10 @@ enum havc_op_type {
                                 src -> NHWC fp16 dst view (Co = stored channels, zeros above Ci)                                         */
     HAVC_OP_PLANAR_OUT = 27, /* NHWC fp16 src view, Ci channels -> fp32 planar [Ci][Hi*Wi] per frame in buffer dst; kh = activation: 0 none,
                                 1 x^2 + 1, 2 sigmoid (KeyProjection, modules.py:226-229), 3 tanh (network.py:141)                        */
+    HAVC_OP_CMN_DECODER_IN = 28, /* the input of ColorMNet's Decoder (modules.py:177-205: cat of the 1/16 image features, the memory readout and the hidden
+                                state, per object) in ONE launch: src = fp16 view of the image features (Ci channels, ONE frame, broadcast to every
+                                object), src2 = fp32 planar readout [kh][Hi*Wi] per object, aux0 = fp32 planar hidden [kw][Hi*Wi] per object ->
+                                dst view channels [0, Ci + kh + kw) and the same rectified into buffer aux1 (same offset and pitch)       */
     HAVC_OP_DWCONV7_LN = 17,    /* DWCONV7 followed by LAYERNORM of its result, one kernel (ConvNeXt block head): fields of both
                                 ops (w_off / bias_off / Kc; scale_off gamma, shift_off beta, f0 eps); Ci = 64, 192, 384, 768 or 1536.
                                 The norm reads the fp32 conv result (the two-op form rounds it to fp16 in between)      */

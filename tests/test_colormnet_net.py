@@ -427,6 +427,32 @@ def test_cbam_gru_planar_ops(ctx):
         assert np.abs(out[outs[act]] - fn(h5)).max() < 1e-5, act
 
 
+@pytest.mark.gpu
+def test_decoder_input_op(ctx):
+    """HAVC_OP_CMN_DECODER_IN (round 5): [g16 of the frame for every object | readout | hidden] and its rectified twin in one launch -- exact
+    (fp16 copies and fp32 -> fp16 roundings), including the bytes around the written channel range"""
+    from vsdeoldify_amd.plan import PlanBuilder, WeightPack, View, pitch_for
+    B, H, W, Cg, CV, HD = 2, 5, 7, 32, 24, 8
+    P = H * W
+    g = _f16(_rand(1, Cg, H, W, seed=31))
+    ro, hid = _rand(B, CV, H, W, seed=32, scale=2.0), _rand(B, HD, H, W, seed=33)
+    pack, b = WeightPack(), PlanBuilder()
+    pack.add(np.zeros(8, np.float32))
+    gv = b.tensor(H, W, Cg)
+    span = Cg + CV + HD
+    pitch = pitch_for(span + 8)
+    dc_buf, dcr_buf = b.buf(P * pitch, 2, zero_init=True), b.buf(P * pitch, 2, zero_init=True)
+    rb, hb = b.buf(CV * P, 4), b.buf(HD * P, 4)
+    b.cmn_decoder_in("dec_in", gv, rb, CV, hb, HD, View(dc_buf, 0, pitch, H, W, span, span), dcr_buf)
+    gin = np.concatenate([nhwc_pad(g, gv.cpitch)] * B, 0)                       # (the op reads frame 0 only)
+    gin[1:] = 77
+    out = run_plan(ctx, pack, b, {gv.buf: gin, rb: ro, hb: hid}, {dc_buf: ((B, H, W, pitch), np.float16), dcr_buf: ((B, H, W, pitch), np.float16)}, B)
+    want = np.concatenate([np.broadcast_to(g, (B, Cg, H, W)), _f16(ro), _f16(hid)], 1).transpose(0, 2, 3, 1).astype(np.float16)
+    assert np.array_equal(out[dc_buf][..., :span], want)
+    assert np.array_equal(out[dcr_buf][..., :span], np.maximum(want, np.float16(0)))
+    assert (out[dc_buf][..., span:] == 0).all() and (out[dcr_buf][..., span:] == 0).all()
+
+
 # =====================================================================================================================================
 # GPU: the network and the frame wrapper
 # =====================================================================================================================================

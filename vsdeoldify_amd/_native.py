@@ -19,7 +19,7 @@ OP_CONV, OP_MAXPOOL, OP_BLUR_RESIZE, OP_AFFINE, OP_ATTENTION, OP_PREP_RGB8, OP_C
 OP_SUBSAMPLE2, OP_PROJ2, OP_BILINEAR2, OP_PREP_LAB_L = 8, 9, 10, 11
 OP_DWCONV7, OP_LAYERNORM, OP_MHA, OP_PIXSHUF4_BLUR, OP_PREP_DDCOLOR, OP_DWCONV7_LN = 12, 13, 14, 15, 16, 17
 OP_FOLD_QUERIES, OP_SHUF4_BLUR_AB = 18, 19
-OP_EW, OP_DWCONV, OP_CHAN_ATTN, OP_MHA64, OP_CBAM, OP_GRU, OP_PLANAR_IN, OP_PLANAR_OUT = 20, 21, 22, 23, 24, 25, 26, 27
+OP_EW, OP_DWCONV, OP_CHAN_ATTN, OP_MHA64, OP_CBAM, OP_GRU, OP_PLANAR_IN, OP_PLANAR_OUT, OP_CMN_DECODER_IN = 20, 21, 22, 23, 24, 25, 26, 27, 28
 EW_SRC_BCAST, EW_RES, EW_RES_BCAST, EW_RELU, EW_DUAL = 1, 2, 4, 8, 16
 F_RELU_PRE, F_AFFINE, F_RESIDUAL, F_RELU_POST = 0x1, 0x2, 0x4, 0x8
 F_OUT_PIXSHUF, F_OUT_TRANSPOSED, F_OUT_RGB8, F_LEAKY, F_FUSE_RGB8, F_PS_BLUR = 0x10, 0x20, 0x40, 0x80, 0x100, 0x200

@@ -402,12 +402,9 @@ class ColorMNetPlan:
         dc_buf, dcr_buf = b.buf(P16 * dc_pitch, 2), b.buf(P16 * dc_pitch, 2)
         dc = View(dc_buf, 0, dc_pitch, h16, w16, dc_span, dc_span)
         dcr = View(dcr_buf, 0, dc_pitch, h16, w16, dc_span, dc_span)
-        b.ew(d + ".distribute", g16, View(dc_buf, 0, dc_pitch, h16, w16, 1024, 1024), src_bcast=True,
-             dual=View(dcr_buf, 0, dc_pitch, h16, w16, 1024, 1024))
-        rh = View(dc_buf, 1024, dc_pitch, h16, w16, CV + HD, CV + HD)
-        b.planar_in(d + ".readout_in", fbuf("readout", CV * P16), CV, View(dc_buf, 1024, dc_pitch, h16, w16, CV, CV))
-        b.planar_in(d + ".hidden_in", io["hidden"], HD, View(dc_buf, 1024 + CV, dc_pitch, h16, w16, HD, HD))
-        b.ew(d + ".relu_in", rh, View(dcr_buf, 1024, dc_pitch, h16, w16, CV + HD, CV + HD), relu=True)
+        # g16 of the frame for both objects, the readout and the hidden state (fp32 planar -> NHWC fp16), each also rectified (the fuser's first
+        # ResBlock reads relu(x), its shortcut x): ONE launch (round 5; four before: distribute, readout_in, hidden_in, relu_in)
+        b.cmn_decoder_in(d + ".input", g16, fbuf("readout", CV * P16), CV, io["hidden"], HD, dc, dcr_buf)
         G16 = self._fusion(b, d + ".fuser", dc, dcr, b.tensor(h16, w16, 512))
         u8, u8r = b.tensor(h8, w8, 512), b.tensor(h8, w8, 512)
         b.ew(d + ".up_16_8.up+skip", G16, u8, mode=1, ratio=(0.5, 0.5), res=skip8, res_bcast=True, dual=u8r)

@@ -422,9 +422,14 @@ __global__ void mem_usage_final_kernel(const unsigned long long* __restrict__ ac
     if (i < total) usage[i] = (float)((double)acc[i] * (1.0 / 1099511627776.0));
 }
 // KeyValueMemoryStore.update_usage in place (kv_memory_store.py:93-101): use_count += usage, life_count += 1, for the elements [from, N)
-__global__ void mem_usage_update_kernel(const unsigned long long* __restrict__ acc, float* __restrict__ use, float* __restrict__ life, int from, int N) {
-    const int i = from + blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) { use[i] = use[i] + (float)((double)acc[i] * (1.0 / 1099511627776.0)); life[i] = life[i] + 1.f; }
+// ... and the accumulators go back to zero for the next read (round 5: the launcher no longer clears them with a memset in front of every read; the
+// caller guarantees zeros before the FIRST use of a buffer, havc_runtime.cpp usage_update_locked)
+__global__ void mem_usage_update_kernel(unsigned long long* __restrict__ acc, float* __restrict__ use, float* __restrict__ life, int from, int N) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const unsigned long long a = acc[i];
+    acc[i] = 0ull;
+    if (i >= from) { use[i] = use[i] + (float)((double)a * (1.0 / 1099511627776.0)); life[i] = life[i] + 1.f; }
 }
 // encode_value's input (network.py:87-101 as colormnet_net.encode_value assembles it): per object i the image (3 planes), its own ab plane and the
 // other object's: vin[i] = [img0, img1, img2, m_i, m_(1-i)]
@@ -439,11 +444,10 @@ __global__ void vec_add_kernel(float* __restrict__ y, const float* __restrict__ 
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) y[i] = y[i] + x[i];
 }
 }  // namespace
+// acc [N] must be all zero on entry and is all zero again on exit
 int launch_mem_usage_update(const int* idx, const float* wgt, unsigned long long* acc, float* use, float* life, int from, int N, int HW, int K, hipStream_t s) {
-    hipError_t e = hipMemsetAsync(acc, 0, (size_t)N * 8, s);
-    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(mem_usage_accum_kernel, dim3(cdiv((int64_t)K * HW, 256), 1), dim3(256), 0, s, idx, wgt, acc, N, HW, K);
-    if (N > from) hipLaunchKernelGGL(mem_usage_update_kernel, dim3(cdiv(N - from, 256)), dim3(256), 0, s, acc, use, life, from, N);
+    hipLaunchKernelGGL(mem_usage_update_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, acc, use, life, from, N);
     return (int)hipGetLastError();
 }
 int launch_cmn_value_in(const float* img, const float* planes, float* vin, int64_t P, hipStream_t s) {

@@ -470,25 +470,53 @@ __global__ void __launch_bounds__(512) cbam_pool_kernel(const half_t* __restrict
     }
 }
 
-// (2) the shared MLP on both pooled vectors, sigmoid -> scale[C]: one block per frame, one wave per hidden unit (coalesced rows of w1)
+// (2) the shared MLP on both pooled vectors, sigmoid -> scale[C]: one block per frame.  Round 5: every load of a phase is independent of the others (the
+// 20 us this kernel took on a 450 us decoder chain were two chains of dependent loads): phase 1, thread (hidden unit kk, 64-channel chunk j) reads its 64
+// weights of w1 as 16 float4 and forms the partial dots with BOTH pooled vectors (one pass over w1); the 8 chunk partials are added in a fixed order;
+// phase 2, thread c reads its Ch weights of w2 as float4.  C <= 4096, C % 64 == 0 (launch_cbam checks C % 16; a chunk tail is handled), Ch = C / 16.
 __global__ void __launch_bounds__(512) cbam_mlp_kernel(int C, int Ch, const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
                                                        const float* __restrict__ b2, float* __restrict__ gate, int64_t gfs) {
-    extern __shared__ float hid[];                                // [2 * Ch]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    extern __shared__ float sm[];                                 // [2 * Ch] hidden | [2 * Ch * NCH] partials
+    const int b = blockIdx.x, tid = threadIdx.x;
     float* g = gate + (int64_t)b * gfs;
-    for (int t = wave; t < 2 * Ch; t += 8) {
-        const int kk = t % Ch;
-        const float* v = g + (t < Ch ? C : 2 * C);
+    const float* va = g + C;
+    const float* vm = g + 2 * C;
+    const int NCH = blockDim.x / Ch > 0 ? (blockDim.x / Ch > 16 ? 16 : blockDim.x / Ch) : 1;       // chunks per hidden unit (Ch = 32, 512 threads: 16)
+    const int clen = ((C + NCH - 1) / NCH + 3) & ~3;              // channels per chunk, a multiple of 4
+    float* hid = sm;
+    float* part = sm + 2 * Ch;
+    for (int t = tid; t < Ch * NCH; t += blockDim.x) {
+        const int kk = t / NCH, j = t - kk * NCH;
+        const int c0 = j * clen, c1 = min(C, c0 + clen);
+        float aa = 0.f, am = 0.f;
+        for (int c = c0; c < c1; c += 4) {                        // C % 16 == 0 and clen % 4 == 0: whole float4s
+            const float4 w = *reinterpret_cast<const float4*>(w1 + (int64_t)kk * C + c);
+            const float4 xa = *reinterpret_cast<const float4*>(va + c), xm = *reinterpret_cast<const float4*>(vm + c);
+            aa += w.x * xa.x + w.y * xa.y + w.z * xa.z + w.w * xa.w;
+            am += w.x * xm.x + w.y * xm.y + w.z * xm.z + w.w * xm.w;
+        }
+        part[(kk * NCH + j) * 2] = aa;
+        part[(kk * NCH + j) * 2 + 1] = am;
+    }
+    __syncthreads();
+    for (int t = tid; t < 2 * Ch; t += blockDim.x) {
+        const int kk = t % Ch, which = t / Ch;
         float acc = 0.f;
-        for (int c = lane; c < C; c += 64) acc += w1[kk * C + c] * v[c];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) hid[t] = fmaxf(acc + b1[kk], 0.f);
+        for (int j = 0; j < NCH; ++j) acc += part[(kk * NCH + j) * 2 + which];
+        hid[t] = fmaxf(acc + b1[kk], 0.f);
     }
     __syncthreads();
     for (int c = tid; c < C; c += blockDim.x) {
         float acc = 2.f * b2[c];
-        for (int kk = 0; kk < Ch; ++kk) acc += w2[c * Ch + kk] * (hid[kk] + hid[Ch + kk]);
+        if ((Ch & 3) == 0) {
+            for (int kk = 0; kk < Ch; kk += 4) {
+                const float4 w = *reinterpret_cast<const float4*>(w2 + (int64_t)c * Ch + kk);
+                acc += w.x * (hid[kk] + hid[Ch + kk]) + w.y * (hid[kk + 1] + hid[Ch + kk + 1]) + w.z * (hid[kk + 2] + hid[Ch + kk + 2]) +
+                       w.w * (hid[kk + 3] + hid[Ch + kk + 3]);
+            }
+        } else {
+            for (int kk = 0; kk < Ch; ++kk) acc += w2[(int64_t)c * Ch + kk] * (hid[kk] + hid[Ch + kk]);
+        }
         g[c] = 1.f / (1.f + __expf(-acc));
     }
 }
@@ -552,7 +580,7 @@ int launch_cbam(const half_t* x, int cp, int co, int64_t fs, int B, int H, int W
     hipLaunchKernelGGL(cbam_pool_kernel, dim3((C + 63) / 64, B), dim3(512), 0, s, x, cp, co, fs, P, C, scale, gfs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(512), 2 * Ch * sizeof(float), s, C, Ch, w1, b1, w2, b2, scale, gfs);
+    hipLaunchKernelGGL(cbam_mlp_kernel, dim3(B), dim3(512), (2 * Ch + 2 * Ch * 16) * sizeof(float), s, C, Ch, w1, b1, w2, b2, scale, gfs);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(cbam_spatial_pool_kernel, dim3(grid_for((int64_t)B * P, 4)), dim3(256), 0, s, x, cp, co, fs, B, P, C, scale, gfs, comp);
@@ -606,6 +634,43 @@ int launch_planar_in(const float* x, int64_t x_fs, half_t* y, int cp, int co, in
                      hipStream_t s) {
     hipLaunchKernelGGL(planar_in_kernel, dim3(grid_for((int64_t)B * (span / 8) * P)), dim3(256), 0, s, x, x_fs, y, cp, co, fs, B, P, C, span / 8, pixel_major,
                        bcast);
+    return (int)hipGetLastError();
+}
+
+// The Decoder's input in one launch (modules.py:177-205): per object b and pixel p the channel row [g16 (Cg, the FRAME's features: the same for every
+// object) | readout (CV, fp32 planar per object) | hidden (HD, fp32 planar per object)] -> y, and relu of it -> y2 (same offset and pitch).
+__global__ void cmn_decoder_in_kernel(const half_t* __restrict__ g, int g_cp, int g_co, const float* __restrict__ ro, int64_t ro_fs, const float* __restrict__ hid,
+                                      int64_t hid_fs, half_t* __restrict__ y, half_t* __restrict__ y2, int cp, int co, int64_t fs, int B, int P, int Cg, int CV,
+                                      int HD) {
+    const int C8 = (Cg + CV + HD) / 8;
+    const int64_t total = (int64_t)B * C8 * P;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % C8);                                // channel groups fastest: a wave reads / writes 1 KiB of a pixel row at a time
+        const int p = (int)((i / C8) % P), b = (int)(i / ((int64_t)P * C8));
+        const int c = c8 * 8;
+        half8 o;
+        if (c < Cg) {
+            o = *reinterpret_cast<const half8*>(g + (int64_t)p * g_cp + g_co + c);
+        } else {
+            const bool r = c < Cg + CV;
+            const float* x = r ? ro + (int64_t)b * ro_fs + (int64_t)(c - Cg) * P + p : hid + (int64_t)b * hid_fs + (int64_t)(c - Cg - CV) * P + p;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (half_t)x[(int64_t)e * P];
+        }
+        half8 o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o2[e] = o[e] > (half_t)0.f ? o[e] : (half_t)0.f;
+        const int64_t off = (int64_t)b * fs + (int64_t)p * cp + co + c;
+        *reinterpret_cast<half8*>(y + off) = o;
+        *reinterpret_cast<half8*>(y2 + off) = o2;
+    }
+}
+
+int launch_cmn_decoder_in(const half_t* g, int g_cp, int g_co, const float* ro, int64_t ro_fs, const float* hid, int64_t hid_fs, half_t* y, half_t* y2, int cp,
+                          int co, int64_t fs, int B, int P, int Cg, int CV, int HD, hipStream_t s) {
+    if ((Cg & 7) || (CV & 7) || (HD & 7) || (g_cp & 7) || (g_co & 7) || (cp & 7) || (co & 7)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(cmn_decoder_in_kernel, dim3(grid_for((int64_t)B * ((Cg + CV + HD) / 8) * P)), dim3(256), 0, s, g, g_cp, g_co, ro, ro_fs, hid, hid_fs, y, y2,
+                       cp, co, fs, B, P, Cg, CV, HD);
     return (int)hipGetLastError();
 }
 

@@ -66,6 +66,7 @@ struct havc_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_main_done = nullptr, ev_side = nullptr, ev_mark = nullptr;
     bool marked = false;                  // havc_cmn_side_mark recorded ev_mark: the next side section starts behind THAT point of the main stream
     bool side = false;                    // between havc_cmn_side_begin / _end: the ColorMNet read (short-term attention, memory read, join) is enqueued on stream2
+    size_t acc_clean_sz = 0;              // scratch 11 (usage accumulators of the banked read) holds zeros over this many bytes (0: unknown -> cleared before use)
     struct { float* use = nullptr; float* life = nullptr; int from = 0, N = 0, HW = 0, top_k = 0; } side_usage;   // its usage update, owed until havc_cmn_side_wait
     hipStream_t cur = nullptr;            // stream the plan executor launches on (stream or stream2)
     bool two_streams = true;              // HAVC_TWO_STREAMS=0 serialises the two generators (A/B measurements)
@@ -746,6 +747,16 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             if (n->bufdesc[op.src].elem_bytes != 4 || (op.Co & 7) || op.Ci > op.Co) return fail(c, HAVC_E_INVALID, "planar-in op: fp32 source, Ci <= Co, Co % 8 == 0");
             e = launch_planar_in((const float*)bufptr(n, op.src), n->bufdesc[op.src].elems_per_frame, (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
                                  n->bufdesc[op.dst].elems_per_frame, batch, op.Hi * op.Wi, op.Ci, op.Co, op.flags & 1, (op.flags & 2) ? 1 : 0, s);
+            break;
+        case HAVC_OP_CMN_DECODER_IN:
+            if (op.src2 < 0 || op.src2 >= (int)n->bufs.size() || op.aux0 < 0 || op.aux0 >= (int)n->bufs.size() || op.aux1 < 0 || op.aux1 >= (int)n->bufs.size() ||
+                n->bufdesc[op.src2].elem_bytes != 4 || n->bufdesc[op.aux0].elem_bytes != 4 || n->bufdesc[op.src].elem_bytes != 2 ||
+                n->bufdesc[op.aux1].elem_bytes != 2 || n->bufdesc[op.aux1].elems_per_frame != n->bufdesc[op.dst].elems_per_frame || op.kh < 8 || op.kw < 8 ||
+                op.Co != op.Ci + op.kh + op.kw || op.dst_coff + op.Co > op.dst_cpitch)
+                return fail(c, HAVC_E_INVALID, "decoder-in op: fp16 features, fp32 planar readout (kh channels) and hidden (kw), twin destination buffers, Co = Ci + kh + kw");
+            e = launch_cmn_decoder_in((const half_t*)bufptr(n, op.src), op.src_cpitch, op.src_coff, (const float*)bufptr(n, op.src2), n->bufdesc[op.src2].elems_per_frame,
+                                      (const float*)bufptr(n, op.aux0), n->bufdesc[op.aux0].elems_per_frame, (half_t*)bufptr(n, op.dst), (half_t*)bufptr(n, op.aux1),
+                                      op.dst_cpitch, op.dst_coff, n->bufdesc[op.dst].elems_per_frame, batch, op.Hi * op.Wi, op.Ci, op.kh, op.kw, s);
             break;
         case HAVC_OP_PLANAR_OUT:
             if (n->bufdesc[op.dst].elem_bytes != 4 || op.kh < 0 || op.kh > 3) return fail(c, HAVC_E_INVALID, "planar-out op: fp32 destination, activation 0..3");
@@ -2224,6 +2235,7 @@ int havc_memory_read_topk_usage(havc_ctx* c, const float* mk, const float* ms, c
         if ((rc = ensure_scratch(c, 11, (size_t)B * N * 8)) || (rc = stage_out_ptr(c, 6, usage, (size_t)B * N * 4, &d_us, &uhost))) return rc;
         e = launch_mem_usage((const int*)c->scratch[9], (const float*)c->scratch[10], (unsigned long long*)c->scratch[11], (float*)d_us, B, N, HW, top_k,
                              c->stream);
+        c->acc_clean_sz = 0;                                   // (the accumulators keep this read's sums: the banked read clears them before its next use)
         c->stats.launches += 2;
         if (e) return hip_fail(c, (hipError_t)e, "memory_read_topk (usage)");
         if ((rc = stage_out(c, usage, d_us, (size_t)B * N * 4, uhost))) return rc;
@@ -2386,6 +2398,19 @@ int havc_cmn_frame_out(havc_ctx* c, const float* l_plane, const float* ab_padded
     return stage_out(c, rgb, d_out, nb, host);
 }
 
+// use_count += usage, life_count += 1 from the top-k lists in scratch 9 / 10.  The accumulators (scratch 11) are kept at zero BETWEEN reads by the update kernel
+// itself; they are cleared here only when the buffer is new (re-grown) or another entry point (havc_memory_read_topk_usage) has used it.
+static int usage_update_locked(havc_ctx* c, float* use, float* life, int from, int N, int HW, int top_k, hipStream_t st) {
+    if (c->acc_clean_sz != c->scratch_sz[11] || !c->acc_clean_sz) {
+        hipError_t m = hipMemsetAsync(c->scratch[11], 0, c->scratch_sz[11], st);
+        if (m != hipSuccess) return (int)m;
+        c->acc_clean_sz = c->scratch_sz[11];
+        c->stats.launches += 1;
+    }
+    c->stats.launches += 2;
+    return launch_mem_usage_update((const int*)c->scratch[9], (const float*)c->scratch[10], (unsigned long long*)c->scratch[11], use, life, from, N, HW, top_k, st);
+}
+
 int havc_memory_read_banked(havc_ctx* c, const float* mk, const float* ms, const float* qk, const float* qe, const float* mv, float* out, float* use_count,
                             float* life_count, int usage_from, int CK, int CV, int N, int64_t pitch, int HW, int top_k) {
     if (!c || !mk || !qk || !mv || !out || CK < 1 || CV < 1 || N < 1 || HW < 1 || pitch < N || top_k < 1 || top_k > 64 || usage_from < 0 ||
@@ -2416,9 +2441,7 @@ int havc_memory_read_banked(havc_ctx* c, const float* mk, const float* ms, const
             c->side_usage.use = use_count; c->side_usage.life = life_count; c->side_usage.from = usage_from;
             c->side_usage.N = N; c->side_usage.HW = HW; c->side_usage.top_k = top_k;
         } else {
-            e = launch_mem_usage_update((const int*)c->scratch[9], (const float*)c->scratch[10], (unsigned long long*)c->scratch[11], use_count, life_count,
-                                        usage_from, N, HW, top_k, st);
-            c->stats.launches += 2;
+            e = usage_update_locked(c, use_count, life_count, usage_from, N, HW, top_k, st);
         }
     }
     if (e) return hip_fail(c, (hipError_t)e, "memory_read_banked");
@@ -2574,9 +2597,7 @@ int havc_cmn_side_wait(havc_ctx* c, int apply_usage) {
     auto u = c->side_usage;
     c->side_usage = {};
     if (apply_usage && u.use) {
-        int e = launch_mem_usage_update((const int*)c->scratch[9], (const float*)c->scratch[10], (unsigned long long*)c->scratch[11], u.use, u.life, u.from,
-                                        u.N, u.HW, u.top_k, c->stream);
-        c->stats.launches += 2;
+        int e = usage_update_locked(c, u.use, u.life, u.from, u.N, u.HW, u.top_k, c->stream);
         if (e) return hip_fail(c, (hipError_t)e, "cmn_side_wait: usage update");
     }
     return HAVC_OK;

@@ -247,6 +247,8 @@ int launch_cbam(const half_t* x, int cp, int co, int64_t fs, int B, int H, int W
                 const float* w7, const float* b7, float* scale, float* comp, half_t* y, int y_cp, int y_co, int64_t y_fs, half_t* y2, int y2_cp, int y2_co,
                 int64_t y2_fs, hipStream_t s);
 int launch_gru(const half_t* v, int cp, int co, int64_t fs, const float* h, float* out, int B, int P, int hd, hipStream_t s);
+int launch_cmn_decoder_in(const half_t* g, int g_cp, int g_co, const float* ro, int64_t ro_fs, const float* hid, int64_t hid_fs, half_t* y, half_t* y2, int cp,
+                          int co, int64_t fs, int B, int P, int Cg, int CV, int HD, hipStream_t s);
 int launch_planar_in(const float* x, int64_t x_fs, half_t* y, int cp, int co, int64_t fs, int B, int P, int C, int span, int pixel_major, int bcast,
                      hipStream_t s);
 int launch_planar_out(const half_t* x, int cp, int co, int64_t fs, float* y, int64_t y_fs, int B, int P, int C, int act, hipStream_t s);

@@ -476,6 +476,12 @@ class PlanBuilder:
         return self._op(name, type=nat.OP_PLANAR_IN, flags=(1 if pixel_major else 0) | (2 if bcast else 0), src=src_buf, dst=y.buf, dst_coff=y.coff,
                         dst_cpitch=y.cpitch, Hi=y.H, Wi=y.W, Ci=C, Ho=y.H, Wo=y.W, Co=y.span)
 
+    def cmn_decoder_in(self, name, g16, readout_buf, CV, hidden_buf, HD, dc, dcr_buf):
+        """dc[:, 0:g16.span | +CV | +HD] = [g16 (one frame, every object) | readout | hidden], dcr = relu(dc): one launch (csrc/colormnet_net.hip)"""
+        assert g16.span % 8 == 0 and CV % 8 == 0 and HD % 8 == 0 and dc.span >= g16.span + CV + HD and g16.H == dc.H and g16.W == dc.W, name
+        return self._op(name, type=nat.OP_CMN_DECODER_IN, src=g16.buf, src_coff=g16.coff, src_cpitch=g16.cpitch, src2=readout_buf, aux0=hidden_buf, aux1=dcr_buf,
+                        dst=dc.buf, dst_coff=dc.coff, dst_cpitch=dc.cpitch, Hi=dc.H, Wi=dc.W, Ci=g16.span, Ho=dc.H, Wo=dc.W, Co=g16.span + CV + HD, kh=CV, kw=HD)
+
     def planar_out(self, name, x, coff, C, dst_buf, act=0):
         return self._op(name, type=nat.OP_PLANAR_OUT, src=x.buf, src_coff=x.coff + coff, src_cpitch=x.cpitch, dst=dst_buf, Hi=x.H, Wi=x.W, Ci=C,
                         Ho=x.H, Wo=x.W, Co=C, kh=act)
