@@ -832,7 +832,8 @@ def bench_c5(args, rank, local_rank, world, dist):
                       "algorithmic_gflop_per_frame": round(gflop_frame, 2), "mem_every": 5, "device_resident": True,
                       "working_memory_elements": int(mem.work_mem.size), "long_term_elements": int(mem.long_mem.size) if mem.long_mem.engaged() else 0,
                       "key_encoder_lookahead": rnd.lookahead, "read_ahead": bool(getattr(rnd.processor, "reads_ahead", 0)),
-                      "host_enqueue_share_of_wall": round(issued / elapsed, 3),
+                      "host_enqueue_share_of_wall": round(issued / elapsed, 3),      # (includes time BLOCKED in launch calls once the queues are full: ~0.92 on a
+                      #  GPU-bound run; tools/c5_host_profile.py shows where the host's own time goes)
                       "parallelism": f"memory step sequential in time (key encoder {rnd.lookahead} frames ahead, concurrently on a second stream): replicas only, one clip per GPU x{world}"},
            "whole_path_tflops": round(total * gflop_frame * 1e9 / elapsed / 1e12 / world, 2),
            "whole_path_frac": round(total * gflop_frame * 1e9 / elapsed / 1e12 / world / PEAK_F16_TFLOPS, 4),

@@ -682,6 +682,7 @@ def test_gpu_fast_step_long_clip_with_consolidation_and_lookahead():
     assert np.array_equal(a, b), (int(np.abs(a.astype(int) - b.astype(int)).max()), float((a != b).mean()))
     c, sc = run(True, 8)                                                      # + key look-ahead (split-K counts of the batched pass: fp32 summation order)
     d = np.abs(a.astype(int) - c.astype(int))
+    print(f"long clip: memory sizes fast {sa} plain {sb} look-ahead {sc}; look-ahead vs frame by frame: max |d| {int(d.max())}, within 2 LSB {float((d <= 2).mean()):.5f}")
     assert sc == sa and (d <= 2).mean() > 0.999, (sc, int(d.max()), float((d <= 2).mean()))
     # round 5: with the look-ahead the READ of frame t+1 runs under the decoder of frame t between memory frames (colormnet_fast.READ_AHEAD):
     # the same kernels on the same numbers, on another stream -- identical frames and memory sizes with it switched off

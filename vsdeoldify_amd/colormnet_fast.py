@@ -303,9 +303,12 @@ class FastInferenceCore(InferenceCore):
         self._next = entry
 
     def drop_read_ahead(self):
-        """forget a read enqueued ahead of its frame (the memory is being replaced): the main stream waits for it, its usage update never happens"""
+        """forget a read enqueued ahead of its frame (the memory is being replaced, or another processor is about to use the context's second
+        stream and read scratch): the main stream waits for it, its usage update never happens; the frame it was for is read again when it is stepped"""
         if getattr(self, "_ahead_read", None) is not None:
             nat.check(self.network.ctx.lib.havc_cmn_side_wait(self.network.ctx.h, 0), self.network.ctx.h)
+            if getattr(self.network, "_side_owner", None) is self:
+                self.network._side_owner = None
         self._ahead_read = self._next = None
 
     def _issue_read(self, B, key, selection, readout, with_short_term):
@@ -320,7 +323,12 @@ class FastInferenceCore(InferenceCore):
         net = self.network
         f = feats[0]
         B = net.fast_buffers(*f.shape)
+        owner = getattr(net, "_side_owner", None)
+        if owner is not None and owner is not self:            # two processors stepping alternately on one network: the other one's read-ahead holds the
+            owner.drop_read_ahead()                            # second stream and the read's scratch -- it is dropped (and redone by its owner), not raced
         ahead, self._ahead_read = getattr(self, "_ahead_read", None), None
+        if ahead is not None:
+            net._side_owner = None
         hit = ahead is not None and ahead[0] is key and with_short_term
         if ahead is not None:                                  # (a miss: the caller stepped another frame than the hinted one -- the read is dropped, its
             nat.check(net.ctx.lib.havc_cmn_side_wait(net.ctx.h, 1 if hit else 0), net.ctx.h)      #  usage update never happens)
@@ -351,6 +359,7 @@ class FastInferenceCore(InferenceCore):
             finally:
                 nat.check(net.ctx.lib.havc_cmn_side_end(net.ctx.h), net.ctx.h)
             self._ahead_read = (nxt[0], other)
+            net._side_owner = self
             self.reads_ahead = getattr(self, "reads_ahead", 0) + 1
         return B.prob                                          # [2, H, W] padded ab planes
 

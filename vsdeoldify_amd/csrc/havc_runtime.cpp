@@ -66,7 +66,7 @@ struct havc_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_main_done = nullptr, ev_side = nullptr, ev_mark = nullptr;
     bool marked = false;                  // havc_cmn_side_mark recorded ev_mark: the next side section starts behind THAT point of the main stream
     bool side = false;                    // between havc_cmn_side_begin / _end: the ColorMNet read (short-term attention, memory read, join) is enqueued on stream2
-    size_t acc_clean_sz = 0;              // scratch 11 (usage accumulators of the banked read) holds zeros over this many bytes (0: unknown -> cleared before use)
+    size_t acc_clean_sz = 0;              // scratch 17 (usage accumulators of the banked read) holds zeros over this many bytes (0: unknown -> cleared before use)
     struct { float* use = nullptr; float* life = nullptr; int from = 0, N = 0, HW = 0, top_k = 0; } side_usage;   // its usage update, owed until havc_cmn_side_wait
     hipStream_t cur = nullptr;            // stream the plan executor launches on (stream or stream2)
     bool two_streams = true;              // HAVC_TWO_STREAMS=0 serialises the two generators (A/B measurements)
@@ -79,8 +79,10 @@ struct havc_ctx {
     havc_stats stats{};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // grow-only scratch (u8 staging + float resample rows): allocated once, reused every call
-    void* scratch[14] = {nullptr};         // 0-3 staging / model i-o, 4-5 plane staging, 6 small, 7 resample rows, 8-11 pipelined host clip,
-    size_t scratch_sz[14] = {0};           // 12 / 13 split-K partial sums of the launches on stream / stream2
+    void* scratch[18] = {nullptr};         // 0-3 staging / model i-o, 4-5 plane staging, 6 small, 7 resample rows, 8-11 pipelined host clip (and the one-shot
+    size_t scratch_sz[18] = {0};           // memory reads), 12 / 13 split-K partial sums of the launches on stream / stream2, 14-17 the BANKED memory read of the
+                                           // ColorMNet frame loop (similarity map, top-k indices / weights, usage accumulators): its own slots, because a read that
+                                           // runs ahead leaves its top-k lists there until its frame is stepped -- no other entry point may touch them meanwhile
     int* sk_cnt[2] = {nullptr, nullptr};   // split-K arrival counters of the launches on stream / stream2 (HAVC_SK_COUNTERS ints each, all zero between launches)
     hipStream_t stream_h2d = nullptr, stream_d2h = nullptr;      // copy streams of havc_colorize_clip_host (created on first use)
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
@@ -1010,7 +1012,7 @@ static void havc_destroy_unlocked(havc_ctx* c) {
         (void)hipStreamDestroy(c->stream_h2d);
         (void)hipStreamDestroy(c->stream_d2h);
     }
-    for (int i = 0; i < 14; ++i)
+    for (int i = 0; i < 18; ++i)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
     for (int k = 0; k < 2; ++k)
         if (c->sk_cnt[k]) (void)hipFree(c->sk_cnt[k]);
@@ -2235,7 +2237,6 @@ int havc_memory_read_topk_usage(havc_ctx* c, const float* mk, const float* ms, c
         if ((rc = ensure_scratch(c, 11, (size_t)B * N * 8)) || (rc = stage_out_ptr(c, 6, usage, (size_t)B * N * 4, &d_us, &uhost))) return rc;
         e = launch_mem_usage((const int*)c->scratch[9], (const float*)c->scratch[10], (unsigned long long*)c->scratch[11], (float*)d_us, B, N, HW, top_k,
                              c->stream);
-        c->acc_clean_sz = 0;                                   // (the accumulators keep this read's sums: the banked read clears them before its next use)
         c->stats.launches += 2;
         if (e) return hip_fail(c, (hipError_t)e, "memory_read_topk (usage)");
         if ((rc = stage_out(c, usage, d_us, (size_t)B * N * 4, uhost))) return rc;
@@ -2398,17 +2399,17 @@ int havc_cmn_frame_out(havc_ctx* c, const float* l_plane, const float* ab_padded
     return stage_out(c, rgb, d_out, nb, host);
 }
 
-// use_count += usage, life_count += 1 from the top-k lists in scratch 9 / 10.  The accumulators (scratch 11) are kept at zero BETWEEN reads by the update kernel
-// itself; they are cleared here only when the buffer is new (re-grown) or another entry point (havc_memory_read_topk_usage) has used it.
+// use_count += usage, life_count += 1 from the top-k lists in scratch 15 / 16.  The accumulators (scratch 17) are kept at zero BETWEEN reads by the update kernel
+// itself; they are cleared here only when the buffer is new (first use, re-grown).  Slots 14 - 17 belong to the banked read alone.
 static int usage_update_locked(havc_ctx* c, float* use, float* life, int from, int N, int HW, int top_k, hipStream_t st) {
-    if (c->acc_clean_sz != c->scratch_sz[11] || !c->acc_clean_sz) {
-        hipError_t m = hipMemsetAsync(c->scratch[11], 0, c->scratch_sz[11], st);
+    if (c->acc_clean_sz != c->scratch_sz[17] || !c->acc_clean_sz) {
+        hipError_t m = hipMemsetAsync(c->scratch[17], 0, c->scratch_sz[17], st);
         if (m != hipSuccess) return (int)m;
-        c->acc_clean_sz = c->scratch_sz[11];
+        c->acc_clean_sz = c->scratch_sz[17];
         c->stats.launches += 1;
     }
     c->stats.launches += 2;
-    return launch_mem_usage_update((const int*)c->scratch[9], (const float*)c->scratch[10], (unsigned long long*)c->scratch[11], use, life, from, N, HW, top_k, st);
+    return launch_mem_usage_update((const int*)c->scratch[15], (const float*)c->scratch[16], (unsigned long long*)c->scratch[17], use, life, from, N, HW, top_k, st);
 }
 
 int havc_memory_read_banked(havc_ctx* c, const float* mk, const float* ms, const float* qk, const float* qe, const float* mv, float* out, float* use_count,
@@ -2420,24 +2421,24 @@ int havc_memory_read_banked(havc_ctx* c, const float* mk, const float* ms, const
     HIP_TRY(c, hipSetDevice(c->dev));
     int rc;
     const size_t lst = (size_t)top_k * HW, cand = lst * (mem_topk_splits(N) > 1 ? mem_topk_splits(N) : 0);
-    if ((rc = ensure_scratch(c, 8, (size_t)N * HW * 4)) || (rc = ensure_scratch(c, 9, (lst + cand) * 4)) || (rc = ensure_scratch(c, 10, (lst + cand) * 4))) return rc;
+    if ((rc = ensure_scratch(c, 14, (size_t)N * HW * 4)) || (rc = ensure_scratch(c, 15, (lst + cand) * 4)) || (rc = ensure_scratch(c, 16, (lst + cand) * 4))) return rc;
     const hipStream_t st = c->side ? c->stream2 : c->stream;       // a read-ahead (havc_cmn_side_begin) runs next to the previous frame's decoder
     static const bool wave_topk = [] { const char* e = getenv("HAVC_TOPK_WAVE"); return !e || atoi(e) != 0; }();
     int e;
     if (wave_topk && mem_topk_select_supported(N)) {
-        e = launch_mem_similarity_t(mk, ms, qk, qe, (float*)c->scratch[8], 1, CK, N, HW, st, pitch);
-        if (!e) e = launch_mem_topk_select_readout((const float*)c->scratch[8], mv, (int*)c->scratch[9], (float*)c->scratch[10], out, 1, CV, N, HW, top_k, st, pitch);
+        e = launch_mem_similarity_t(mk, ms, qk, qe, (float*)c->scratch[14], 1, CK, N, HW, st, pitch);
+        if (!e) e = launch_mem_topk_select_readout((const float*)c->scratch[14], mv, (int*)c->scratch[15], (float*)c->scratch[16], out, 1, CV, N, HW, top_k, st, pitch);
     } else {
-        e = launch_mem_similarity(mk, ms, qk, qe, (float*)c->scratch[8], 1, CK, N, HW, st, pitch);
-        if (!e) e = launch_mem_topk_readout((const float*)c->scratch[8], mv, (int*)c->scratch[9], (float*)c->scratch[10], (float*)c->scratch[10] + lst,
-                                            (int*)c->scratch[9] + lst, out, 1, CV, N, HW, top_k, st, pitch);
+        e = launch_mem_similarity(mk, ms, qk, qe, (float*)c->scratch[14], 1, CK, N, HW, st, pitch);
+        if (!e) e = launch_mem_topk_readout((const float*)c->scratch[14], mv, (int*)c->scratch[15], (float*)c->scratch[16], (float*)c->scratch[16] + lst,
+                                            (int*)c->scratch[15] + lst, out, 1, CV, N, HW, top_k, st, pitch);
     }
     c->stats.launches += 3;
     if (!e && use_count) {
-        if ((rc = ensure_scratch(c, 11, (size_t)N * 8))) return rc;
+        if ((rc = ensure_scratch(c, 17, (size_t)N * 8))) return rc;
         if (c->side) {
             // a read that runs ahead must not touch the counters before its frame is really stepped (a caller may leave the announced order): the
-            // top-k lists stay in scratch 9 / 10 until the next read, havc_cmn_side_wait(apply = 1) launches the update from them on the main stream
+            // top-k lists stay in scratch 15 / 16 until the next read, havc_cmn_side_wait(apply = 1) launches the update from them on the main stream
             c->side_usage.use = use_count; c->side_usage.life = life_count; c->side_usage.from = usage_from;
             c->side_usage.N = N; c->side_usage.HW = HW; c->side_usage.top_k = top_k;
         } else {
@@ -2484,8 +2485,8 @@ int havc_memory_read_reserve(havc_ctx* c, int N_max, int HW, int top_k) {
     for (int n = 64; n <= N_max + 63; n += 64) splits = std::max(splits, (size_t)mem_topk_splits(std::min(n, N_max)));
     const size_t lst = (size_t)top_k * HW, cand = lst * (splits > 1 ? splits : 0);
     int rc;
-    if ((rc = ensure_scratch(c, 8, (size_t)N_max * HW * 4)) || (rc = ensure_scratch(c, 9, (lst + cand) * 4)) || (rc = ensure_scratch(c, 10, (lst + cand) * 4)) ||
-        (rc = ensure_scratch(c, 11, (size_t)N_max * 8)))
+    if ((rc = ensure_scratch(c, 14, (size_t)N_max * HW * 4)) || (rc = ensure_scratch(c, 15, (lst + cand) * 4)) || (rc = ensure_scratch(c, 16, (lst + cand) * 4)) ||
+        (rc = ensure_scratch(c, 17, (size_t)N_max * 8)))
         return rc;
     return HAVC_OK;
 }
