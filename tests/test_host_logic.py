@@ -53,6 +53,23 @@ def test_op_struct_layout_matches_c(tmp_path):
                    d.fields["out_ox"][1], nat.BUF_DTYPE.itemsize]
 
 
+def test_python_constants_match_the_header():
+    """every HAVC_OP_* value, conv epilogue flag HAVC_F_* and element-wise flag HAVC_EW_* of include/havc_mi355.h against the constants of
+    vsdeoldify_amd/_native.py the plan emitters write into the op records (a renumbered op would still build, load and run the WRONG kernel)"""
+    text = open(HEADER).read()
+    ops = {k: int(v) for k, v in re.findall(r"\bHAVC_(OP_[A-Z0-9_]+)\s*=\s*(\d+)", text)}
+    assert len(ops) >= 28 and len(set(ops.values())) == len(ops), "op values are unique"
+    for name, val in ops.items():
+        assert getattr(nat, name) == val, (name, val, getattr(nat, name, None))
+    defs = {k: int(v, 0) for k, v in re.findall(r"#define\s+HAVC_((?:F|EW)_[A-Z0-9_]+)\s+(0x[0-9a-fA-F]+|\d+)\b", text)}
+    checked = 0
+    for name, val in defs.items():
+        if hasattr(nat, name):
+            assert getattr(nat, name) == val, (name, hex(val), hex(getattr(nat, name)))
+            checked += 1
+    assert checked >= 15, checked
+
+
 def test_norm_folds_match_oracle():
     from oracle import unet as ou
     sd = synth_state_dict("deep", 4)
