@@ -70,6 +70,33 @@ def test_python_constants_match_the_header():
     assert checked >= 15, checked
 
 
+def test_gelu_epilogue_constants_stay_within_their_stated_error():
+    """gelu_erf of csrc/conv_common.h (round 5: Phi as a logistic function of an odd polynomial, tools/fit_gelu.py) restated in numpy float32 from the
+    constants IN THE SOURCE FILE, against the exact v Phi(v) (nn.GELU(), the ConvNeXt block / ViT MLP of the reference's models): |error| < 1.3e-5 for
+    every fp16-representable |v| <= 16 and exact limits beyond the clamp -- the bound the kernel comment and DESIGN.md section 8 state."""
+    from scipy.special import ndtr
+    src = open(os.path.join(ROOT, "vsdeoldify_amd", "csrc", "conv_common.h")).read()
+    body = src[src.index("__device__ __forceinline__ float gelu_erf(float v)"):]
+    body = body[:body.index("\n}\n")]
+    c = [np.float32(x) for x in re.findall(r"(-?\d\.\d+e?-?\d*)f \* -L2E", body)]
+    assert len(c) == 4 and "fminf(v * v, 36.0f)" in body, (c, body[:200])
+    c3, c2, c1, c0 = c                                                       # source order: v^6, v^4, v^2, v^0 coefficients of P
+    L2E = np.float32(1.44269504088896341)
+    v = np.arange(-16, 16, 2.0 ** -9, dtype=np.float64).astype(np.float16).astype(np.float32)
+    v = np.unique(np.concatenate([v, np.float32([-60000, -20, 20, 60000, 0.0])]))
+    v2 = np.minimum(v * v, np.float32(36.0))
+    p = (np.float32(c3 * -L2E) * v2 + np.float32(c2 * -L2E)).astype(np.float32)
+    p = (p * v2 + np.float32(c1 * -L2E)).astype(np.float32)
+    p = (p * v2 + np.float32(c0 * -L2E)).astype(np.float32)
+    with np.errstate(over="ignore"):
+        e = np.exp2((p * v).astype(np.float32)).astype(np.float32)
+        got = (v * (np.float32(1.0) / (np.float32(1.0) + e))).astype(np.float32)
+    want = v.astype(np.float64) * ndtr(v.astype(np.float64))
+    err = np.abs(got - want)
+    assert np.isfinite(got).all() and err.max() < 1.3e-5, (float(err.max()), float(v[err.argmax()]))
+    assert got[v == 0][0] == 0 and got[v == 60000][0] == 60000 and got[v == -60000][0] == 0
+
+
 def test_norm_folds_match_oracle():
     from oracle import unet as ou
     sd = synth_state_dict("deep", 4)
