@@ -293,7 +293,10 @@ class MemoryManager:
         cand_k, cand_s, cand_e, usage = self.work_mem.get_all_sliced(start, end)
         stop = self.work_mem.size + end if end < 0 else self.work_mem.size
         cand_v = self.work_mem.v[..., start:stop]
-        _, top = torch.topk(usage, k=self.num_prototypes, dim=-1, sorted=True)
+        # memory_manager.py:240-243 takes torch.topk(usage, k = num_prototypes): on a GPU its choice (and order) among EQUAL usage values is unspecified and may
+        # differ from run to run -- and the order of the prototypes is the order of the long-term memory, i.e. the summation order of every later read.  A stable
+        # descending sort picks the same elements whenever the values differ and the LOWER index among equals: one answer, every run (round 5).
+        top = torch.sort(usage, dim=-1, descending=True, stable=True).indices[..., :self.num_prototypes]
         proto = top.flatten()
         proto_k = cand_k[:, :, proto]
         proto_e = cand_e[:, :, proto] if cand_e is not None else None
