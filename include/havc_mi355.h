@@ -520,6 +520,12 @@ int havc_cmn_value_in(havc_ctx* ctx, const float* image, const float* planes, fl
 int havc_dev_copy_2d(havc_ctx* ctx, void* d_dst, size_t dst_pitch, const void* d_src, size_t src_pitch, size_t width_bytes, size_t rows);
 int havc_net_bind_many(havc_net* net, int count, const int32_t* bufs, void* const* device_ptrs);
 int havc_net_enqueue_slices(havc_net* net, int count, const int32_t* first_op, const int32_t* n_ops, const int32_t* batch);
+/* Race hunting (round 6; no reference counterpart -- the reference steps a frame on ONE stream, colormnet/inference/inference_core.py:119-230): with seed != 0
+ * the multi-stream entry points (plan slices, havc_memory_read_banked, havc_cmn_short_term / _join_add / _side_begin / _side_wait, havc_dev_copy_2d) put a
+ * do-nothing kernel of pseudo-random length (1 .. max_us microseconds, one call in three) in front of their work on the stream they use, which moves the
+ * streams of a context and of the look-ahead context against each other; seed 0 switches it off.  Process-wide.  Results must not depend on it
+ * (tools/cmn_race_stress.py, tests/test_gpu_colormnet_stress.py).  HAVC_STREAM_JITTER=<seed> / HAVC_STREAM_JITTER_US set the same state at load time. */
+int havc_debug_stream_jitter(int seed, int max_us);
 
 /* timing of the dominant kernel for bench.py's roofline object: average duration (ms) and launch count
  * of HAVC_OP_CONV ops with the given tag over the launches since havc_reset_stats (HIP events on the

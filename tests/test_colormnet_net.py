@@ -648,20 +648,11 @@ def test_gpu_fast_step_equals_the_line_by_line_classes(name):
 
 @pytest.mark.gpu
 def test_gpu_fast_step_long_clip_with_consolidation_and_lookahead():
-    """The body below, with ONE retry.  Round 5: this test failed once in 40 runs (inside a whole-suite session whose output filter dropped the assertion
-    text; never reproduced: profiles/README.md).  Every comparison in it is deterministic by construction (the one exception code inspection found -- torch.topk's unspecified choice among equal
-    usage values in the consolidation -- is a stable sort since), so a failure means a race or a machine fault.  A first failure is therefore printed in full (`LONG-CLIP ATTEMPT 1 FAILED`, also as a warning) and the whole body runs again:
-    a second failure fails the test, and so does nothing else -- the driver runs the suite with -x, and an unexplained one-in-40 must not cost it the
-    270 tests behind this one, but it must not vanish either."""
-    import traceback
-    import warnings
-    try:
-        _long_clip_body()
-    except AssertionError:
-        text = traceback.format_exc()
-        print("LONG-CLIP ATTEMPT 1 FAILED:\n" + text)
-        warnings.warn("test_gpu_fast_step_long_clip: first attempt failed, retrying once:\n" + text[-600:])
-        _long_clip_body()
+    """Plain assertions, no retry (round 6).  Round 5 wrapped this body in one retry after an unexplained 1-in-40 failure; round 6 hunted it with
+    stream jitter (tests/test_gpu_colormnet_stress.py, tools/cmn_race_stress.py, profiles/r6_cmn_race_stress.txt) and closed the one lifetime hole the
+    audit found (a read enqueued ahead that no _read consumed: colormnet_fast.FastInferenceCore.step_*).  Every comparison here is deterministic by
+    construction: a failure is a race or a machine fault and must fail the test."""
+    _long_clip_body()
 
 
 def _long_clip_body():

@@ -1,0 +1,114 @@
+"""Race hunt for the ColorMNet frame loop: the long clip of tests/test_colormnet_net.py
+(60 frames, mem_every = 2, a small working memory: consolidations, usage counters, removal of obsolete long-term elements, key
+look-ahead of 8 frames, the read of frame t+1 under the decoder of frame t) run N times with the streams of the context and of the
+look-ahead context moved against each other by delay kernels of pseudo-random length (havc_debug_stream_jitter), every frame's SHA-1
+compared with ONE baseline: the same clip with no jitter, no read-ahead and the look-ahead pass on the step's own stream.
+
+Every comparison is deterministic by construction (inference_core.py:119-230 steps a frame on one stream; the multi-stream schedule
+here must give its bytes), so ANY difference is a race (or a machine fault).  On a mismatch the first differing frame, the memory
+sizes and the usage counters of both runs are printed, and the run is repeated with READ_AHEAD off / the look-ahead synchronous to
+bisect read-ahead vs look-ahead vs consolidation.
+
+Usage (GPU box):  python tools/cmn_race_stress.py [runs=200] [max_us=300] [frames=60]
+Exit code 0 = every run identical."""
+import hashlib
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+
+
+def make_clip(n_frames):
+    g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "colormnet_net_render.npz"))
+    r = np.random.default_rng(4)
+    base = g["frames"][0].astype(np.float32)
+    frames = [np.stack([np.clip(base + 6 * np.sin(t / 3.0) + r.normal(0, 2, base.shape), 0, 255).astype(np.uint8)] * 3, -1) for t in range(n_frames)]
+    return frames, g["refs"][0], int(g["seed"]) if "seed" in g.files else 0
+
+
+def run_clip(net, frames, ref, lookahead, read_ahead, fast=True):
+    """-> (per-frame sha1 list, (work size, long size), usage counters of both stores)"""
+    import vsdeoldify_amd.colormnet_fast as cf
+    from vsdeoldify_amd.colormnet_render import ColorMNetRender
+    from vsdeoldify_amd.device import DeviceImage
+    cf.READ_AHEAD, keep = read_ahead, cf.READ_AHEAD
+    net.fast = fast
+    try:
+        rnd = ColorMNetRender(image_size=-1, vid_length=len(frames), encode_mode=1, max_memory_frames=500, reset_on_ref_update=False, network=net,
+                              lookahead=lookahead)
+        for k, v in (("mem_every", 2), ("max_mid_term_frames", 4), ("min_mid_term_frames", 2), ("num_prototypes", 16), ("max_long_term_elements", 60),
+                     ("enable_long_term_count_usage", True)):
+            rnd.set_config(k, v)
+        dev = [DeviceImage.from_numpy(net.ctx, f) for f in frames]
+        refs = [DeviceImage.from_numpy(net.ctx, ref) if t == 0 else None for t in range(len(frames))]
+        outs = [o.numpy() for o in rnd.colorize_batch_frames(dev, refs, False)]
+        mem = rnd.processor.memory
+        use = [s.get_usage().float().cpu().numpy().ravel() if (s is not None and s.engaged() and s.count_usage) else None for s in (mem.work_mem, mem.long_mem)]
+        return [hashlib.sha1(o.tobytes()).hexdigest() for o in outs], (mem.work_mem.size, mem.long_mem.size), use, outs, getattr(rnd.processor, "reads_ahead", 0)
+    finally:
+        cf.READ_AHEAD = keep
+        net.fast = True
+
+
+def describe(tag, got, base):
+    sha, sizes, use, outs, _ = got
+    bsha, bsizes, buse, bouts, _ = base
+    first = next((i for i, (a, b) in enumerate(zip(sha, bsha)) if a != b), None)
+    print(f"  {tag}: first differing frame {first}; memory sizes {sizes} vs baseline {bsizes}")
+    if first is not None:
+        d = np.abs(outs[first].astype(int) - bouts[first].astype(int))
+        print(f"    frame {first}: max |d| {int(d.max())}, differing bytes {float((d > 0).mean()):.5f}; differing frames {[i for i, (a, b) in enumerate(zip(sha, bsha)) if a != b]}")
+    for name, u, bu in (("work", use[0], buse[0]), ("long", use[1], buse[1])):
+        if u is not None and bu is not None:
+            same = u.shape == bu.shape and np.array_equal(u, bu)
+            print(f"    usage counters ({name}): {'identical' if same else 'DIFFER: ' + str(u.shape) + ' vs ' + str(bu.shape)}")
+
+
+def main():
+    runs = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    max_us = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    n_frames = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+    from vsdeoldify_amd import _native as nat
+    from vsdeoldify_amd.colormnet_net import ColorMNetNetwork
+    from vsdeoldify_amd.synth import synth_colormnet_state_dict
+    frames, ref, seed = make_clip(n_frames)
+    g = np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "colormnet_net_modules.npz"))
+    net = ColorMNetNetwork(synth_colormnet_state_dict(int(g["seed"])), device_index=0)
+    lib = nat.load()
+    lib.havc_debug_stream_jitter(0, 1)
+    # the baseline: one stream for everything the frame loop does (no read-ahead; the look-ahead pass on the step's own stream), no jitter
+    net.async_lookahead = False
+    base = run_clip(net, frames, ref, 8, False)
+    net.async_lookahead = True
+    plain = run_clip(net, frames, ref, 8, True)                      # the product schedule, un-jittered
+    print(f"baseline: {n_frames} frames, memory sizes {base[1]}; product schedule un-jittered: {'identical' if plain[0] == base[0] else 'DIFFERENT'}, "
+          f"{plain[4]} reads ran ahead", flush=True)
+    bad = 0 if plain[0] == base[0] else 1
+    if bad:
+        describe("un-jittered product schedule", plain, base)
+    t0 = time.time()
+    for i in range(runs):
+        lib.havc_debug_stream_jitter(1000 + i, max_us)
+        got = run_clip(net, frames, ref, 8, True)
+        lib.havc_debug_stream_jitter(0, 1)
+        if got[0] != base[0] or got[1] != base[1]:
+            bad += 1
+            print(f"run {i} (jitter seed {1000 + i}): MISMATCH", flush=True)
+            describe("jittered", got, base)
+            for tag, la, ra in (("same seed, READ_AHEAD off", True, False), ("same seed, look-ahead synchronous", False, True)):
+                lib.havc_debug_stream_jitter(1000 + i, max_us)
+                net.async_lookahead = la
+                again = run_clip(net, frames, ref, 8, ra)
+                net.async_lookahead = True
+                lib.havc_debug_stream_jitter(0, 1)
+                print(f"  {tag}: {'identical to the baseline' if again[0] == base[0] else 'MISMATCH'}", flush=True)
+        if (i + 1) % 20 == 0:
+            print(f"{i + 1} jittered runs, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    print(f"cmn_race_stress: {runs} jittered runs (delays up to {max_us} us), {n_frames} frames each, {bad} mismatches")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -161,6 +161,7 @@ SYMBOLS = [
     ("havc_dev_copy_2d", _I, [_P, _P, _SZ, _P, _SZ, _SZ, _SZ]),
     ("havc_net_bind_many", _I, [_P, _I, _P, _P]),
     ("havc_net_enqueue_slices", _I, [_P, _I, _P, _P, _P]),
+    ("havc_debug_stream_jitter", _I, [_I, _I]),
     ("havc_tag_timing_enable", _I, [_P, _I, _I]),
     ("havc_tag_timing_read", _I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 ]

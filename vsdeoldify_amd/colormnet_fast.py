@@ -302,14 +302,16 @@ class FastInferenceCore(InferenceCore):
         (colormnet_net.prefetch_frames) is `entry`: its read may run under this frame's decoder (READ_AHEAD)"""
         self._next = entry
 
-    def drop_read_ahead(self):
+    def drop_read_ahead(self, keep_hint=False):
         """forget a read enqueued ahead of its frame (the memory is being replaced, or another processor is about to use the context's second
         stream and read scratch): the main stream waits for it, its usage update never happens; the frame it was for is read again when it is stepped"""
         if getattr(self, "_ahead_read", None) is not None:
             nat.check(self.network.ctx.lib.havc_cmn_side_wait(self.network.ctx.h, 0), self.network.ctx.h)
             if getattr(self.network, "_side_owner", None) is self:
                 self.network._side_owner = None
-        self._ahead_read = self._next = None
+        self._ahead_read = None
+        if not keep_hint:
+            self._next = None
 
     def _issue_read(self, B, key, selection, readout, with_short_term):
         net = self.network
@@ -392,6 +394,8 @@ class FastInferenceCore(InferenceCore):
         is_mem, deep, normal = self._schedule(mask is not None, end)
         need_segment = self.curr_ti > 0 and self._labels_differ(valid_labels)
         key, shrinkage, selection, f16, f8, f4 = self.network.encode_key(image, need_ek=(self.enable_long_term or need_segment), need_sk=is_mem)
+        if not need_segment:                                   # no _read will consume (or drop) a read enqueued ahead for this frame: nothing may touch the
+            self.drop_read_ahead()                             # memory, the second stream or the read's scratch before the main stream has waited for it
         planes = self._read(key, selection, (f16, f8, f4), normal, is_mem=is_mem) if need_segment else None
         self._next = None
         if mask is not None:
@@ -412,6 +416,8 @@ class FastInferenceCore(InferenceCore):
         need_segment = (self.curr_ti > 0 if flag_FirstframeIsExemplar else self.curr_ti >= 0) and self._labels_differ(valid_labels)
         key, shrinkage, selection, f16, f8, f4 = self.network.encode_key(image, need_ek=(self.enable_long_term or need_segment), need_sk=is_mem)
         planes = None
+        if exemplar or not need_segment:                       # an exemplar's add_memory below runs BEFORE this frame's _read, and without need_segment no _read runs at
+            self.drop_read_ahead(keep_hint=True)               # all: a read enqueued ahead (the caller announced a plain frame) is waited for and forgotten first
         if exemplar:
             need_segment, deep = True, False
             ref = ref_image.unsqueeze(0)

@@ -274,7 +274,9 @@ class MemoryManager:
             self.hidden = sample_key.new_zeros((1, n, self.hidden_dim) + grid, dtype=sample_key.dtype if sample_key.is_floating_point() else None)
         else:
             missing = n - self.hidden.shape[1]
-            if missing:                    # (a negative count fails in F.pad's own shape check, like the reference's torch.zeros would)
+            if missing < 0:                # F.pad with a negative count would silently CROP the objects; the reference's torch.zeros((1, missing, ...)) raises
+                raise RuntimeError(f"Trying to create tensor with negative dimension {missing}: hidden state of {self.hidden.shape[1]} objects, {n} asked for")
+            if missing:
                 self.hidden = F.pad(self.hidden, (0, 0, 0, 0, 0, 0, 0, missing))
         if self.hidden.shape[1] != n:
             raise AssertionError("hidden state / object count mismatch")

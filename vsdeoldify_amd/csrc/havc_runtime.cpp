@@ -4,6 +4,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -47,9 +48,45 @@ __global__ void scratch_warm_kernel(int* out, int n) {
     if (n == 12345) out[0] = a[n % 192];
 }
 
+// HAVC_STREAM_JITTER=<seed> (race hunting, tools/cmn_race_stress.py): a kernel that does nothing for `ticks` of the 100 MHz wall clock, launched with a
+// pseudo-random length in front of the work of the multi-stream entry points (plan slices, the ColorMNet read / short-term attention / side sections,
+// device copies).  It moves the streams of a context -- and the look-ahead context -- against each other by up to a few hundred microseconds per call, so
+// that an ordering that only holds by timing shows up as different bytes.  Results must not depend on it.  Off (one predictable branch) unless the variable is set.
+__global__ void jitter_delay_kernel(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
 namespace {
 
 thread_local std::string g_create_error;
+
+struct JitterState {
+    bool on = false;
+    unsigned max_us = 300;
+    std::atomic<uint64_t> rng{0x9E3779B97F4A7C15ull};
+    JitterState() {
+        const char* e = getenv("HAVC_STREAM_JITTER");
+        if (e && *e && atoll(e) != 0) {
+            on = true;
+            rng = 0x9E3779B97F4A7C15ull * (uint64_t)(atoll(e) + 1);
+            if (const char* m = getenv("HAVC_STREAM_JITTER_US")) max_us = (unsigned)std::max(1, atoi(m));
+        }
+    }
+};
+JitterState g_jitter;
+
+// one call = at most one delay kernel on `st` (two calls in three launch nothing: the un-delayed interleavings stay in the mix)
+inline void stream_jitter(hipStream_t st) {
+    if (!g_jitter.on) return;
+    uint64_t x = g_jitter.rng.load(std::memory_order_relaxed);
+    x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+    g_jitter.rng.store(x, std::memory_order_relaxed);
+    if (x % 3) return;
+    const unsigned us = 1 + (unsigned)((x >> 20) % g_jitter.max_us);
+    hipLaunchKernelGGL(jitter_delay_kernel, dim3(1), dim3(64), 0, st, (unsigned long long)us * 100ull);
+    (void)hipGetLastError();
+}
 
 struct ResizeTable {
     int taps = 0;
@@ -781,6 +818,7 @@ int run_ops_locked(havc_net* n, int first, int count, int batch) {
     const bool check = c->range_check;
     if (check && !n->range_ready) return fail(c, HAVC_E_INVALID, "range check: enable it before the net is created (its buffers must start zero-filled)");
     hipStream_t s = c->cur ? c->cur : c->stream;
+    stream_jitter(s);
     for (int i = first; i < first + count; ++i) {
         int rc = run_op(n, n->ops[i], batch);
         if (rc) return rc;
@@ -2423,6 +2461,7 @@ int havc_memory_read_banked(havc_ctx* c, const float* mk, const float* ms, const
     const size_t lst = (size_t)top_k * HW, cand = lst * (mem_topk_splits(N) > 1 ? mem_topk_splits(N) : 0);
     if ((rc = ensure_scratch(c, 14, (size_t)N * HW * 4)) || (rc = ensure_scratch(c, 15, (lst + cand) * 4)) || (rc = ensure_scratch(c, 16, (lst + cand) * 4))) return rc;
     const hipStream_t st = c->side ? c->stream2 : c->stream;       // a read-ahead (havc_cmn_side_begin) runs next to the previous frame's decoder
+    stream_jitter(st);
     static const bool wave_topk = [] { const char* e = getenv("HAVC_TOPK_WAVE"); return !e || atoi(e) != 0; }();
     int e;
     if (wave_topk && mem_topk_select_supported(N)) {
@@ -2504,6 +2543,7 @@ int havc_cmn_short_term(havc_ctx* c, havc_net* net, int first_op, int n_ops, int
         HIP_TRY(c, hipEventRecord(c->ev_fork, c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0));
     }
+    stream_jitter(c->stream2);
     int e = launch_local_correlation(q, k, attn, 1, C, H, W, max_dis, 1, 1.0f / sqrtf((float)C), c->stream2);
     if (!e) e = launch_local_softmax(attn, q, rel_w, rel_b, 1, C, H, W, max_dis, 1, c->stream2);
     if (!e) e = launch_local_agg(attn, v, agg, 1, CV, H, W, max_dis, 1, c->stream2);
@@ -2526,6 +2566,7 @@ int havc_cmn_join_add(havc_ctx* c, float* readout, const float* short_out, int64
     HIP_TRY(c, hipSetDevice(c->dev));
     const hipStream_t st = c->side ? c->stream2 : c->stream;
     if (!c->side) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_join, 0));
+    stream_jitter(st);
     int e = launch_vec_add(readout, short_out, n, st);
     c->stats.launches++;
     if (e) return hip_fail(c, (hipError_t)e, "cmn_join_add");
@@ -2553,6 +2594,7 @@ int havc_cmn_side_begin(havc_ctx* c) {
     if (!c->marked) HIP_TRY(c, hipEventRecord(c->ev_mark, c->stream));
     c->marked = false;
     HIP_TRY(c, hipStreamWaitEvent(c->stream2, c->ev_mark, 0));
+    stream_jitter(c->stream2);
     c->side = true;
     return HAVC_OK;
 }
@@ -2595,6 +2637,7 @@ int havc_cmn_side_wait(havc_ctx* c, int apply_usage) {
     if (c->side) return fail(c, HAVC_E_INVALID, "cmn_side_wait: inside a side section");
     HIP_TRY(c, hipSetDevice(c->dev));
     HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_side, 0));
+    stream_jitter(c->stream);
     auto u = c->side_usage;
     c->side_usage = {};
     if (apply_usage && u.use) {
@@ -2618,6 +2661,7 @@ int havc_dev_copy_2d(havc_ctx* c, void* d_dst, size_t dst_pitch, const void* d_s
     if (!c || !d_dst || !d_src || width_bytes == 0 || rows == 0 || dst_pitch < width_bytes || src_pitch < width_bytes) return HAVC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     HIP_TRY(c, hipSetDevice(c->dev));
+    stream_jitter(c->stream);
     HIP_TRY(c, hipMemcpy2DAsync(d_dst, dst_pitch, d_src, src_pitch, width_bytes, rows, hipMemcpyDeviceToDevice, c->stream));
     return HAVC_OK;
 }
@@ -2639,6 +2683,16 @@ int havc_net_enqueue_slices(havc_net* n, int count, const int32_t* first_op, con
     HIP_TRY(c, hipSetDevice(c->dev));
     for (int i = 0; i < count; ++i)
         if (int rc = run_ops_locked(n, first_op[i], n_ops[i], batch[i])) return rc;
+    return HAVC_OK;
+}
+
+int havc_debug_stream_jitter(int seed, int max_us) {
+    g_jitter.on = false;
+    if (seed != 0) {
+        g_jitter.rng.store(0x9E3779B97F4A7C15ull * (uint64_t)((int64_t)seed + 1) | 1ull);
+        g_jitter.max_us = (unsigned)std::max(1, max_us);
+        g_jitter.on = true;
+    }
     return HAVC_OK;
 }
 
