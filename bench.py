@@ -54,6 +54,11 @@ TAG_TAIL_RES = 1
 PMC_FILES = [os.path.join("profiles", "r5_tail_conv_pmc.json"), os.path.join("profiles", "r4_tail_conv_pmc.json"), os.path.join("profiles", "r3_tail_conv_pmc.json"), os.path.join("profiles", "r2_tail_conv_pmc.json")]   # newest first
 
 
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X fp32 matrix (xf32-free v_mfma_f32_*_f32) peak: the fair context for an fp32-class figure (MI355X_MICROARCH.md)
+PRECISE_MIN_SECONDS = 5.0           # the precise (contract-meeting) leg is timed over at least this long
+CHILD_MIN_SECONDS = 2.0             # ... and every c3 / c4 / c5 child leg over at least this long
+
+
 PARITY_SEEDS = ((1, 2), (11, 12), (21, 22))     # (video, stable) weight seeds: the bench weights first
 PARITY_FRAMES = (4, 2, 2)                       # frames of the clip checked per seed pair: 8 frames over 3 weight sets
 
@@ -144,9 +149,14 @@ def precise_leg(args, sds, device_index, frames, fbytes, batch=None):
             cc.colorize_device(off(d_src, f0 * fbytes), off(d_dst, f0 * fbytes), batch, WIDTH, HEIGHT)
         step(0)
         ctx.synchronize()
+        t0 = time.perf_counter()
+        step(1)                                                # one more untimed step: its duration sizes the timed region
+        ctx.synchronize()
+        est = max(time.perf_counter() - t0, 1e-3)
         ctx.reset_stats()
         nat.check(ctx.lib.havc_tag_timing_enable(ctx.h, TAG_TAIL_RES, 1), ctx.h)
-        steps = max(2, min(args.steps, 4))
+        # the contract-meeting figure is timed like the headline: --steps steps, and never less than PRECISE_MIN_SECONDS of work
+        steps = max(2, args.steps, int(np.ceil(PRECISE_MIN_SECONDS / est)))
         ctx.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -173,7 +183,9 @@ def precise_leg(args, sds, device_index, frames, fbytes, batch=None):
     fps = steps * batch / dt
     leg = {"value": round(fps, 2), "unit": "frames/s", "frames_per_step": batch, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2), "dtype": "f16x2 (hi / lo pairs, fp32 accumulate)",
            "whole_path_tflops": round(fps * 2759.32e9 / 1e12, 2), "whole_path_frac": round(fps * 2759.32e9 / 1e12 / PEAK_F16_TFLOPS, 4),
+           "seconds_timed": round(dt, 2),
            "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4),
+                        "peak_fp32_matrix": PEAK_F32_MATRIX_TFLOPS, "frac_of_fp32_matrix_peak": round(ach / PEAK_F32_MATRIX_TFLOPS, 3),
                         "mfma_executed_frac": round(3 * ach / PEAK_F16_TFLOPS, 4), "launches_timed": int(launches.value), "frames_per_launch": round(fpl, 2),
                         "avg_launch_ms": round(avg_ms.value, 4), "flops_per_launch": alg,
                         "kernel": "conv_pipe_kernel<2,4,8,1> on the three-segment K walk (layers.10 res-block 3x3 259->259 @560x560): `achieved` counts the "
@@ -236,6 +248,8 @@ def main():
     ap.add_argument("--precision", default="fast", choices=["fast", "precise"],
                     help="c3 / c4: build every model of the graph in this mode (HAVCFrameColorizer(precision=...)); the headline config has its own precise leg")
     ap.add_argument("--sustain-seconds", type=float, default=30.0)
+    ap.add_argument("--min-seconds", type=float, default=0.0,
+                    help="c3 / c4 / c5: raise --steps (BEFORE the timed region, from one untimed probe step) so that the timed region lasts at least this long")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU-oracle baseline leg (0 = all host cores: os.cpu_count())")
     args = ap.parse_args()
     if args.batch is None:              # 64 frames per step fill the small encoder / decoder layers better than 32 (+2 %, same-box A/B; 105 GB of activations)
@@ -361,6 +375,8 @@ def main():
         "config": {"workload": "DeOldify 'stable' generator, render_factor=35, 1080p clip (BASELINE.json configs[1])",
                    "frames_per_step_per_gpu": args.batch, "net_input": f"{S}x{S}", "unet_passes_per_frame": 2,
                    "algorithmic_gflop_per_frame": 2759.32, "weights": "seeded synthetic (wide resnet101 x2)",
+                   "precision": "fast (fp16 MFMA operands, fp32 accumulate) -- the reference is fp32 end to end (deoldify/filters.py:45-68); this mode meets "
+                                "CIEDE2000 < 1.0 in the mean only: the figure that meets the per-pixel contract is `contract` (precise mode)",
                    "conv_tile_autotune": os.environ.get("HAVC_AUTOTUNE", "1") != "0",
                    "parallelism": f"frame-sharded x{world}, weight replica per GPU, no collective"},
         "whole_path_tflops": round(total_frames * 2759.32e9 / elapsed / 1e12 / world, 2),
@@ -400,6 +416,16 @@ def main():
         out["parity"] = parity
         if parity_p is not None:
             out["precise"]["parity"] = parity_p
+    # ---- which number meets north_star's tolerance: a reader of the top-level keys alone sees both ----
+    if isinstance(out.get("precise"), dict) and "value" in out["precise"]:
+        pp, fp_ = out["precise"].get("parity") or {}, out.get("parity") or {}
+        out["contract"] = {"mode": "precise", "value": out["precise"]["value"], "unit": "frames/s", "dtype": "f16x2 -> fp32-class (hi / lo fp16 pairs, 22 significand bits, fp32 accumulate)",
+                           "meets_contract": pp.get("meets_contract"), "ciede2000_p99": pp.get("ciede2000_p99"), "pixels_with_dE_below_1": pp.get("pixels_with_dE_below_1"),
+                           "steps": out["precise"]["steps"], "frames_per_step": out["precise"]["frames_per_step"], "seconds_timed": out["precise"].get("seconds_timed"),
+                           "headline_value_meets_contract": fp_.get("meets_contract"),
+                           "reading": "`value` (top level) is the fast mode at dtype f16: mean CIEDE2000 < 1.0 but p99 > 1.0 -- OUTSIDE the per-pixel tolerance; "
+                                      "`contract.value` is the same step in precise mode, inside it (p99 < 1.0 and >= 99 % of the pixels below 1.0), timed over the same "
+                                      "--steps (>= 5 s).  Details: `precise` (roofline, parity per frame)."}
     if other is not None:
         out["other_configs"] = other
     if dist is not None:
@@ -416,6 +442,19 @@ def main():
         print(json.dumps(out))
 
 
+def _raise_steps(args, step, sync_all, world):
+    """--min-seconds: one more UNTIMED step sizes the timed region; K is fixed before it starts and reported in `steps` (single-process legs only: every
+    rank of a multi-GPU run must time the same K)"""
+    if args.min_seconds <= 0 or world > 1:
+        return
+    sync_all()
+    t0 = time.perf_counter()
+    step(0)
+    sync_all()
+    est = max(time.perf_counter() - t0, 1e-4)
+    args.steps = max(args.steps, int(np.ceil(args.min_seconds / est)))
+
+
 def _progress(msg):
     print(f"bench: [{time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
@@ -427,7 +466,8 @@ def other_configs_leg(args):
 
     def child(cfg, extra, steps, warm):
         _progress(f"child leg {cfg} {' '.join(extra)}")
-        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", steps, "--warmup", warm, "--no-extras", "--cpu-threads", str(args.cpu_threads)] + extra
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", steps, "--warmup", warm, "--no-extras", "--cpu-threads", str(args.cpu_threads),
+               "--min-seconds", str(CHILD_MIN_SECONDS)] + extra
         if args.no_cpu_baseline:
             cmd.append("--no-cpu-baseline")
         t0 = time.time()
@@ -439,7 +479,7 @@ def other_configs_leg(args):
             o = json.loads(lines[-1])
             par = o.get("parity") or {}
             return {"metric": o["metric"], "value": o["value"], "unit": "frames/s", "ms_per_step": o["ms_per_step"], "dtype": o.get("dtype"),
-                    "frames_per_step": o["config"].get("frames_per_step_per_gpu"), "steps": o["steps"],
+                    "frames_per_step": o["config"].get("frames_per_step_per_gpu"), "steps": o["steps"], "seconds_timed": round(o["steps"] * o["ms_per_step"] / 1e3, 2),
                     "whole_path_tflops": o.get("whole_path_tflops"), "whole_path_frac": round((o.get("whole_path_tflops") or 0.0) / PEAK_F16_TFLOPS, 4),
                     "roofline": {k: o["roofline"].get(k) for k in ("bound", "scope", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "frames_per_launch") if k in o["roofline"]},
                     "parity": {k: par.get(k) for k in ("ciede2000_mean", "ciede2000_p99", "ciede2000_max", "pixels_with_dE_below_1", "meets_contract", "frames_checked")} if par else None,
@@ -454,6 +494,11 @@ def other_configs_leg(args):
         if cfg in ("c3", "c4") and not args.no_precise:
             # the same graph with every model in precise mode (HAVCFrameColorizer(precision="precise"), round 5): 16 frames per step (pair activations)
             res[cfg]["precise"] = child(cfg, ["--precision", "precise", "--batch", "16"], "2", "1")
+        # which figure of this config meets the tolerance (c5's fast path already does)
+        src = res[cfg].get("precise") if isinstance(res[cfg].get("precise"), dict) and "value" in res[cfg].get("precise", {}) else res[cfg]
+        if "value" in src:
+            res[cfg]["contract"] = {"mode": "precise" if src is not res[cfg] else "fast", "value": src["value"], "meets_contract": (src.get("parity") or {}).get("meets_contract"),
+                                    "seconds_timed": src.get("seconds_timed")}
     return res
 
 
@@ -628,6 +673,7 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
     ctx.reset_stats()
     if side:
         dd_ctx.reset_stats()
+    _raise_steps(args, step, sync_all, world)
     nat.check(ctx.lib.havc_tag_timing_enable(ctx.h, tag, 1), ctx.h)
     sync_all()
     t0 = time.perf_counter()
@@ -784,6 +830,7 @@ def bench_c5(args, rank, local_rank, world, dist):
     tctx = look.ctx if key_nets else ctx                                          # tag timing is per context: the one that launches the tagged op
     tag_name = "key_encoder.fuse2.encode_enc"
     op = tag_net.plan_ops[tag_net.names.index(tag_name)]
+    _raise_steps(args, step, sync_all, world)
     ctx.reset_stats()
     nat.check(tctx.lib.havc_tag_timing_enable(tctx.h, int(op["tag"]), 1), tctx.h)
     sync_all()
