@@ -297,7 +297,8 @@ def main():
     from vsdeoldify_amd.synth import synth_state_dict
 
     sds = {"video": synth_state_dict("wide", 1), "stable": synth_state_dict("wide", 2)}
-    cc = ClipColorizer("stable", RENDER_FACTOR, 0.5, device_index=local_rank, state_dicts=sds, max_batch=args.batch)
+    # the headline is the opt-in speed mode, asked for explicitly; the package default is "precise" (vsdeoldify_amd/precision.py) = the `contract` leg
+    cc = ClipColorizer("stable", RENDER_FACTOR, 0.5, device_index=local_rank, state_dicts=sds, max_batch=args.batch, precision="fast")
     ctx = cc.ctx
 
     # ---- synthetic clip, resident in HBM before the timed region --------------------------------
@@ -375,8 +376,9 @@ def main():
         "config": {"workload": "DeOldify 'stable' generator, render_factor=35, 1080p clip (BASELINE.json configs[1])",
                    "frames_per_step_per_gpu": args.batch, "net_input": f"{S}x{S}", "unet_passes_per_frame": 2,
                    "algorithmic_gflop_per_frame": 2759.32, "weights": "seeded synthetic (wide resnet101 x2)",
-                   "precision": "fast (fp16 MFMA operands, fp32 accumulate) -- the reference is fp32 end to end (deoldify/filters.py:45-68); this mode meets "
-                                "CIEDE2000 < 1.0 in the mean only: the figure that meets the per-pixel contract is `contract` (precise mode)",
+                   "precision": "fast (fp16 MFMA operands, fp32 accumulate): the OPT-IN speed mode (precision='fast' / HAVC_PRECISION=fast) -- the reference is fp32 end "
+                                "to end (deoldify/filters.py:45-68) and this mode meets CIEDE2000 < 1.0 in the mean only; the package DEFAULT is 'precise' "
+                                "(vsdeoldify_amd/precision.py), which meets the per-pixel contract: its figure is `contract`",
                    "conv_tile_autotune": os.environ.get("HAVC_AUTOTUNE", "1") != "0",
                    "parallelism": f"frame-sharded x{world}, weight replica per GPU, no collective"},
         "whole_path_tflops": round(total_frames * 2759.32e9 / elapsed / 1e12 / world, 2),
@@ -419,7 +421,7 @@ def main():
     # ---- which number meets north_star's tolerance: a reader of the top-level keys alone sees both ----
     if isinstance(out.get("precise"), dict) and "value" in out["precise"]:
         pp, fp_ = out["precise"].get("parity") or {}, out.get("parity") or {}
-        out["contract"] = {"mode": "precise", "value": out["precise"]["value"], "unit": "frames/s", "dtype": "f16x2 -> fp32-class (hi / lo fp16 pairs, 22 significand bits, fp32 accumulate)",
+        out["contract"] = {"mode": "precise (the package default)", "value": out["precise"]["value"], "unit": "frames/s", "dtype": "f16x2 -> fp32-class (hi / lo fp16 pairs, 22 significand bits, fp32 accumulate)",
                            "meets_contract": pp.get("meets_contract"), "ciede2000_p99": pp.get("ciede2000_p99"), "pixels_with_dE_below_1": pp.get("pixels_with_dE_below_1"),
                            "steps": out["precise"]["steps"], "frames_per_step": out["precise"]["frames_per_step"], "seconds_timed": out["precise"].get("seconds_timed"),
                            "headline_value_meets_contract": fp_.get("meets_contract"),
@@ -580,7 +582,7 @@ def extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds):
     # ---- batch 1, one blocking call per frame: what a ModifyFrame selector gets ----
     from PIL import Image
     from vsdeoldify_amd.render import ModelImageRender
-    r1 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1)
+    r1 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1, precision="fast")
     S = RENDER_FACTOR * 16
     img = Image.fromarray(np.ascontiguousarray(frames[0][:S, :S]))
     for _ in range(3):
@@ -593,7 +595,7 @@ def extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds):
     res["batch1"] = {"value": round(k / dt, 2), "unit": "frames/s", "ms_per_call": round(dt / k * 1e3, 3),
                      "how": "ModelImageRender('stable', rf=35).get_transformed_image(PIL 560x560), one blocking call per frame (H2D + 2 passes + D2H)"}
     # ---- the same single caller with the low-latency nets (split-K convs for one frame per launch; fp32 summation order differs) ----
-    r2 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1, low_latency=True)
+    r2 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1, low_latency=True, precision="fast")
     for _ in range(3):
         r2.get_transformed_image(img)
     t0 = time.perf_counter()
@@ -606,7 +608,7 @@ def extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds):
     # ---- the same per-frame call from 16 threads (VapourSynth's worker pool) through ONE coalescing render: havc_batcher ----
     import threading
     T, K = 16, 6
-    rc = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, coalesce=T)
+    rc = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, coalesce=T, precision="fast")
     imgs = [Image.fromarray(np.ascontiguousarray(frames[i % len(frames)][:S, :S])) for i in range(T)]
 
     def worker(t, n):

@@ -151,9 +151,10 @@ enum havc_op_type {
                                      larger than the 256 MiB Infinity Cache that are not re-read soon (set by the runtime, HAVC_NT_STORE_MB) */
 #define HAVC_F_SPLITK(n) ((n) << 16) /* bits 16-19: split-K count n = 2..15 for convs with few output tiles and a long K (one frame of a small
                                      layer: 4 x 8 tiles on 256 CUs): the K range is cut into n parts (even stage boundaries), one block per
-                                     (tile, part) writes fp32 partial sums to a ctx scratch buffer; the LAST block of a tile to arrive (a per-tile
-                                     counter, release / acquire at agent scope) adds them IN A FIXED ORDER (0 .. n-1, its own included) and
-                                     runs the epilogue (round 5; HAVC_SPLITK_FUSED=0: a second kernel does, same bytes).  The count is part of the PLAN (chosen by the emitter from the shape), not
+                                     (tile, part) writes fp32 partial sums to a ctx scratch buffer; a second launch (splitk_reduce_kernel) adds them
+                                     IN A FIXED ORDER (0 .. n-1) and runs the epilogue.  (Round 5 also built the reduction into the conv kernel -- last block
+                                     of a tile, agent-scope release / acquire -- measured it 2x slower and round 6 removed it: profiles/r5_splitk_fused_ab.txt.)
+                                     The count is part of the PLAN (chosen by the emitter from the shape), not
                                      of the tile autotuner: every tile configuration produces the same bytes for a given count.  Plain convs
                                      only (no PS_BLUR / FUSE_* / W_FROM_BUF / extra-column tile)                                      */
 #define HAVC_F_SPLITK_COUNT(flags) (((flags) >> 16) & 15)

@@ -106,3 +106,19 @@ def conv_op_precise(ctx, x, W, bias=None, scale=None, shift=None, stride=1, pad=
     b.conv("t", pc, xv, yv, stride=stride, pad=pad, dil=dil, flags=flags, res=rv)
     raw = run_plan(ctx, pack, b, ups, {yv.buf: ((B, yv.H, yv.W, yv.cpitch), np.float16)}, B, cfg)[yv.buf]
     return hl_unpack(raw, yv.C), raw
+
+
+# ---- shared CPU-oracle frames (round 6: the suite evaluated the same 1080p oracle frame in several files, ~5 s each) ----
+_ORACLE_FULLSIZE = {}
+
+
+def oracle_fullsize_stable(seed_video, seed_stable, frame_index, render_factor=35):
+    """oracle.pipeline.colorize_frame_fullsize('stable') of frame `frame_index` of the synthetic 1080p clip on the seeded weight pair; cached per process"""
+    key = (seed_video, seed_stable, frame_index, render_factor)
+    if key not in _ORACLE_FULLSIZE:
+        from oracle import pipeline
+        from vsdeoldify_amd.clip import synthetic_gray_frame
+        from vsdeoldify_amd.synth import synth_state_dict
+        sds = {"video": synth_state_dict("wide", seed_video), "stable": synth_state_dict("wide", seed_stable)}
+        _ORACLE_FULLSIZE[key] = pipeline.colorize_frame_fullsize(sds, "stable", synthetic_gray_frame(frame_index, 1920, 1080), render_factor, 0.5)
+    return _ORACLE_FULLSIZE[key]

@@ -149,18 +149,26 @@ def test_model_image_render_precision_argument_and_environment(ctx):
     rf, img = 5, make_frame(80, 42)
     ref = pipeline.model_image_render(sds, "stable", img, rf, 0.5)
     outs = {}
-    for how in ("argument", "environment"):
+    keep = os.environ.get("HAVC_PRECISION")
+    for how in ("argument", "environment", "default"):
         if how == "environment":
             os.environ["HAVC_PRECISION"] = "precise"
+        elif how == "default":
+            os.environ.pop("HAVC_PRECISION", None)             # no argument, no switch: the package default (precision.py) must be the contract-meeting mode
         try:
             r = ModelImageRender(None, "stable", rf, 0.5, state_dicts=sds, precision="precise" if how == "argument" else None)
         finally:
-            os.environ.pop("HAVC_PRECISION", None)
-        assert r._video.gen.precise and r._second.gen.precise
+            if keep is None:
+                os.environ.pop("HAVC_PRECISION", None)
+            else:
+                os.environ["HAVC_PRECISION"] = keep
+        assert r._video.gen.precise and r._second.gen.precise, how
         outs[how] = np.asarray(r.get_transformed_image(Image.fromarray(img)))
         for rt in (r._video, r._second):
             rt.close()
-    assert np.array_equal(outs["argument"], outs["environment"])
+    assert np.array_equal(outs["argument"], outs["environment"]) and np.array_equal(outs["argument"], outs["default"])
+    r = ModelImageRender(None, "stable", rf, 0.5, state_dicts=sds, precision="fast")                 # the opt-in speed mode is still there
+    assert not r._video.gen.precise
     de = imaging.delta_e00_images(outs["argument"], ref)
     assert np.percentile(de, 99) < PRECISE_CLIP["p99"] and (de < 1.0).mean() >= PRECISE_CLIP["frac_lt1"], (float(np.percentile(de, 99)), float((de < 1).mean()))
     with pytest.raises(ValueError):
@@ -188,7 +196,7 @@ def test_colorize_clip_1080p_8_frames_3_weight_sets_precise_meets_the_contract(c
             del cc
             gc.collect()
         for k in range(n):
-            ref = pipeline.colorize_frame_fullsize(sds, "stable", frames[k], 35, 0.5)
+            ref = gu.oracle_fullsize_stable(sv, ss, idx[k])
             for mode in ("fast", "precise"):
                 de = imaging.delta_e00_images(got[mode][k], ref)
                 pooled[mode].append(de.reshape(-1))

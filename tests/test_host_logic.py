@@ -330,3 +330,21 @@ def test_sharded_clip_runner_failure_on_one_rank_raises_everywhere_and_nobody_ha
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r.startswith("raised: colorize_clip_sharded") for r in res), res
+
+
+def test_default_precision_is_the_contract_meeting_mode(monkeypatch):
+    """round 6: explicit argument > HAVC_PRECISION > "precise" (vsdeoldify_amd/precision.py) -- the reference computes in fp32 (deoldify/filters.py:45-68), so a
+    drop-in built without any switch must be the mode that meets north_star's CIEDE2000 < 1.0; "fast" is opt-in.  (tests/conftest.py selects "fast" for the
+    suite through the process-wide switch.)"""
+    from vsdeoldify_amd import precision as P
+    monkeypatch.delenv("HAVC_PRECISION", raising=False)
+    assert P.DEFAULT_PRECISION == "precise" and P.resolve() == "precise" and P.resolve(None) == "precise"
+    assert P.resolve("fast") == "fast"
+    monkeypatch.setenv("HAVC_PRECISION", "fast")
+    assert P.resolve() == "fast" and P.resolve("precise") == "precise"
+    for bad in ("double", "fp32"):
+        with pytest.raises(ValueError):
+            P.resolve(bad)
+    monkeypatch.setenv("HAVC_PRECISION", "half")
+    with pytest.raises(ValueError):
+        P.resolve()

@@ -5,6 +5,8 @@ buffers out on one GPU, seeded synthetic weights:
   C4  HAVC merge method 2 defaults: DeOldify video rf=24 + DDColor rf=24 at 384x384, Image.blend(mweight 0.4 -> weight of b)
 Usage: python tools/configs_bench.py [frames]"""
 import sys, os, time
+import os as _os
+_os.environ.setdefault("HAVC_PRECISION", "fast")      # this tool measures the fast (fp16) mode unless told otherwise; the package default is "precise"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from vsdeoldify_amd import mcomb

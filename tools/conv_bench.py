@@ -2,6 +2,8 @@
    python tools/conv_bench.py [batch] [reps] [shape-filter]
 Each shape is a 1-op plan run through the C ABI; time = HIP events around the op (havc_net_profile)."""
 import sys, os
+import os as _os
+_os.environ.setdefault("HAVC_PRECISION", "fast")      # this tool measures the fast (fp16) mode unless told otherwise; the package default is "precise"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from vsdeoldify_amd import _native as nat

@@ -1,5 +1,7 @@
 """GPU-vs-oracle accuracy table for the DeOldify generators (raw colour + final image). Run on the GPU box."""
 import sys, os, time
+import os as _os
+_os.environ.setdefault("HAVC_PRECISION", "fast")      # this tool measures the fast (fp16) mode unless told otherwise; the package default is "precise"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import imaging, pipeline

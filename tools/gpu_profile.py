@@ -1,6 +1,8 @@
 """Per-op GPU timing of one generator pass (HIP events around every op).  Usage:
    python tools/gpu_profile.py [arch] [S] [batch]   -> table sorted by time + totals."""
 import sys, os, time
+import os as _os
+_os.environ.setdefault("HAVC_PRECISION", "fast")      # this tool measures the fast (fp16) mode unless told otherwise; the package default is "precise"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from vsdeoldify_amd.render import GeneratorRuntime, get_context

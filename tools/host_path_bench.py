@@ -1,5 +1,7 @@
 """PCIe-inclusive rate of the clip path: host uint8 frames in -> coloured host frames out (H2D + pipeline + D2H)."""
 import sys, os, time
+import os as _os
+_os.environ.setdefault("HAVC_PRECISION", "fast")      # this tool measures the fast (fp16) mode unless told otherwise; the package default is "precise"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from vsdeoldify_amd.clip import ClipColorizer, synthetic_gray_frame

@@ -3,6 +3,8 @@
    python tools/range_headroom.py            # the seeded synthetic weights of bench.py: wide 560 (video, stable), DDColor 512, ColorMNet 224x448
 With real checkpoints: pass state dicts to the same classes; a run that overflows raises HavcRangeError naming the op."""
 import os
+import os as _os
+_os.environ.setdefault("HAVC_PRECISION", "fast")      # this tool measures the fast (fp16) mode unless told otherwise; the package default is "precise"
 import sys
 
 import numpy as np

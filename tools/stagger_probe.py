@@ -2,6 +2,8 @@
 (560 x 560, 32 frames per pass), started together (lockstep, re-aligned every pass through a barrier) or free-running with thread B
 started half a pass late.  Prints generator frames/s for both.  Usage: python tools/stagger_probe.py [batch] [passes]"""
 import sys, os, threading, time
+import os as _os
+_os.environ.setdefault("HAVC_PRECISION", "fast")      # this tool measures the fast (fp16) mode unless told otherwise; the package default is "precise"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from vsdeoldify_amd.device import DeviceImage

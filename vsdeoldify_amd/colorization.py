@@ -12,6 +12,7 @@ import threading
 import numpy as np
 
 from . import _native as nat
+from .precision import DEFAULT_PRECISION, resolve as resolve_precision
 from .render import get_context
 from .zhang_net import ZhangGenerator
 
@@ -34,12 +35,10 @@ class ModelColorization:
     def __init__(self, model="siggraph17", use_gpu=True, device_index=0, state_dict=None, max_batch=1, coalesce=0, precision=None):
         """coalesce = N > 0: colorize_frame calls made concurrently by N threads are merged into batches (havc_batcher, kind 2).
         precision: "fast" (fp16 activations, fp32 accumulation) or "precise" (fp32-class arithmetic like the reference, which runs the nets in fp32,
-        colorization/__init__.py:76-95: hi / lo fp16 pairs, three-segment convs, fp32 softmax / tanh projection); None reads HAVC_PRECISION."""
+        colorization/__init__.py:76-95: hi / lo fp16 pairs, three-segment convs, fp32 softmax / tanh projection); None reads HAVC_PRECISION, then the package default "precise" (precision.py)."""
         if not use_gpu:
             raise nat.NativeLibraryError("vsdeoldify_amd.ModelColorization is MI355X only (use_gpu=False is not supported)")
-        precision = precision or os.environ.get("HAVC_PRECISION", "fast")
-        if precision not in ("fast", "precise"):
-            raise ValueError(f"precision must be 'fast' or 'precise', not {precision!r}")
+        precision = resolve_precision(precision)                  # explicit > HAVC_PRECISION > "precise" (vsdeoldify_amd/precision.py)
         if self._initialized and self.colorizer_model == model and state_dict is None and getattr(self, "precision", "fast") == precision:
             return
         if self._initialized:

@@ -127,7 +127,9 @@ __device__ __forceinline__ void epilogue_frag_precise(const ConvArgs& p, const f
 // one 16x16 accumulator fragment -> fused epilogue -> store.  lane owns pixel m, channels n..n+3.
 // PRECISE is a COMPILE-TIME switch: the precise epilogue lives in kernel instantiations of its own, the fast kernels carry none of its
 // code (a run-time branch here cost the dominant fast kernel 60 % -- register allocation of the whole kernel changed).
-template <bool PRECISE = false>
+// UNIT_STEP: the caller knows the op's out step is 1 (the compile-time-flag kernels are only launched then): the output pixel IS the GEMM row, and the
+// reciprocals of out_pixel's divisions need not stay live across the main loop (round 6: one of them was the tail conv's only spilled register)
+template <bool PRECISE = false, bool UNIT_STEP = false>
 __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v acc, int m, int n, int HoWo, const int flags) {
     if (m >= p.M || n >= p.Npad) return;
     if (PRECISE) { epilogue_frag_precise(p, acc, m, n, HoWo); return; }
@@ -179,7 +181,7 @@ __device__ __forceinline__ void epilogue_frag(const ConvArgs& p, const float4v a
         return;
     }
     if (n >= p.Co) return;
-    const int64_t mo = out_pixel(p, m, HoWo);
+    const int64_t mo = UNIT_STEP ? (int64_t)m : out_pixel(p, m, HoWo);
     if (flags & HAVC_F_RESIDUAL) {
         // Same rounding points as the LDS epilogue of the pipelined kernels (conv_pipe_epilogue.inc): the conv result is rounded
         // to fp16 BEFORE the residual is added (and once more after), so every tile configuration produces the same bytes and a

@@ -250,6 +250,7 @@ __global__ void __launch_bounds__(512) conv_halo_kernel(const ConvArgs p) {
 #define PF(mi) (mi)
 #define HAVC_STAMP(i) do { } while (0)
     const int eflags = p.flags;
+    constexpr bool UNIT_STEP = false;                                   // (identity either way; true changes this kernel's register allocation for the worse: 12 spills)
     auto opix = [&](int m) -> int64_t { return (int64_t)m; };          // launch_halo requires out step 1
 #include "conv_pipe_epilogue.inc"
 #undef PF
@@ -295,7 +296,6 @@ static int launch_pipe(const ConvArgs& a, hipStream_t s) {
     if ((a.Kc & 7) || !a.ktab || a.x_bytes == 0 || a.x_bytes >= OOB || a.w_bytes >= OOB || (EXTRA && a.Npad != G::BN + 16)) return (int)hipErrorInvalidValue;
     const int MT = (a.M + G::BM - 1) / G::BM, NT = (a.Npad - 16 * EXTRA + G::BN - 1) / G::BN;
     const int SK = a.splitk > 1 ? a.splitk : 1;
-    if (SK > 1 && a.sk_cnt && MT * NT > HAVC_SK_COUNTERS) return (int)hipErrorInvalidValue;
     if (SK > 1 && (EXTRA || ABL || !a.ws || (a.Kc >> 3) < 2 * SK || (a.Npad & 3) ||
                    (a.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_FUSE_PROJ | HAVC_F_W_FROM_BUF))))
         return (int)hipErrorInvalidValue;
@@ -305,7 +305,7 @@ static int launch_pipe(const ConvArgs& a, hipStream_t s) {
     ensure_lds_optin<conv_pipe_kernel<WM, WN, FM, EXTRA, ABL, EF>>(LDS);
     hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, ABL, EF>), dim3(MT * NT * SK), dim3(G::NW * 64), LDS, s, a);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess || SK == 1 || a.sk_cnt) return (int)e;          // sk_cnt: the last block of every tile has reduced the parts and run the epilogue
+    if (e != hipSuccess || SK == 1) return (int)e;
     const int64_t work = (int64_t)a.M * (a.Npad >> 2);
     const int64_t gb = (work + 255) / 256;
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(gb > 8192 ? 8192 : gb)), dim3(256), 0, s, a);

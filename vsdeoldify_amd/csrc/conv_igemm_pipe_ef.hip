@@ -23,11 +23,10 @@ int launch_ef(const ConvArgs& a, hipStream_t s) {
     using G = Geo<WM, WN, FM, EXTRA>;
     if ((a.Kc & 7) || !a.ktab || a.x_bytes == 0 || a.x_bytes >= OOB || a.w_bytes >= OOB || (EXTRA && a.Npad != G::BN + 16)) return (int)hipErrorInvalidValue;
     const int MT = (a.M + G::BM - 1) / G::BM, NT = (a.Npad - 16 * EXTRA + G::BN - 1) / G::BN;
-    const int SK = a.splitk > 1 ? a.splitk : 1;            // split-K with in-kernel reduction (ConvArgs::sk_cnt): a block per (tile, K part)
-    if (SK > 1 && (EXTRA || !a.sk_cnt || !a.ws || (a.Kc >> 3) < 2 * SK || (a.Npad & 3) || MT * NT > HAVC_SK_COUNTERS)) return (int)hipErrorInvalidValue;
+    if (a.splitk > 1) return (int)hipErrorInvalidValue;   // split-K main loops store raw partial sums and never reach an epilogue: the run-time-flag kernel serves them
     constexpr int LDS = G::LDS_BYTES;
     ensure_lds_optin<conv_pipe_kernel<WM, WN, FM, EXTRA, 0, EF>>(LDS);
-    hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, 0, EF>), dim3(MT * NT * SK), dim3(G::NW * 64), LDS, s, a);
+    hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, 0, EF>), dim3(MT * NT), dim3(G::NW * 64), LDS, s, a);
     return (int)hipGetLastError();
 }
 
@@ -75,8 +74,7 @@ void preload_conv_pipe_ef2();
 // -1: no specialised kernel for this (tile configuration, layer kind) -- the caller launches the run-time-flag kernel
 int launch_conv_pipe_ef(const ConvArgs& a, int cfg, hipStream_t s) {
     static const bool on = [] { const char* e = getenv("HAVC_EPI_SPECIAL"); return !e || atoi(e) != 0; }();
-    if (!on || (a.flags & HAVC_F_PRECISE) || (a.splitk > 1 && !a.sk_cnt) || a.oss != 1) return -1;
-    if (a.splitk > 1 && (a.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_RGB8 | HAVC_F_FUSE_PROJ | HAVC_F_W_FROM_BUF))) return -1;
+    if (!on || (a.flags & HAVC_F_PRECISE) || a.splitk > 1 || a.oss != 1) return -1;
     const int ef = a.flags & HAVC_EPI_MASK;
 #define X(WM, WN, FM, EX, EF) if (cfg == geo_cfg(WM, WN, FM, EX) && ef == (EF)) return launch_ef<WM, WN, FM, EX, (EF)>(a, s);
     HAVC_EF_ALL(X)

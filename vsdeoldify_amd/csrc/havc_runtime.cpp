@@ -120,7 +120,6 @@ struct havc_ctx {
     size_t scratch_sz[18] = {0};           // memory reads), 12 / 13 split-K partial sums of the launches on stream / stream2, 14-17 the BANKED memory read of the
                                            // ColorMNet frame loop (similarity map, top-k indices / weights, usage accumulators): its own slots, because a read that
                                            // runs ahead leaves its top-k lists there until its frame is stepped -- no other entry point may touch them meanwhile
-    int* sk_cnt[2] = {nullptr, nullptr};   // split-K arrival counters of the launches on stream / stream2 (HAVC_SK_COUNTERS ints each, all zero between launches)
     hipStream_t stream_h2d = nullptr, stream_d2h = nullptr;      // copy streams of havc_colorize_clip_host (created on first use)
     hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_comp[2] = {nullptr, nullptr}, ev_down[2] = {nullptr, nullptr};
     std::map<std::pair<int, int>, ResizeTable> resize_tables;
@@ -440,12 +439,6 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                 const size_t need = (size_t)a.splitk * batch * op.Ho * op.Wo * op.Npad * 4;
                 if (int rc2 = ensure_scratch(c, slot, need)) return rc2;
                 a.ws = (float*)c->scratch[slot];
-                // round 5 experiment, OFF by default: HAVC_SPLITK_FUSED=1 lets the last block of a tile reduce the parts and run the epilogue itself (no second
-                // launch).  Same bytes -- but the agent-scope release every block needs in front of its arrival count writes back its XCD's L2, and a
-                // low-latency DeOldify frame went 6.2 -> 13.2 ms, ColorMNet 885 -> 590 frames/s (profiles/r5_splitk_fused_ab.txt): the separate
-                // 5 us reduce launch is the cheaper form on this part.
-                static const bool fused = [] { const char* e = getenv("HAVC_SPLITK_FUSED"); return e ? atoi(e) != 0 : false; }();
-                a.sk_cnt = fused ? c->sk_cnt[slot - 12] : nullptr;
             }
             {
                 const int oi = (int)(&op - n->ops.data());
@@ -1013,13 +1006,6 @@ int havc_create(havc_ctx** out, int device_id) {
         delete c;
         return fail(nullptr, HAVC_E_HIP, "failed to create stream/events");
     }
-    for (int k = 0; k < 2; ++k) {
-        if (hipMalloc(&c->sk_cnt[k], HAVC_SK_COUNTERS * sizeof(int)) != hipSuccess || hipMemset(c->sk_cnt[k], 0, HAVC_SK_COUNTERS * sizeof(int)) != hipSuccess) {
-            (void)hipGetLastError();
-            havc_destroy_unlocked(c);
-            return fail(nullptr, HAVC_E_HIP, "failed to allocate the split-K counters");
-        }
-    }
     static const bool eager = [] { const char* e = getenv("HAVC_EAGER_SETUP"); return e ? atoi(e) != 0 : true; }();
     if (eager) {
         preload_device_locked(device_id);
@@ -1052,8 +1038,6 @@ static void havc_destroy_unlocked(havc_ctx* c) {
     }
     for (int i = 0; i < 18; ++i)
         if (c->scratch[i]) (void)hipFree(c->scratch[i]);
-    for (int k = 0; k < 2; ++k)
-        if (c->sk_cnt[k]) (void)hipFree(c->sk_cnt[k]);
     for (auto& kv : c->resize_tables) { (void)hipFree(kv.second.d_start); (void)hipFree(kv.second.d_w); }
     for (auto& p : c->tag_events) { (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second); }
     (void)hipEventDestroy(c->ev0);

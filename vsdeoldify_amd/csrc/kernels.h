@@ -42,12 +42,9 @@ struct ConvArgs {
     int prio;              // 1: static s_setprio 1 for the younger half of an 8-wave block (HAVC_SETPRIO, default on)
     int splitk;            // > 1: the K range is cut into `splitk` parts, one block per (tile, part) stores its fp32 partial sums to `ws`
     float* ws;             //      [splitk][M][Npad]; splitk_reduce_kernel adds them in a fixed order and runs the usual epilogue
-    int* sk_cnt;           // split-K, round 5: per-tile arrival counters (all zero between launches) -> the last block of a tile reduces the parts and runs the
-                           //      epilogue in the conv kernel itself; null = the parts are reduced by splitk_reduce_kernel in a second launch
     float pscale;          // HAVC_F_PRECISE: the accumulator is this factor away from the convolution (2^-11 x the weight pre-scale, op.f3)
 };
 #define HAVC_KTAB_PAD_DH 0x7fff
-#define HAVC_SK_COUNTERS 65536     // arrival counters per stream (ConvArgs::sk_cnt): split-K convs have < 128 output tiles by construction
 
 // returns hipError_t as int
 int launch_conv(const ConvArgs& a, hipStream_t s);

@@ -10,6 +10,7 @@ import threading
 import numpy as np
 
 from . import _native as nat
+from .precision import DEFAULT_PRECISION, resolve as resolve_precision
 from .ddcolor_net import DDColorGenerator
 from .render import get_context
 
@@ -125,10 +126,8 @@ class DDColorRender:
             state_dict = load_state_dict(os.path.join(model_dir, self.MODEL_FILES[model]))
         # worker: which context of the GPU the model lives on (render.get_context): a caller that runs DDColor next to another model (HAVC's
         # DeOldify + DDColor methods) gives it a context of its own, i.e. its own HIP stream
-        # precision: "fast" (fp16 activations) / "precise" (fp32-class arithmetic on hi / lo pairs, ddcolor_net.DDColorGenerator); None reads HAVC_PRECISION
-        self.precision = precision or os.environ.get("HAVC_PRECISION", "fast")
-        if self.precision not in ("fast", "precise"):
-            raise ValueError(f"precision must be 'fast' or 'precise', not {self.precision!r}")
+        # precision: "fast" (fp16 activations) / "precise" (fp32-class arithmetic on hi / lo pairs, ddcolor_net.DDColorGenerator); None reads HAVC_PRECISION, then the package default "precise" (precision.py)
+        self.precision = resolve_precision(precision)            # explicit > HAVC_PRECISION > "precise" (vsdeoldify_amd/precision.py)
         self.rt = DDColorRuntime(get_context(device_index, worker), state_dict, depths, dec_layers, precision=self.precision)
         self._coalesce, self._batchers = coalesce, {}
         # num_streams (vsddcolor's parameter, vsslib/vsmodels.py:356; the reference's callers leave it at 1): clips of >= 8 frames are cut into

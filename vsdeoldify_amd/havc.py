@@ -24,6 +24,7 @@ import os
 import numpy as np
 
 from . import _native as nat
+from .precision import DEFAULT_PRECISION, resolve as resolve_precision
 from . import imfilters as F
 from . import mcomb
 from .device import DeviceImage, is_device
@@ -62,10 +63,11 @@ class HAVCFrameColorizer:
                  ddcolor_model_dir=None, state_dicts=None, ddcolor_state_dict=None, zhang_state_dict=None, max_batch=1,
                  ddcolor_kwargs=None, ddtweak=(False, False, False), ddtweak_p=(DEF_TWEAK_p, "none"), precision=None):
         """precision: "fast" / "precise" for EVERY model of the graph (DeOldify, DDColor, the Zhang colorizers): the reference runs them all in fp32
-        (deoldify/filters.py:45-68, vsslib/vsmodels.py:353-363, colorization/__init__.py:76-95); None reads HAVC_PRECISION (default "fast")."""
-        self.precision = precision or os.environ.get("HAVC_PRECISION", "fast")
-        if self.precision not in ("fast", "precise"):
-            raise HAVCError(f"HAVC: precision must be 'fast' or 'precise', not {self.precision!r}")
+        (deoldify/filters.py:45-68, vsslib/vsmodels.py:353-363, colorization/__init__.py:76-95); None reads HAVC_PRECISION, then the package default "precise" (vsdeoldify_amd/precision.py)."""
+        try:
+            self.precision = resolve_precision(precision)        # explicit > HAVC_PRECISION > "precise" (vsdeoldify_amd/precision.py)
+        except ValueError as e:
+            raise HAVCError(f"HAVC: {e}") from None
         # ---- __init__.py:2452-2462: method <-> merge weight normalisation ----
         merge_weight = 0.0 if method == 0 else (1.0 if method == 1 else mweight)
         if merge_weight == 0.0:
@@ -358,7 +360,7 @@ def HAVC_colorizer(clip, method=2, mweight=0.4, deoldify_p=(0, 24, 1.0, 0.0), dd
     flags = tuple(ddtweak) if isinstance(ddtweak, (list, tuple)) else (ddtweak, False, False)
     key = (method, mweight, tuple(deoldify_p), tuple(ddcolor_p), tuple(cmc), tuple(lmm_p), tuple(alm_p), tuple(crt_p), cmb_sw, device_index,
            torch_dir, id(harness.get("state_dicts")), id(harness.get("ddcolor_state_dict")), harness.get("max_batch", 1), flags, repr(ddtweak_p),
-           harness.get("precision") or os.environ.get("HAVC_PRECISION", "fast"))
+           harness.get("precision") or os.environ.get("HAVC_PRECISION") or DEFAULT_PRECISION)
     col = _colorizers.get(key)
     if col is None:
         col = HAVCFrameColorizer(method, mweight, deoldify_p, ddcolor_p, cmc, lmm_p, alm_p, crt_p, cmb_sw, device_index, package_dir=torch_dir,

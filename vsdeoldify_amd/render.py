@@ -15,6 +15,7 @@ import threading
 import numpy as np
 
 from . import _native as nat
+from .precision import DEFAULT_PRECISION, resolve as resolve_precision
 from .deoldify_net import DeoldifyGenerator
 
 WEIGHTS = {"video": ("ColorizeVideo_gen", "wide"), "stable": ("ColorizeStable_gen", "wide"),
@@ -102,7 +103,7 @@ class ModelImageRender:
                  state_dicts=None, max_batch=1, worker=0, coalesce=0, precision=None, low_latency=None):
         """`precision`: "fast" (default: fp16 activations and MFMA operands, fp32 accumulation: CIEDE2000 against the reference's fp32 path small
         in the mean but p99 1.2 - 2.3 on the final image) or "precise" (fp32-class arithmetic like the reference,
-        deoldify/filters.py:45-68: hi / lo fp16 pairs on the same MFMA kernels, 3x the matrix work); None reads HAVC_PRECISION.
+        deoldify/filters.py:45-68: hi / lo fp16 pairs on the same MFMA kernels, 3x the matrix work); None reads HAVC_PRECISION, then the package default "precise" (precision.py).
         `low_latency` (None reads HAVC_LOW_LATENCY, default off): a render that colours ONE frame per call (max_batch <= 2: the reference's call
         shape, vsslib/vsmodels.py:219-230) builds its nets with split-K convs -- a single frame gives most layers 5 - 40 tiles for 256 CUs; bytes
         differ from the batched nets in fp32 summation order only.  Round 5 measured that difference on three weight sets (tests/test_gpu_deoldify.py):
@@ -122,9 +123,7 @@ class ModelImageRender:
         self._coalesce = coalesce
         self._batchers = {}
         self._low_latency = (os.environ.get("HAVC_LOW_LATENCY", "0") != "0") if low_latency is None else bool(low_latency)
-        self._precision = precision or os.environ.get("HAVC_PRECISION", "fast")
-        if self._precision not in ("fast", "precise"):
-            raise ValueError(f"precision must be 'fast' or 'precise', not {self._precision!r}")
+        self._precision = resolve_precision(precision)           # explicit > HAVC_PRECISION > "precise" (vsdeoldify_amd/precision.py)
         self.ctx = get_context(device_index, worker)
         second = None if modelname == "video" else ("stable" if modelname == "stable" else "artistic")
         self._video = self._runtime("video", state_dicts)
