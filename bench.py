@@ -404,7 +404,7 @@ def main():
             cc = None
         except Exception:                               # noqa: BLE001
             pass
-        for pb in (32, 16):
+        for pb in ((48, 32, 16) if os.environ.get('HAVC_BENCH_PRECISE_48') else (32, 16)):
             try:
                 _progress(f"precise leg ({pb} frames per step)")
                 out["precise"], cc_precise = precise_leg(args, sds, local_rank, frames, fbytes, batch=pb)
