@@ -211,3 +211,31 @@ def test_colorize_clip_1080p_8_frames_3_weight_sets_precise_meets_the_contract(c
         de = np.concatenate(pooled[mode])
         print(f"pooled {mode}: mean {de.mean():.4f} p99 {np.percentile(de, 99):.3f} dE<1 {float((de < 1).mean()):.5f}")
         assert np.percentile(de, 99) < lim["p99"] and (de < 1.0).mean() >= lim["frac_lt1"] and (mode == "precise" or de.mean() < lim["mean"])
+
+
+@pytest.mark.parametrize("S", [272, 320])
+def test_precise_fused_shuffle_blur_is_bit_identical(ctx, S):
+    """round 6: HAVC_F_PS_BLUR in precise form (1x1 conv + PixelShuffle + blur on hi / lo pairs in one kernel, two 32-channel passes through the LDS image;
+    CustomPixelShuffle_ICNR, vsdeoldify/deoldify/unet.py:24-52) must give exactly the bytes of the conv -> pair tensor -> blur_resize_p chain: the same
+    rounding of the shuffled value to its pair, the same fp32 window sum.  Compared on the tail tensor itself (hi and lo planes of the 256 blurred channels,
+    every frame) and on the generator's raw colour.  272: a last tile of one useful row + clamping; 320: 160 low-res rows."""
+    from vsdeoldify_amd.render import GeneratorRuntime
+    sd = synth_state_dict("wide", 1)
+    frames = np.stack([make_frame(S, 40), make_frame(S, 41)])
+    outs, tails = [], []
+    for fuse in (True, False):
+        rt = GeneratorRuntime(ctx, sd, "wide", fuse_blur=fuse, precision="precise")
+        try:
+            net = rt.net(S, 2)
+            names = list(net.names)
+            assert ("layers.8+blur" in names) == fuse and ("layers.8.blur" in names) != fuse
+            outs.append(raw_gpu(ctx, rt, frames))
+            ops, _, _, _, _ = rt.gen.plan(S)
+            op = ops[names.index("layers.8+blur" if fuse else "layers.8.blur")]
+            pitch = int(op["dst_cpitch"])
+            t = net.download(int(op["dst"]), (2, S, S, pitch), np.float16)
+            tails.append(np.concatenate([t[..., :256], t[..., pitch // 2:pitch // 2 + 256]], -1).copy())     # hi | lo planes of the blurred channels
+        finally:
+            rt.close()
+    assert np.array_equal(tails[0].view(np.uint16), tails[1].view(np.uint16)), float((tails[0] != tails[1]).mean())
+    assert np.array_equal(outs[0], outs[1])

@@ -426,7 +426,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             if (a.splitk == 1) a.splitk = 0;
             a.pscale = 1.f;
             if (op.flags & HAVC_F_PRECISE) {
-                if ((op.flags & (HAVC_F_PS_BLUR | HAVC_F_FUSE_PROJ | HAVC_F_W_FROM_BUF)) || a.splitk ||
+                if ((op.flags & (HAVC_F_FUSE_PROJ | HAVC_F_W_FROM_BUF)) || a.splitk ||
                     !(op.f3 > 0.f) || (op.src_cpitch & 15) || (!(op.flags & HAVC_F_OUT_RGB8) && (op.dst_cpitch & 15)))
                     return fail(c, HAVC_E_INVALID, "conv op: PRECISE needs a plain conv (no fused / transposed / split-K form), f3 = accumulator scale > 0, hi|lo pixel rows");
                 a.pscale = op.f3;

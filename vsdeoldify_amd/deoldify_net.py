@@ -53,11 +53,13 @@ class DeoldifyGenerator:
     def __init__(self, state_dict, arch="wide", fuse_final=True, fuse_blur=True, precision="fast"):
         """precision: "fast" = fp16 activations / fp16 MFMA operands / fp32 accumulate; "precise" = fp32-class arithmetic
         like the reference's (deoldify/filters.py:45-68): hi / lo fp16 pairs, three-segment convs, fp32 attention (HAVC_F_PRECISE), the
-        op-by-op plan (no fused shuffle+blur / RGB8 epilogues)."""
+        same fusions as the fast plan (shuffle + blur since round 6, layers.11 + SigmoidRange + u8 since round 5) with fp32 epilogues."""
         assert arch in RESNET and precision in ("fast", "precise")
         self.precise = precision == "precise"
         if self.precise:
-            fuse_blur = False                  # (the fused shuffle + blur epilogue keeps its tile image in LDS as fp16: pairs would need 256 KiB)
+            # round 6: the fused shuffle + blur epilogue exists for pairs too (two passes of 32 channels through the 128 KiB LDS image,
+            # conv_pipe_epilogue.inc); HAVC_PRECISE_FUSE_BLUR=0 keeps the two-op chain (A/B runs; same bytes)
+            fuse_blur = fuse_blur and os.environ.get("HAVC_PRECISE_FUSE_BLUR", "1") != "0"
             fuse_final = fuse_final and os.environ.get("HAVC_PRECISE_FUSE_FINAL", "1") != "0"      # round 5: layers.11 + SigmoidRange + u8 in the precise epilogue
         self.sd, self.arch, self.fuse_final, self.fuse_blur = to_np(state_dict), arch, fuse_final, fuse_blur
         self.pack, self._pc, self._vec = WeightPack(), {}, {}

@@ -213,7 +213,6 @@ def pack_conv(pack, W, cmap, Ci, bias=None, scale=None, shift=None, pixshuf=Fals
     flat = np.concatenate(segs, axis=1)
     pscale = 0.0
     if precise:
-        assert not pixshuf or pixshuf is True, "precise convs use the plain pixel-shuffle row order"
         flat, pscale = split_weights(flat)
     flat = flat.astype(np.float16)
     Kc = flat.shape[1] // 8
