@@ -66,6 +66,28 @@ def test_precise_layernorm_dwconv_gelu(ctx, C, hw):
     close32(gu.hl_unpack(out[y4.buf], Co), pw.float().numpy(), "1x1 conv + GELU")
 
 
+@pytest.mark.parametrize("C,hw,B", [(192, (9, 7), 2), (384, (13, 18), 1), (768, (5, 6), 3), (192, (32, 32), 2)])
+def test_precise_fused_dwconv7_layernorm(ctx, C, hw, B):
+    """round 6: the ConvNeXt block head (depthwise 7x7 + bias, then LayerNorm over the channels; convnext.py Block: dwconv, norm -- the wheel runs it in fp32,
+    vsslib/vsmodels.py:353-363) as ONE kernel on pair tensors (HAVC_OP_DWCONV7_LN with HAVC_F_PRECISE: dwconv7_ln_kernel<..., PREC>) against torch in float64,
+    at the tolerance of the two-kernel precise chain (2e-5); ragged patch grids (sizes that are not multiples of the 4 x 4 patch), borders on every side."""
+    H, W = hw
+    r = np.random.default_rng(C + H + B)
+    x = (r.standard_normal((B, C, H, W)) * 2 + 0.3).astype(np.float32)
+    g, be = (1 + 0.2 * r.standard_normal(C)).astype(np.float32), (0.1 * r.standard_normal(C)).astype(np.float32)
+    wd, bd = (r.standard_normal((C, 1, 7, 7)) / 7).astype(np.float32), (0.1 * r.standard_normal(C)).astype(np.float32)
+    pack, b = WeightPack(), PlanBuilder(precise=True)
+    xv, y = b.tensor(H, W, C), b.tensor(H, W, C)
+    wp = np.zeros((49, xv.span), np.float32)
+    wp[:, :C] = wd.reshape(C, 49).T
+    b.dwconv7_ln("dwln", xv, y, pack.add(wp), pack.add(bd), xv.span, pack.add(g), pack.add(be), 1e-6)
+    out = gu.run_plan(ctx, pack, b, {xv.buf: gu.hl_pack(x, xv.cpitch)}, {y.buf: _shape(y, B)}, B)
+    xt = torch.from_numpy(x).double()
+    dw = F.conv2d(xt, torch.from_numpy(wd).double(), torch.from_numpy(bd).double(), padding=3, groups=C)
+    ref = F.layer_norm(dw.permute(0, 2, 3, 1), (C,), torch.from_numpy(g).double(), torch.from_numpy(be).double(), 1e-6).permute(0, 3, 1, 2)
+    close32(gu.hl_unpack(out[y.buf], C), ref.float().numpy(), "fused depthwise 7x7 + LayerNorm (precise)", rtol=2e-5)
+
+
 @pytest.mark.parametrize("Lk_hw", [(10, 10), (24, 24), (5, 13)])
 def test_precise_multihead_attention(ctx, Lk_hw):
     """nn.MultiheadAttention core (8 heads x 32) on pair buffers: 100 queries of a 112-token frame, keys = pixels of a feature map (K at +0, V at +256

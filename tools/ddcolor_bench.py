@@ -13,7 +13,7 @@ ctx = get_context(0)
 t = time.time()
 sd = synth_ddcolor_state_dict(1)
 print(f"synth {time.time()-t:.1f}s"); t = time.time()
-rt = DDColorRuntime(ctx, sd)
+rt = DDColorRuntime(ctx, sd, precision=os.environ.get("PRECISION", "fast"))       # PRECISION=precise: the fp32-class plan
 print(f"pack+upload {time.time()-t:.1f}s, {len(rt.gen.blob)/1e6:.0f} MB"); t = time.time()
 net = rt.net(S, batch)
 print(f"net {time.time()-t:.1f}s, {len(net.plan_ops)} ops, {net.plan_ops['flops'].sum()/1e9:.1f} GFLOP/frame")

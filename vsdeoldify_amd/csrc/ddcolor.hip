@@ -194,6 +194,11 @@ __device__ __forceinline__ float dw_group_sum(float v) {      // 8-lane sums, or
     return v;
 }
 
+__device__ __forceinline__ void split_hl_dd(float v, half_t& hi, half_t& lo) {      // conv_common.h split_hl (this unit does not include it)
+    hi = (half_t)v;
+    lo = (half_t)((v - (float)hi) * 2048.f);
+}
+
 constexpr int DWLN_T = 4, DWLN_R = 4;
 constexpr unsigned DWLN_OOB = 0xF0000000u;        // voffset beyond every descriptor range: the buffer load returns zeros
 static inline size_t dwln_lds_bytes(int C, bool wf32, int threads) {
@@ -205,8 +210,10 @@ typedef unsigned int uint2e __attribute__((ext_vector_type(2)));
 // C4 (channel groups of 4) is a template parameter so that the 49 LDS weight offsets are immediates, not 49 live registers.
 // THREADS / PAIR: 768 threads (3 waves per SIMD, <= 168 VGPRs) with one output row per step, or 512 threads (2 per SIMD, 256 VGPRs)
 // with two output rows per step (a step then covers the LDS latency by itself) -- picked per channel count by measurement.
-template <int C4, bool WF32, int THREADS, bool PAIR>
-__global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __restrict__ x, const half_t* __restrict__ w,
+// PREC (round 6): the precise form (HAVC_F_PRECISE; the wheel's torch modules run in fp32, vsslib/vsmodels.py:353-363): x and y are hi / lo pair tensors (pixel row =
+// [hi: P | lo: P], cpitch = 2 P), the weights are fp32 [49][w_pitch] in the blob and in LDS; the arithmetic between load and store is the fp32 of the fast form.
+template <int C4, bool WF32, int THREADS, bool PAIR, bool PREC = false>
+__global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __restrict__ x, const void* __restrict__ w_,
                                                                    const float* __restrict__ bias, const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, float eps, half_t* __restrict__ y, int B,
                                                                    int H, int W, unsigned x_bytes, int x_cpitch, int x_coff, int y_cpitch,
@@ -215,6 +222,8 @@ __global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __res
     constexpr bool WAVE_SUM = (C4 % 64 == 0);                  // a patch's threads are whole waves: LayerNorm partials per wave (DPP + 2 shuffles), not per 8 lanes
     constexpr int C = C4 * 4, S = THREADS / C4, G = WAVE_SUM ? C4 / 64 : C4 / 8;
     constexpr int WB = WF32 ? 16 : 8;                         // bytes of one thread's weights per tap
+    static_assert(!PREC || WF32, "precise: fp32 weights in LDS");
+    const half_t* w = reinterpret_cast<const half_t*>(w_);
     extern __shared__ __attribute__((aligned(16))) char dw_smem[];
     const int tid = threadIdx.x;
     const int c4 = tid % C4, strip = tid / C4;
@@ -223,6 +232,21 @@ __global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __res
     float* red = reinterpret_cast<float*>(dw_smem + (size_t)49 * C4 * WB);
     {   // all of a thread's weight loads in flight at once (the block has a single pass over them: a serial loop costs ~1 us per trip)
         constexpr int NW_IT = (49 * C4 + THREADS - 1) / THREADS;
+        if constexpr (PREC) {
+            const float* wf = reinterpret_cast<const float*>(w_);
+            float4e fv[NW_IT];
+#pragma unroll
+            for (int k = 0; k < NW_IT; ++k) {
+                const int i = tid + k * THREADS, tap = i / C4, cc = i - tap * C4;
+                fv[k] = float4e{0.f, 0.f, 0.f, 0.f};
+                if (i < 49 * C4) fv[k] = *reinterpret_cast<const float4e*>(wf + (size_t)tap * w_pitch + cc * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < NW_IT; ++k) {
+                const int i = tid + k * THREADS;
+                if (i < 49 * C4) *reinterpret_cast<float4e*>(dw_smem + (size_t)i * 16) = fv[k];
+            }
+        } else {
         half4 hv[NW_IT];
 #pragma unroll
         for (int k = 0; k < NW_IT; ++k) {
@@ -237,6 +261,7 @@ __global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __res
                 if (WF32) *reinterpret_cast<float4e*>(dw_smem + (size_t)i * 16) = __builtin_convertvector(hv[k], float4e);
                 else *reinterpret_cast<half4*>(dw_smem + (size_t)i * 8) = hv[k];
             }
+        }
         }
     }
     __syncthreads();
@@ -282,13 +307,17 @@ __global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __res
 #pragma unroll
         for (int j = 0; j < XR; ++j) colmask |= ((unsigned)(wo0 + j - 3) < (unsigned)W ? 1u : 0u) << j;
         if (!valid) colmask = 0;
-        auto load_row = [&](int r, uint2e (&dst)[XR]) {
+        constexpr int NPL = PREC ? 2 : 1;                        // planes per pixel: hi (+ lo, x_cpitch BYTES = half a pixel row behind it)
+        auto load_row = [&](int r, uint2e (&dst)[NPL][XR]) {
             const int hi = ho0 + r - 3;
             const bool rok = (unsigned)hi < (unsigned)H;
             const unsigned rowoff = col0 + (unsigned)hi * (unsigned)W * pix_bytes;
 #pragma unroll
-            for (int j = 0; j < XR; ++j)
-                dst[j] = __builtin_amdgcn_raw_buffer_load_b64(rx, (rok && ((colmask >> j) & 1)) ? rowoff + (unsigned)j * pix_bytes : DWLN_OOB, 0, 0);
+            for (int j = 0; j < XR; ++j) {
+                const unsigned vo = (rok && ((colmask >> j) & 1)) ? rowoff + (unsigned)j * pix_bytes : DWLN_OOB;
+                dst[0][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, vo, 0, 0);
+                if constexpr (PREC) dst[1][j] = __builtin_amdgcn_raw_buffer_load_b64(rx, vo, (unsigned)x_cpitch, 0);      // (soffset: an out-of-range voffset stays out of range)
+            }
         };
         float2v acc[T][R][2];
 #pragma unroll
@@ -299,7 +328,7 @@ __global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __res
             if (WF32) return *reinterpret_cast<const float4e*>(p);
             return __builtin_convertvector(*reinterpret_cast<const half4*>(p), float4e);
         };
-        uint2e nxt[XR];
+        uint2e nxt[NPL][XR];
         load_row(0, nxt);
         // Per input row: convert it, start the loads of the next one, then for every output row t it feeds (tap row dy = r - t) seven
         // steps of one LDS weight read (issued one step ahead) + 2R packed FMAs.  The sched_barriers pin that order: left alone,
@@ -309,7 +338,8 @@ __global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __res
             float2v xr[XR][2];
 #pragma unroll
             for (int j = 0; j < XR; ++j) {
-                const float4e f = __builtin_convertvector(__builtin_bit_cast(half4, nxt[j]), float4e);
+                float4e f = __builtin_convertvector(__builtin_bit_cast(half4, nxt[0][j]), float4e);
+                if constexpr (PREC) f += __builtin_convertvector(__builtin_bit_cast(half4, nxt[1][j]), float4e) * (1.f / 2048.f);      // join_hl: exact product, one rounding
                 xr[j][0][0] = f[0]; xr[j][0][1] = f[1]; xr[j][1][0] = f[2]; xr[j][1][1] = f[3];
             }
             if (r + 1 < T + 6) load_row(r + 1, nxt);
@@ -423,26 +453,34 @@ __global__ void __launch_bounds__(THREADS) dwconv7_ln_kernel(const half_t* __res
                     const int ho = ho0 + t, wo = wo0 + j;
                     if (ho >= H || wo >= W) continue;
                     const float rstd = __builtin_amdgcn_rsqf(part[t * R + j] * inv_c + eps);      // v_rsq_f32 (1 ulp); 1 / sqrtf was a 20-instruction division sequence, 16 times per thread
+                    const float of[4] = {acc[t][j][0][0] * rstd * g4.x + b4.x, acc[t][j][0][1] * rstd * g4.y + b4.y,
+                                         acc[t][j][1][0] * rstd * g4.z + b4.z, acc[t][j][1][1] * rstd * g4.w + b4.w};
+                    half_t* yp = y + ((int64_t)(b * H + ho) * W + wo) * y_cpitch + y_coff + c4 * 4;
                     half4 o;
-                    o[0] = (half_t)(acc[t][j][0][0] * rstd * g4.x + b4.x);
-                    o[1] = (half_t)(acc[t][j][0][1] * rstd * g4.y + b4.y);
-                    o[2] = (half_t)(acc[t][j][1][0] * rstd * g4.z + b4.z);
-                    o[3] = (half_t)(acc[t][j][1][1] * rstd * g4.w + b4.w);
-                    *reinterpret_cast<half4*>(y + ((int64_t)(b * H + ho) * W + wo) * y_cpitch + y_coff + c4 * 4) = o;
+                    if constexpr (PREC) {
+                        half4 ol;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { half_t a_, b_; split_hl_dd(of[e], a_, b_); o[e] = a_; ol[e] = b_; }
+                        *reinterpret_cast<half4*>(yp + (y_cpitch >> 1)) = ol;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = (half_t)of[e];
+                    }
+                    *reinterpret_cast<half4*>(yp) = o;
                 }
         }
     }
 }
 bool dwconv7_ln_supported(int C) { return C == 64 || C == 192 || C == 384 || C == 768 || C == 1536; }
 
-template <int C4, bool WF32, int THREADS, bool PAIR>
+template <int C4, bool WF32, int THREADS, bool PAIR, bool PREC = false>
 static void dwln_optin() {                                  // > 64 KiB of dynamic LDS: once per kernel instantiation and device
     static std::atomic<uint64_t> optin{0};
     int dev = 0;
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
     if (optin.load(std::memory_order_acquire) & bit) return;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv7_ln_kernel<C4, WF32, THREADS, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv7_ln_kernel<C4, WF32, THREADS, PAIR, PREC>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     optin.fetch_or(bit, std::memory_order_release);
 }
 // every instantiation launch_dwconv7_ln may pick: opted in eagerly from havc_create (see preload_elementwise)
@@ -452,19 +490,20 @@ void preload_ddcolor() {
     dwln_optin<96, true, 512, true>(); dwln_optin<96, true, 768, false>();
     dwln_optin<192, true, 512, true>(); dwln_optin<192, true, 768, false>();
     dwln_optin<384, false, 768, false>(); dwln_optin<384, false, 512, true>();
+    dwln_optin<48, true, 512, false, true>(); dwln_optin<96, true, 512, false, true>(); dwln_optin<192, true, 512, false, true>();      // precise
     (void)hipGetLastError();
 }
 
-template <int C4, bool WF32, int THREADS, bool PAIR>
-static int launch_dwln(const half_t* x, const half_t* w, const float* bias, const float* gamma, const float* beta, float eps, half_t* y, int B, int H,
+template <int C4, bool WF32, int THREADS, bool PAIR, bool PREC = false>
+static int launch_dwln(const half_t* x, const void* w, const float* bias, const float* gamma, const float* beta, float eps, half_t* y, int B, int H,
                        int W, unsigned x_bytes, int x_cpitch, int x_coff, int y_cpitch, int y_coff, int w_pitch, hipStream_t s) {
     constexpr int S = THREADS / C4;
     const size_t lds = dwln_lds_bytes(C4 * 4, WF32, THREADS);
     const int64_t total = (int64_t)B * ((H + DWLN_T - 1) / DWLN_T) * ((W + DWLN_R - 1) / DWLN_R);
     const int64_t need = (total + S - 1) / S;
     const int grid = (int)(need < 256 ? need : 256);
-    dwln_optin<C4, WF32, THREADS, PAIR>();
-    hipLaunchKernelGGL((dwconv7_ln_kernel<C4, WF32, THREADS, PAIR>), dim3(grid), dim3(THREADS), lds, s, x, w, bias, gamma, beta, eps, y, B, H, W, x_bytes,
+    dwln_optin<C4, WF32, THREADS, PAIR, PREC>();
+    hipLaunchKernelGGL((dwconv7_ln_kernel<C4, WF32, THREADS, PAIR, PREC>), dim3(grid), dim3(THREADS), lds, s, x, w, bias, gamma, beta, eps, y, B, H, W, x_bytes,
                        x_cpitch, x_coff, y_cpitch, y_coff, w_pitch);
     return (int)hipGetLastError();
 }
@@ -480,6 +519,23 @@ int launch_dwconv7_ln(const half_t* x, const half_t* w, const float* bias, const
         case 384: return variant == 1 ? launch_dwln<96, true, 512, true>(DWLN_ARGS) : launch_dwln<96, true, 768, false>(DWLN_ARGS);
         case 768: return variant == 1 ? launch_dwln<192, true, 512, true>(DWLN_ARGS) : launch_dwln<192, true, 768, false>(DWLN_ARGS);
         case 1536: return variant == 2 ? launch_dwln<384, false, 768, false>(DWLN_ARGS) : launch_dwln<384, false, 512, true>(DWLN_ARGS);
+    }
+#undef DWLN_ARGS
+    return (int)hipErrorInvalidValue;
+}
+
+// precise form: x / y pair tensors (cpitch = 2 P), fp32 weights [49][w_pitch]; the ConvNeXt widths whose fp32 weights fit the LDS (192 / 384 / 768 channels: 150 KB at 768;
+// the 1536-channel stage -- 16 x 16 pixels per frame -- keeps dwconv7_p + layernorm_p)
+bool dwconv7_ln_p_supported(int C) { return C == 192 || C == 384 || C == 768; }
+int launch_dwconv7_ln_p(const half_t* x, const float* w, const float* bias, const float* gamma, const float* beta, float eps, half_t* y, int B,
+                        int H, int W, int C, int x_cpitch, int x_coff, int y_cpitch, int y_coff, int w_pitch, hipStream_t s) {
+    const size_t xb = ((size_t)B * H * W * x_cpitch + x_coff) * 2;
+    if (!dwconv7_ln_p_supported(C) || xb >= DWLN_OOB || (x_cpitch & 1) || (y_cpitch & 1)) return (int)hipErrorInvalidValue;
+#define DWLN_ARGS x, w, bias, gamma, beta, eps, y, B, H, W, (unsigned)xb, x_cpitch, x_coff, y_cpitch, y_coff, w_pitch, s
+    switch (C) {
+        case 192: return launch_dwln<48, true, 512, false, true>(DWLN_ARGS);
+        case 384: return launch_dwln<96, true, 512, false, true>(DWLN_ARGS);
+        case 768: return launch_dwln<192, true, 512, false, true>(DWLN_ARGS);
     }
 #undef DWLN_ARGS
     return (int)hipErrorInvalidValue;

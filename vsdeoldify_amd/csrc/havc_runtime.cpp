@@ -630,6 +630,13 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
         case HAVC_OP_DWCONV7_LN:
             if (op.w_off < 0 || op.scale_off < 0 || op.shift_off < 0 || !dwconv7_ln_supported(op.Ci))
                 return fail(c, HAVC_E_INVALID, "dwconv7+layernorm op: weights / gamma / beta / channel count");
+            if (op.flags & HAVC_F_PRECISE) {                       // pair tensors, fp32 weights (round 6)
+                if (!dwconv7_ln_p_supported(op.Ci)) return fail(c, HAVC_E_INVALID, "dwconv7+layernorm op: the precise form exists for 192 / 384 / 768 channels");
+                e = launch_dwconv7_ln_p((const half_t*)bufptr(n, op.src), wptr<float>(n, op.w_off), wptr<float>(n, op.bias_off), wptr<float>(n, op.scale_off),
+                                        wptr<float>(n, op.shift_off), op.f0, (half_t*)bufptr(n, op.dst), batch, op.Hi, op.Wi, op.Ci, op.src_cpitch,
+                                        op.src_coff, op.dst_cpitch, op.dst_coff, op.Kc, s);
+                break;
+            }
             e = launch_dwconv7_ln((const half_t*)bufptr(n, op.src), wptr<half_t>(n, op.w_off), wptr<float>(n, op.bias_off), wptr<float>(n, op.scale_off),
                                   wptr<float>(n, op.shift_off), op.f0, (half_t*)bufptr(n, op.dst), batch, op.Hi, op.Wi, op.Ci, op.src_cpitch,
                                   op.src_coff, op.dst_cpitch, op.dst_coff, op.Kc, s);

@@ -202,6 +202,9 @@ int launch_proj2_p(const half_t* x, int x_cpitch, int x_coff, int C, const float
                    hipStream_t s);
 int launch_layernorm_p(const half_t* x, half_t* y, const float* gamma, const float* beta, float eps, int64_t npix, int C, int x_cpitch, int x_coff,
                        int y_cpitch, int y_coff, int relu, hipStream_t s);
+bool dwconv7_ln_p_supported(int C);      // precise fused dwconv 7x7 + LayerNorm (ddcolor.hip): 192 / 384 / 768 channels
+int launch_dwconv7_ln_p(const half_t* x, const float* w, const float* bias, const float* gamma, const float* beta, float eps, half_t* y, int B,
+                        int H, int W, int C, int x_cpitch, int x_coff, int y_cpitch, int y_coff, int w_pitch, hipStream_t s);
 int launch_dwconv7_p(const half_t* x, const float* w, const float* bias, half_t* y, int B, int H, int W, int C, int x_cpitch, int x_coff, int y_cpitch,
                      int y_coff, int w_pitch, hipStream_t s);
 int launch_mha32_p(const half_t* q, int q_cpitch, int q_coff, int q_tok, const half_t* kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok, half_t* o,

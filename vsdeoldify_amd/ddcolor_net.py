@@ -54,7 +54,7 @@ class DDColorGenerator:
         self.pack, self._pc, self._vec = WeightPack(), {}, {}
         self._frozen = False
         self.fuse_tail = os.environ.get("HAVC_DD_FUSE_TAIL", "1") != "0" or self.precise      # A/B switch: einsum + refine folded into the last_shuf conv
-        self.fuse_dwln = os.environ.get("HAVC_DD_FUSE_DWLN", "1") != "0" and not self.precise      # A/B switch: dwconv + LayerNorm as one kernel
+        self.fuse_dwln = os.environ.get("HAVC_DD_FUSE_DWLN", "1") != "0"      # A/B switch: dwconv + LayerNorm as one kernel (precise: round 6, the widths whose fp32 weights fit the LDS)
         # encoder.norm{0,1,2} feed nothing but the decoder's BatchNorm + ReLU on the skip connection: LayerNorm -> BN -> ReLU as ONE LayerNorm launch with
         # the BN folded into its gamma / beta, written straight into the concat buffer (round 4: the separate affine pass was 1.2 ms per 64 frames)
         self.fuse_skip_norm = os.environ.get("HAVC_DD_FUSE_SKIPNORM", "1") != "0" and self.fuse_tail
@@ -127,7 +127,7 @@ class DDColorGenerator:
                 p = f"{e}.stages.{i}.{j}"
                 wdw, bdw = self._vecs(p + ".dwconv", lambda p=p, x=x: (
                     self._dw_pack(sd[p + ".dwconv.weight"], x.span, np.float32 if self.precise else np.float16), sd[p + ".dwconv.bias"].astype(np.float32)))
-                if self.fuse_dwln and c in (64, 192, 384, 768, 1536):          # channel counts the fused kernel is instantiated for
+                if self.fuse_dwln and c in ((192, 384, 768) if self.precise else (64, 192, 384, 768, 1536)):      # channel counts the fused kernel is instantiated for
                     g, be = self._vecs(p + ".norm", lambda p=p: (sd[p + ".norm.weight"].astype(np.float32), sd[p + ".norm.bias"].astype(np.float32)))
                     b.dwconv7_ln(p + ".dwconv+norm", x, nbuf, wdw, bdw, x.span, g, be, 1e-6)
                 else:

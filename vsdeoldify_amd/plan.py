@@ -224,7 +224,7 @@ def pack_conv(pack, W, cmap, Ci, bias=None, scale=None, shift=None, pixshuf=Fals
 # csrc/precise2.hip, csrc/zhang.hip); BILINEAR2 works on fp32 maps in both modes
 PRECISE_OPS = (nat.OP_CONV, nat.OP_MAXPOOL, nat.OP_BLUR_RESIZE, nat.OP_AFFINE, nat.OP_ATTENTION, nat.OP_PREP_RGB8, nat.OP_SUBSAMPLE2, nat.OP_PROJ2,
                nat.OP_BILINEAR2, nat.OP_PREP_LAB_L, nat.OP_DWCONV7, nat.OP_LAYERNORM, nat.OP_MHA, nat.OP_PREP_DDCOLOR, nat.OP_FOLD_QUERIES,
-               nat.OP_SHUF4_BLUR_AB)
+               nat.OP_SHUF4_BLUR_AB, nat.OP_DWCONV7_LN)
 
 
 class PlanBuilder:
