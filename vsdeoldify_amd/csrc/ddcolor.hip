@@ -567,6 +567,8 @@ int launch_fold_queries(const half_t* e, int e_cpitch, int e_coff, int tok, cons
 
 // proj: fp32 [B][Hi*Wi][16][2] (sub-pixel dy*4+dx of the shuffle) -> y[b][Y][X][0..1] = 0.25 * (the 2x2 window ending at (Y, X), replicate-
 // padded on the top / left: ReplicationPad2d((1,0,1,0)) + AvgPool2d(2, 1)) + R_img . img[Y][X] + bias
+// PREC (round 6, the precise plan's HAVC_F_FUSE_PROJ tail): the image is a pair view and the ab map is written as pairs; the arithmetic is the same fp32
+template <bool PREC>
 __global__ void shuf4_blur_ab_kernel(const float* __restrict__ proj, const half_t* __restrict__ img, int img_cpitch, int img_coff,
                                      const float* __restrict__ rimg, const float* __restrict__ bias, half_t* __restrict__ y, int y_cpitch,
                                      int y_coff, int B, int Hi, int Wi) {
@@ -582,10 +584,21 @@ __global__ void shuf4_blur_ab_kernel(const float* __restrict__ proj, const half_
         };
         const float2 v00 = ld(y0, x0), v01 = ld(y0, X), v10 = ld(Y, x0), v11 = ld(Y, X);
         const half_t* ip = img + i * img_cpitch + img_coff;
-        const float i0 = (float)ip[0], i1 = (float)ip[1], i2 = (float)ip[2];
+        float i0 = (float)ip[0], i1 = (float)ip[1], i2 = (float)ip[2];
+        if (PREC) {
+            const int ilo = img_cpitch >> 1;
+            i0 += (float)ip[ilo] * (1.f / 2048.f); i1 += (float)ip[ilo + 1] * (1.f / 2048.f); i2 += (float)ip[ilo + 2] * (1.f / 2048.f);
+        }
         const float a = (v00.x + v01.x + v10.x + v11.x) * 0.25f + (rimg[0] * i0 + rimg[1] * i1 + rimg[2] * i2) + bias[0];
         const float bb = (v00.y + v01.y + v10.y + v11.y) * 0.25f + (rimg[3] * i0 + rimg[4] * i1 + rimg[5] * i2) + bias[1];
         half_t* yp = y + i * y_cpitch + y_coff;
+        if (PREC) {
+            const int ylo = y_cpitch >> 1;
+            half_t hh, ll;
+            split_hl_dd(a, hh, ll); yp[0] = hh; yp[ylo] = ll;
+            split_hl_dd(bb, hh, ll); yp[1] = hh; yp[ylo + 1] = ll;
+            continue;
+        }
         if ((y_coff & 7) == 0) {                            // the ab map is an 8-channel chunk with six zero pads: one 16-byte store (no partial-line writes)
             half8 o;
 #pragma unroll
@@ -600,7 +613,13 @@ __global__ void shuf4_blur_ab_kernel(const float* __restrict__ proj, const half_
 }
 int launch_shuf4_blur_ab(const float* proj, const half_t* img, int img_cpitch, int img_coff, const float* rimg, const float* bias, half_t* y,
                          int y_cpitch, int y_coff, int B, int Hi, int Wi, hipStream_t s) {
-    hipLaunchKernelGGL(shuf4_blur_ab_kernel, dim3(grid_for_dd((int64_t)B * Hi * 4 * Wi * 4)), dim3(256), 0, s, proj, img, img_cpitch, img_coff, rimg,
+    hipLaunchKernelGGL(shuf4_blur_ab_kernel<false>, dim3(grid_for_dd((int64_t)B * Hi * 4 * Wi * 4)), dim3(256), 0, s, proj, img, img_cpitch, img_coff, rimg,
+                       bias, y, y_cpitch, y_coff, B, Hi, Wi);
+    return (int)hipGetLastError();
+}
+int launch_shuf4_blur_ab_p(const float* proj, const half_t* img, int img_cpitch, int img_coff, const float* rimg, const float* bias, half_t* y,
+                           int y_cpitch, int y_coff, int B, int Hi, int Wi, hipStream_t s) {
+    hipLaunchKernelGGL(shuf4_blur_ab_kernel<true>, dim3(grid_for_dd((int64_t)B * Hi * 4 * Wi * 4)), dim3(256), 0, s, proj, img, img_cpitch, img_coff, rimg,
                        bias, y, y_cpitch, y_coff, B, Hi, Wi);
     return (int)hipGetLastError();
 }

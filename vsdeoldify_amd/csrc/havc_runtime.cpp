@@ -426,7 +426,7 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
             if (a.splitk == 1) a.splitk = 0;
             a.pscale = 1.f;
             if (op.flags & HAVC_F_PRECISE) {
-                if ((op.flags & (HAVC_F_FUSE_PROJ | HAVC_F_W_FROM_BUF)) || a.splitk ||
+                if ((op.flags & HAVC_F_W_FROM_BUF) || a.splitk ||
                     !(op.f3 > 0.f) || (op.src_cpitch & 15) || (!(op.flags & HAVC_F_OUT_RGB8) && (op.dst_cpitch & 15)))
                     return fail(c, HAVC_E_INVALID, "conv op: PRECISE needs a plain conv (no fused / transposed / split-K form), f3 = accumulator scale > 0, hi|lo pixel rows");
                 a.pscale = op.f3;
@@ -654,6 +654,16 @@ int run_op(havc_net* n, const havc_op& op, int batch) {
                                     (float*)bufptr(n, op.dst), batch, op.Ci, s);
             break;
         case HAVC_OP_SHUF4_BLUR_AB:
+            if ((op.flags & HAVC_F_PRECISE) && op.Ci == 2) {
+                // precise plan with the projection fused into the last_shuf conv (round 6): src = its fp32 [Hi*Wi][16][2] output, image and ab map as pairs
+                if (op.w_off < 0 || op.bias_off < 0 || op.src2 < 0 || n->bufdesc[op.src].elem_bytes != 4 ||
+                    (uint64_t)n->bufdesc[op.src].elems_per_frame < (uint64_t)op.Hi * op.Wi * 32)
+                    return fail(c, HAVC_E_INVALID, "shuffle+blur(ab) op, precise: weights, image view, fp32 [Hi*Wi][16][2] source");
+                e = launch_shuf4_blur_ab_p((const float*)bufptr(n, op.src), (const half_t*)bufptr(n, op.src2), op.res_cpitch, op.res_coff,
+                                           wptr<float>(n, op.w_off), wptr<float>(n, op.bias_off), (half_t*)bufptr(n, op.dst), op.dst_cpitch, op.dst_coff,
+                                           batch, op.Hi, op.Wi, s);
+                break;
+            }
             if (op.flags & HAVC_F_PRECISE) {
                 // precise form: src = the last_shuf conv's pair tensor [Hi][Wi][16 x 256], aux0 = the folded projection (fp32 [2][256] per frame, FOLD_QUERIES)
                 if (op.w_off < 0 || op.bias_off < 0 || op.src2 < 0 || op.aux0 < 0 || op.aux0 >= (int)n->bufs.size() || n->bufdesc[op.aux0].elem_bytes != 4 ||

@@ -110,6 +110,8 @@ int launch_fold_queries(const half_t* e, int e_cpitch, int e_coff, int tok, cons
                         hipStream_t s);
 int launch_shuf4_blur_ab(const float* proj, const half_t* img, int img_cpitch, int img_coff, const float* rimg, const float* bias, half_t* y,
                          int y_cpitch, int y_coff, int B, int Hi, int Wi, hipStream_t s);
+int launch_shuf4_blur_ab_p(const float* proj, const half_t* img, int img_cpitch, int img_coff, const float* rimg, const float* bias, half_t* y,
+                         int y_cpitch, int y_coff, int B, int Hi, int Wi, hipStream_t s);   // pair image, pair output (precise FUSE_PROJ tail)
 int launch_layernorm_c(const half_t* x, half_t* y, const float* gamma, const float* beta, float eps, int64_t npix, int C, int x_cpitch,
                        int x_coff, int y_cpitch, int y_coff, hipStream_t s, int relu = 0);
 int launch_mha32(const half_t* q, int q_cpitch, int q_coff, int q_tok, const half_t* kv, int kv_cpitch, int k_coff, int v_coff, int kv_tok,

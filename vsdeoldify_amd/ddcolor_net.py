@@ -54,6 +54,9 @@ class DDColorGenerator:
         self.pack, self._pc, self._vec = WeightPack(), {}, {}
         self._frozen = False
         self.fuse_tail = os.environ.get("HAVC_DD_FUSE_TAIL", "1") != "0" or self.precise      # A/B switch: einsum + refine folded into the last_shuf conv
+        # precise: fold the projection into the last_shuf conv's epilogue as the fast plan does (round 6; 0 = round 5's form: the 4096-channel pair tensor is
+        # stored and one fp32 kernel shuffles, blurs and projects it)
+        self.fuse_proj_p = os.environ.get("HAVC_DD_PRECISE_FUSE_PROJ", "1") != "0"
         self.fuse_dwln = os.environ.get("HAVC_DD_FUSE_DWLN", "1") != "0"      # A/B switch: dwconv + LayerNorm as one kernel (precise: round 6, the widths whose fp32 weights fit the LDS)
         # encoder.norm{0,1,2} feed nothing but the decoder's BatchNorm + ReLU on the skip connection: LayerNorm -> BN -> ReLU as ONE LayerNorm launch with
         # the BN folded into its gamma / beta, written straight into the concat buffer (round 4: the separate affine pass was 1.2 ms per 64 frames)
@@ -194,7 +197,7 @@ class DDColorGenerator:
             return pack_conv(self.pack, W[perm], up.cmap, up.span, bias=sh[perm], precise=self.precise)
         pcl = self._conv(p, make_last)
         last_in = up
-        if self.precise:
+        if self.precise and not self.fuse_proj_p:
             t4 = b.tensor(up.H, up.W, pcl.Cout)
             b.conv(p + ".conv", pcl, up, t4, flags=nat.F_RELU_PRE)
         elif not self.fuse_tail:
@@ -302,6 +305,15 @@ class DDColorGenerator:
             rq_off, rimg_off, rb_off = self._vecs("refine_net.0.0/fold", make_refine)
             m2 = b.buf(2 * E, 4)
             b.fold_queries(d + ".fold", emb, QUERIES, rq_off, 104, m2)
+            if self.precise and self.fuse_proj_p:
+                # the fast plan's form in fp32: the projection in the last_shuf conv's precise epilogue (HAVC_F_FUSE_PROJ with HAVC_F_PRECISE), then the
+                # shuffle + blur of the fp32 2-channel map with the image term read from / the ab map written as pairs
+                proj = b.buf(last_in.H * last_in.W * 16 * 2, 4)
+                b.conv(p + ".conv+proj", pcl, last_in, proj, flags=nat.F_RELU_PRE | nat.F_FUSE_PROJ, proj=(m2, proj))
+                b.shuf4_blur_ab("refine_net.0.0", proj, last_in.H, last_in.W, img_view, rimg_off, rb_off, ab,
+                                flops=2 * S * S * (E * QUERIES + 2 * (QUERIES + 3)))
+                ops, bufs = b.finish()
+                return ops, bufs, in_buf, ab.buf, b.names, consts
             if self.precise:
                 # the same fold in fp32: shuffle + blur of the 4096-channel pair tensor, the 2 x 256 projection, the image term and the bias in one kernel
                 b.shuf4_blur_proj("refine_net.0.0", t4, m2, img_view, rimg_off, rb_off, ab, flops=2 * S * S * (E * QUERIES + 2 * (QUERIES + 3)))
