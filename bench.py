@@ -51,7 +51,7 @@ METRIC = "colorized frames/sec/GPU @1080p (DeOldify stable rf=35); CIEDE2000 vs 
 RENDER_FACTOR, WIDTH, HEIGHT = 35, 1920, 1080
 PEAK_F16_TFLOPS = 2500.0            # MI355X dense fp16/bf16 MFMA peak (MI355X_MICROARCH.md: ~2.5 PF dense)
 TAG_TAIL_RES = 1
-PMC_FILES = [os.path.join("profiles", "r5_tail_conv_pmc.json"), os.path.join("profiles", "r4_tail_conv_pmc.json"), os.path.join("profiles", "r3_tail_conv_pmc.json"), os.path.join("profiles", "r2_tail_conv_pmc.json")]   # newest first
+PMC_FILES = [os.path.join("profiles", "r6_tail_conv_pmc.json"), os.path.join("profiles", "r5_tail_conv_pmc.json"), os.path.join("profiles", "r4_tail_conv_pmc.json"), os.path.join("profiles", "r3_tail_conv_pmc.json"), os.path.join("profiles", "r2_tail_conv_pmc.json")]   # newest first
 
 
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X fp32 matrix (xf32-free v_mfma_f32_*_f32) peak: the fair context for an fp32-class figure (MI355X_MICROARCH.md)
@@ -703,8 +703,8 @@ def bench_c4(args, rank, local_rank, world, dist, ddcolor_only=False):
                 "avg_launch_ms": round(avg_ms.value, 4), "flops_per_launch": flops_frame * fpl}
     # HBM bytes per launch of that kernel from separate --pmc FETCH_SIZE / WRITE_SIZE passes of this very command (tools/pmc_cfg.sh, tools/pmc_cfg_to_json.py),
     # corrected as MI355X_MICROARCH.md prescribes; recorded at its own frames-per-launch and scaled linearly to this run's
-    for pf in (os.path.join(ROOT, "profiles", f"r5_{'c3' if ddcolor_only else 'c4'}_pmc.json"),):
-        if os.path.isfile(pf):
+    for pf in (os.path.join(ROOT, "profiles", f"r6_{'c3' if ddcolor_only else 'c4'}_pmc.json"), os.path.join(ROOT, "profiles", f"r5_{'c3' if ddcolor_only else 'c4'}_pmc.json")):
+        if os.path.isfile(pf) and roofline["traffic"] is None:
             try:
                 rec = json.load(open(pf))
                 if abs(float(rec.get("frames_per_launch", 0)) - fpl) < 0.5:       # a record taken at another frames-per-launch is not this run's traffic
