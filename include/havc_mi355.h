@@ -236,7 +236,9 @@ int havc_create(havc_ctx** out, int device_id);
 int havc_ctx_set_stream_priority(havc_ctx* ctx, int level);
 /* the ctx's two streams are re-created with a CU mask of n_cus compute units (hipExtStreamCreateWithCUMask; the first n bits = n / 8 CUs of every XCD):
  * the batched look-ahead pass of ColorMNet then cannot occupy the whole chip, and the memory step's small dependent launches (another context, all CUs)
- * always find free CUs.  Same calling rules as havc_ctx_set_stream_priority. */
+ * always find free CUs.  Same calling rules as havc_ctx_set_stream_priority: both calls fail with HAVC_E_INVALID once havc_get_stream has handed a handle of the ctx
+ * out (round 6: enforced, a wrapped handle would dangle).  hipExtStreamCreateWithCUMask takes no flags: masked streams are ordinary (blocking) streams with respect to
+ * the NULL stream, which this library never uses.  Both are A/B switches of the ColorMNet look-ahead (measured slower, off by default: DESIGN.md section 9). */
 int havc_ctx_set_stream_cus(havc_ctx* ctx, int n_cus);
 void havc_destroy(havc_ctx* ctx);
 const char* havc_last_error(const havc_ctx* ctx);      /* ctx may be NULL: last creation error            */

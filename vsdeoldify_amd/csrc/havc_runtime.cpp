@@ -102,6 +102,7 @@ struct havc_ctx {
     hipStream_t stream2 = nullptr;        // the second generator of a stable/artistic render runs here, concurrently
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_main_done = nullptr, ev_side = nullptr, ev_mark = nullptr;
     bool marked = false;                  // havc_cmn_side_mark recorded ev_mark: the next side section starts behind THAT point of the main stream
+    bool stream_exported = false;         // havc_get_stream handed a stream handle out: the streams may not be re-created any more (havc_ctx_set_stream_*)
     bool side = false;                    // between havc_cmn_side_begin / _end: the ColorMNet read (short-term attention, memory read, join) is enqueued on stream2
     size_t acc_clean_sz = 0;              // scratch 17 (usage accumulators of the banked read) holds zeros over this many bytes (0: unknown -> cleared before use)
     struct { float* use = nullptr; float* life = nullptr; int from = 0, N = 0, HW = 0, top_k = 0; } side_usage;   // its usage update, owed until havc_cmn_side_wait
@@ -1326,7 +1327,12 @@ int havc_net_enqueue_ops(havc_net* n, int first_op, int n_ops, int batch) {
     return run_ops_locked(n, first_op, n_ops, batch);
 }
 
-void* havc_get_stream(havc_ctx* c) { return c ? (void*)c->stream : nullptr; }
+void* havc_get_stream(havc_ctx* c) {
+    if (!c) return nullptr;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->stream_exported = true;            // (a wrapped torch ExternalStream would dangle if the stream were re-created: ADVICE r5)
+    return (void*)c->stream;
+}
 
 int havc_net_run_ops(havc_net* n, int first_op, int n_ops, int batch) {
     if (!n) return HAVC_E_INVALID;
@@ -2493,6 +2499,7 @@ int havc_ctx_set_stream_cus(havc_ctx* c, int n_cus) {
     if (!c || n_cus < 1) return fail(c, HAVC_E_INVALID, "set_stream_cus: n_cus >= 1");
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->side) return fail(c, HAVC_E_INVALID, "set_stream_cus: inside a side section");
+    if (c->stream_exported) return fail(c, HAVC_E_INVALID, "set_stream_cus: a stream handle of this context has been handed out (havc_get_stream): call it before");
     HIP_TRY(c, hipSetDevice(c->dev));
     hipDeviceProp_t prop;
     HIP_TRY(c, hipGetDeviceProperties(&prop, c->dev));
@@ -2604,6 +2611,7 @@ int havc_ctx_set_stream_priority(havc_ctx* c, int level) {
     if (!c) return HAVC_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->side) return fail(c, HAVC_E_INVALID, "set_stream_priority: inside a side section");
+    if (c->stream_exported) return fail(c, HAVC_E_INVALID, "set_stream_priority: a stream handle of this context has been handed out (havc_get_stream): call it before");
     HIP_TRY(c, hipSetDevice(c->dev));
     int least = 0, greatest = 0;
     HIP_TRY(c, hipDeviceGetStreamPriorityRange(&least, &greatest));
