@@ -145,13 +145,14 @@ __global__ void dwconv7_p_kernel(const half_t* __restrict__ x, const float* __re
 }
 
 // ---- multi-head attention, head dim 32, fp32 (nn.MultiheadAttention of the colour decoder): block = (8 queries, head, frame) ----
-// K / V tiles of 64 keys staged in LDS as fp32 (pitch 33: conflict-free for 32 different keys per half wave); thread (query t >> 5, key lane t & 31)
+// K / V tiles of 64 keys staged in LDS as fp32 (pitch 36, see MP_P); thread (query t >> 5, key lane t & 31)
 // walks keys kl, kl + 32 of every tile with a private online softmax; the 32 key lanes of a query merge their states by shuffles at the end.
-constexpr int MP_QG = 8, MP_TK = 64, MP_P = 33;
+constexpr int MP_QG = 8, MP_TK = 64, MP_P = 36;       // row pitch 36 floats (round 6): 16-byte aligned rows -> the K / V rows are read with ds_read_b128 (8 instead of 32 LDS
+                                                        // instructions per row); 32 key lanes x 16 B at a 144-byte pitch touch every bank exactly 4 times: no excess conflicts
 __global__ void __launch_bounds__(256) mha32_p_kernel(const half_t* __restrict__ q, int q_cp, int q_co, int q_tok, const half_t* __restrict__ kv, int kv_cp,
                                                       int k_co, int v_co, int kv_tok, half_t* __restrict__ o, int o_cp, int o_co, int o_tok, int heads, int Lq,
                                                       int Lk, float scale) {
-    __shared__ float Ks[MP_TK * MP_P], Vs[MP_TK * MP_P];
+    __shared__ __attribute__((aligned(16))) float Ks[MP_TK * MP_P], Vs[MP_TK * MP_P];
     const int t = threadIdx.x, qi = t >> 5, kl = t & 31;
     const int h = blockIdx.y, b = blockIdx.z;
     const int iq = blockIdx.x * MP_QG + qi;
@@ -184,7 +185,10 @@ __global__ void __launch_bounds__(256) mha32_p_kernel(const half_t* __restrict__
                 load8(kp + v_co + lc * 8, kv_cp >> 1, vx);
             }
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { Ks[lr * MP_P + lc * 8 + e] = kx[e]; Vs[lr * MP_P + lc * 8 + e] = vx[e]; }
+            for (int e = 0; e < 8; e += 4) {
+                *reinterpret_cast<float4*>(&Ks[lr * MP_P + lc * 8 + e]) = make_float4(kx[e], kx[e + 1], kx[e + 2], kx[e + 3]);
+                *reinterpret_cast<float4*>(&Vs[lr * MP_P + lc * 8 + e]) = make_float4(vx[e], vx[e + 1], vx[e + 2], vx[e + 3]);
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -193,12 +197,19 @@ __global__ void __launch_bounds__(256) mha32_p_kernel(const half_t* __restrict__
             if (k0 + kk >= Lk) continue;
             float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 32; ++e) s += qv[e] * Ks[kk * MP_P + e];
+            for (int e = 0; e < 32; e += 4) {                  // (same order of the 32 additions as before)
+                const float4 k4 = *reinterpret_cast<const float4*>(&Ks[kk * MP_P + e]);
+                s += qv[e] * k4.x; s += qv[e + 1] * k4.y; s += qv[e + 2] * k4.z; s += qv[e + 3] * k4.w;
+            }
             const float mn = fmaxf(m, s);
             const float corr = (m == -INFINITY) ? 0.f : expf(m - mn), pj = expf(s - mn);
             l = l * corr + pj;
 #pragma unroll
-            for (int e = 0; e < 32; ++e) acc[e] = acc[e] * corr + pj * Vs[kk * MP_P + e];
+            for (int e = 0; e < 32; e += 4) {
+                const float4 v4 = *reinterpret_cast<const float4*>(&Vs[kk * MP_P + e]);
+                acc[e] = acc[e] * corr + pj * v4.x; acc[e + 1] = acc[e + 1] * corr + pj * v4.y;
+                acc[e + 2] = acc[e + 2] * corr + pj * v4.z; acc[e + 3] = acc[e + 3] * corr + pj * v4.w;
+            }
             m = mn;
         }
     }
