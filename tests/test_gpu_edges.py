@@ -107,3 +107,15 @@ def test_oom_returns_gray_input_like_the_reference(ctx, monkeypatch):
         assert got.size == im.size and np.array_equal(np.asarray(got), want)
     with pytest.raises(FileNotFoundError):
         render.ModelImageRender("/nonexistent", "video", render_factor=4)
+
+
+def test_stream_recreation_is_refused_once_a_handle_is_out():
+    """havc_ctx_set_stream_priority / _cus destroy and re-create the context's streams (A/B switches of the ColorMNet look-ahead): legal on a fresh
+    context, refused with HAVC_E_INVALID once havc_get_stream has handed a handle out -- a torch ExternalStream wrapped around it would dangle."""
+    from vsdeoldify_amd.render import get_context
+    c = get_context(0, ("stream-rule-test", 0))
+    assert c.lib.havc_ctx_set_stream_priority(c.h, 0) == nat.HAVC_OK           # nothing exported yet
+    assert c.stream_ptr() != 0
+    assert c.lib.havc_ctx_set_stream_priority(c.h, 0) == nat.HAVC_E_INVALID
+    assert c.lib.havc_ctx_set_stream_cus(c.h, 64) == nat.HAVC_E_INVALID
+    assert b"handed out" in c.lib.havc_last_error(c.h)

@@ -70,6 +70,10 @@ def main():
     runs = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     max_us = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     n_frames = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+    # bisecting switches (round 6): frames per look-ahead window, read-ahead on / off, look-ahead pass on its own stream / on the step's stream
+    L = int(os.environ.get("STRESS_LOOKAHEAD", "8"))
+    RA = os.environ.get("STRESS_READ_AHEAD", "1") != "0"
+    ASYNC = os.environ.get("STRESS_ASYNC_LOOKAHEAD", "1") != "0"
     from vsdeoldify_amd import _native as nat
     from vsdeoldify_amd.colormnet_net import ColorMNetNetwork
     from vsdeoldify_amd.synth import synth_colormnet_state_dict
@@ -80,9 +84,10 @@ def main():
     lib.havc_debug_stream_jitter(0, 1)
     # the baseline: one stream for everything the frame loop does (no read-ahead; the look-ahead pass on the step's own stream), no jitter
     net.async_lookahead = False
-    base = run_clip(net, frames, ref, 8, False)
-    net.async_lookahead = True
-    plain = run_clip(net, frames, ref, 8, True)                      # the product schedule, un-jittered
+    base = run_clip(net, frames, ref, L, False)
+    net.async_lookahead = ASYNC
+    plain = run_clip(net, frames, ref, L, RA)                        # the product schedule, un-jittered
+    print(f"variant: look-ahead window {L}, read-ahead {RA}, look-ahead pass on its own stream {ASYNC}", flush=True)
     print(f"baseline: {n_frames} frames, memory sizes {base[1]}; product schedule un-jittered: {'identical' if plain[0] == base[0] else 'DIFFERENT'}, "
           f"{plain[4]} reads ran ahead", flush=True)
     bad = 0 if plain[0] == base[0] else 1
@@ -91,7 +96,7 @@ def main():
     t0 = time.time()
     for i in range(runs):
         lib.havc_debug_stream_jitter(1000 + i, max_us)
-        got = run_clip(net, frames, ref, 8, True)
+        got = run_clip(net, frames, ref, L, RA)
         lib.havc_debug_stream_jitter(0, 1)
         if got[0] != base[0] or got[1] != base[1]:
             bad += 1
@@ -100,8 +105,8 @@ def main():
             for tag, la, ra in (("same seed, READ_AHEAD off", True, False), ("same seed, look-ahead synchronous", False, True)):
                 lib.havc_debug_stream_jitter(1000 + i, max_us)
                 net.async_lookahead = la
-                again = run_clip(net, frames, ref, 8, ra)
-                net.async_lookahead = True
+                again = run_clip(net, frames, ref, L, ra)
+                net.async_lookahead = ASYNC
                 lib.havc_debug_stream_jitter(0, 1)
                 print(f"  {tag}: {'identical to the baseline' if again[0] == base[0] else 'MISMATCH'}", flush=True)
         if (i + 1) % 20 == 0:

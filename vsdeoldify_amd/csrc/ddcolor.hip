@@ -491,6 +491,7 @@ void preload_ddcolor() {
     dwln_optin<192, true, 512, true>(); dwln_optin<192, true, 768, false>();
     dwln_optin<384, false, 768, false>(); dwln_optin<384, false, 512, true>();
     dwln_optin<48, true, 512, false, true>(); dwln_optin<96, true, 512, false, true>(); dwln_optin<192, true, 512, false, true>();      // precise
+    dwln_optin<48, true, 512, false>(); dwln_optin<96, true, 512, false>(); dwln_optin<192, true, 512, false>();                        // HAVC_DWLN_VARIANT=3
     (void)hipGetLastError();
 }
 
@@ -515,9 +516,10 @@ int launch_dwconv7_ln(const half_t* x, const half_t* w, const float* bias, const
 #define DWLN_ARGS x, w, bias, gamma, beta, eps, y, B, H, W, (unsigned)xb, x_cpitch, x_coff, y_cpitch, y_coff, w_pitch, s
     switch (C) {
         case 64: return launch_dwln<16, true, 768, false>(DWLN_ARGS);
-        case 192: return variant == 1 ? launch_dwln<48, true, 512, true>(DWLN_ARGS) : launch_dwln<48, true, 768, false>(DWLN_ARGS);
-        case 384: return variant == 1 ? launch_dwln<96, true, 512, true>(DWLN_ARGS) : launch_dwln<96, true, 768, false>(DWLN_ARGS);
-        case 768: return variant == 1 ? launch_dwln<192, true, 512, true>(DWLN_ARGS) : launch_dwln<192, true, 768, false>(DWLN_ARGS);
+        // variant 3 (round 6 A/B): 512 threads, one output row per step -- the geometry of the precise form (no spills, 2 waves per SIMD)
+        case 192: return variant == 3 ? launch_dwln<48, true, 512, false>(DWLN_ARGS) : variant == 1 ? launch_dwln<48, true, 512, true>(DWLN_ARGS) : launch_dwln<48, true, 768, false>(DWLN_ARGS);
+        case 384: return variant == 3 ? launch_dwln<96, true, 512, false>(DWLN_ARGS) : variant == 1 ? launch_dwln<96, true, 512, true>(DWLN_ARGS) : launch_dwln<96, true, 768, false>(DWLN_ARGS);
+        case 768: return variant == 3 ? launch_dwln<192, true, 512, false>(DWLN_ARGS) : variant == 1 ? launch_dwln<192, true, 512, true>(DWLN_ARGS) : launch_dwln<192, true, 768, false>(DWLN_ARGS);
         case 1536: return variant == 2 ? launch_dwln<384, false, 768, false>(DWLN_ARGS) : launch_dwln<384, false, 512, true>(DWLN_ARGS);
     }
 #undef DWLN_ARGS
