@@ -43,13 +43,68 @@ def run_clip(net, frames, ref, lookahead, read_ahead, fast=True):
             rnd.set_config(k, v)
         dev = [DeviceImage.from_numpy(net.ctx, f) for f in frames]
         refs = [DeviceImage.from_numpy(net.ctx, ref) if t == 0 else None for t in range(len(frames))]
+        trace = _install_trace(rnd, len(frames)) if TRACE else None
         outs = [o.numpy() for o in rnd.colorize_batch_frames(dev, refs, False)]
         mem = rnd.processor.memory
         use = [s.get_usage().float().cpu().numpy().ravel() if (s is not None and s.engaged() and s.count_usage) else None for s in (mem.work_mem, mem.long_mem)]
-        return [hashlib.sha1(o.tobytes()).hexdigest() for o in outs], (mem.work_mem.size, mem.long_mem.size), use, outs, getattr(rnd.processor, "reads_ahead", 0)
+        res = [hashlib.sha1(o.tobytes()).hexdigest() for o in outs], (mem.work_mem.size, mem.long_mem.size), use, outs, getattr(rnd.processor, "reads_ahead", 0)
+        if trace is not None:
+            LAST_TRACE[0] = trace.cpu().numpy()
+        return res
     finally:
         cf.READ_AHEAD = keep
         net.fast = True
+
+
+# STRESS_TRACE=1 (round 6, after the one mismatch of the closing session): behind every frame's step a few reductions are enqueued ON THE STEP'S STREAM (no host
+# synchronisation, so the schedule under test is not serialised): double-precision sums of the decoder's output, of the usage / life counters and of the key / value
+# banks.  Compared with the baseline's trace, a mismatching clip then says WHICH quantity left the one-stream schedule first, and at which frame.
+TRACE = os.environ.get("STRESS_TRACE", "0") != "0"
+TRACE_NAMES = ("prob", "use", "life", "K bank", "V bank", "work n", "long n")
+LAST_TRACE = [None]
+
+
+def _install_trace(rnd, n_frames):
+    import torch
+    proc = rnd.processor
+    log = torch.zeros((n_frames, len(TRACE_NAMES)), dtype=torch.float64, device=rnd.network.device)
+    state = {"t": 0}
+
+    def wrap(fn):
+        def stepped(*a, **kw):
+            out = fn(*a, **kw)
+            t = state["t"]
+            state["t"] = t + 1
+            if t < n_frames and out is not None:
+                mem = proc.memory
+                b = getattr(mem, "_banks", None)
+                log[t, 0] = out.double().sum()
+                if b is not None and hasattr(b, "use"):
+                    nw, nl = int(mem.work_mem.n), int(mem.long_mem.n if mem.long_mem is not None else 0)
+                    lo, hi = b.cap_long - nl, b.cap_long + nw                 # the live columns [long | work] (the banks are torch.empty beyond them)
+                    log[t, 1] = b.use[..., lo:hi].double().sum(); log[t, 2] = b.life[..., lo:hi].double().sum()
+                    log[t, 3] = b.K[..., lo:hi].double().sum(); log[t, 4] = b.V[..., lo:hi].double().sum()
+                    log[t, 5] = float(nw); log[t, 6] = float(nl)
+            return out
+        return stepped
+    for name in ("step_padded", "step_AnyExemplar_padded"):
+        if hasattr(proc, name):
+            setattr(proc, name, wrap(getattr(proc, name)))
+    return log
+
+
+def describe_trace(got, base):
+    if got is None or base is None:
+        return
+    d = got != base
+    if not d.any():
+        print("    trace: identical (the difference is not in a traced quantity)")
+        return
+    for k, name in enumerate(TRACE_NAMES):
+        rows = np.nonzero(d[:, k])[0]
+        if rows.size:
+            t = int(rows[0])
+            print(f"    trace: {name:7s} first differs at frame {t}: {got[t, k]!r} vs baseline {base[t, k]!r} (relative {abs(got[t, k] - base[t, k]) / max(abs(base[t, k]), 1e-300):.3g})")
 
 
 def describe(tag, got, base):
@@ -85,6 +140,7 @@ def main():
     # the baseline: one stream for everything the frame loop does (no read-ahead; the look-ahead pass on the step's own stream), no jitter
     net.async_lookahead = False
     base = run_clip(net, frames, ref, L, False)
+    base_trace = LAST_TRACE[0]
     net.async_lookahead = ASYNC
     plain = run_clip(net, frames, ref, L, RA)                        # the product schedule, un-jittered
     print(f"variant: look-ahead window {L}, read-ahead {RA}, look-ahead pass on its own stream {ASYNC}", flush=True)
@@ -102,6 +158,7 @@ def main():
             bad += 1
             print(f"run {i} (jitter seed {1000 + i}): MISMATCH", flush=True)
             describe("jittered", got, base)
+            describe_trace(LAST_TRACE[0], base_trace)
             for tag, la, ra in (("same seed, READ_AHEAD off", True, False), ("same seed, look-ahead synchronous", False, True)):
                 lib.havc_debug_stream_jitter(1000 + i, max_us)
                 net.async_lookahead = la
