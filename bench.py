@@ -11,7 +11,7 @@ offline), activations fp16 with fp32 MFMA accumulation.
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
   python bench.py --config c4          # BASELINE configs[3]: DeOldify + DDColor merge (combine_method=2) at 1080p
 
-`value` is the whole-job rate over the EXACTLY K timed steps (sum over all ranks; `value_per_gpu` = value / n_gpus); one step = 64 frames per GPU
+`value` is the fast mode (precision="fast", asked for explicitly; the package default is "precise" = the line's `contract` object).  It is the whole-job rate over the EXACTLY K timed steps (sum over all ranks; `value_per_gpu` = value / n_gpus); one step = 64 frames per GPU
 (--batch).  Beside it the line carries, measured in the same process after the timed region (rank 0, N = 1):
   precise        the same step with ModelImageRender(precision="precise") (fp32-class arithmetic; measured against the oracle: mean ~1e-3, p99 0.000,
                  >= 99.97 % of the pixels below CIEDE2000 1.0, residual maximum 2.5 - 3.6 = single truncation flips of uint8(x * 255), which two fp32
@@ -23,7 +23,8 @@ offline), activations fp16 with fp32 MFMA accumulation.
   pcie_inclusive host frames in -> host frames out through havc_colorize_clip_host (pinned memory, uploads / passes /
                  downloads of consecutive batches overlapped on three streams)
   batch1         ModelImageRender.get_transformed_image on one 560x560 PIL image per call: the rate a VapourSynth
-                 ModifyFrame selector sees (vsslib/vsmodels.py:219-230)
+                 ModifyFrame selector sees (vsslib/vsmodels.py:219-230) -- fast mode; `batch1_default_precise` = the same call on a
+                 render built without any precision switch (the package default)
   cpu_baseline / parity   the CPU oracle on one frame of the same clip, and the GPU frame against it
 
 Wall time of the default run (`python bench.py`, one MI355X box, round 5): about 4 minutes -- the five child legs (c3, c3 precise, c4, c4 precise, c5) 85 s, the
@@ -605,6 +606,25 @@ def extras(args, cc, ctx, frames, d_src, d_dst, fbytes, n_batches, sds):
     res["batch1_low_latency"] = {"value": round(k / dt, 2), "unit": "frames/s", "ms_per_call": round(dt / k * 1e3, 3),
                                  "how": "the same call on ModelImageRender(..., low_latency=True) / HAVC_LOW_LATENCY=1: nets for one frame per launch with split-K convs "
                                         "(opt-in: 3 LSB from the batched nets on isolated bytes at this size, tests/test_gpu_deoldify.py)"}
+    # ---- the same single caller in the package's DEFAULT mode (precision.py: "precise"): what a drop-in user who sets no switch gets per blocking call ----
+    try:
+        for r_ in (r1._video, r1._second, r2._video, r2._second):       # (the fast one-frame nets are done: their arenas go first)
+            r_.close()
+        r3 = ModelImageRender(None, "stable", RENDER_FACTOR, 0.5, device_index=ctx.device_id, state_dicts=sds, max_batch=1)
+        for _ in range(3):
+            r3.get_transformed_image(img)
+        k3 = 20
+        t0 = time.perf_counter()
+        for _ in range(k3):
+            r3.get_transformed_image(img)
+        dt = time.perf_counter() - t0
+        res["batch1_default_precise"] = {"value": round(k3 / dt, 2), "unit": "frames/s", "ms_per_call": round(dt / k3 * 1e3, 3), "precision": r3._precision,
+                                         "how": "ModelImageRender('stable', rf=35) built WITHOUT a precision switch (the package default), one blocking "
+                                                "get_transformed_image(PIL 560x560) per frame"}
+        for r_ in (r3._video, r3._second):
+            r_.close()
+    except Exception as e:                                          # noqa: BLE001 -- an extra leg never costs the line
+        res["batch1_default_precise"] = {"error": f"{type(e).__name__}: {e}"}
     # ---- the same per-frame call from 16 threads (VapourSynth's worker pool) through ONE coalescing render: havc_batcher ----
     import threading
     T, K = 16, 6
