@@ -22,6 +22,8 @@ SHAPES = {  # name: (Cin, Cout, k, stride, pad, H, W, flags)
     "pw2_s1": (1536, 384, 1, 1, 0, 64, 64, nat.F_AFFINE),
     "pw1_s2": (768, 3072, 1, 1, 0, 32, 32, nat.F_GELU),
     "pw1n_s2": (768, 3072, 1, 1, 0, 32, 32, 0),
+    "pw1_s3": (1536, 6144, 1, 1, 0, 16, 16, nat.F_GELU),
+    "pw2_s3": (6144, 1536, 1, 1, 0, 16, 16, nat.F_AFFINE),
     "pw2_s2": (3072, 768, 1, 1, 0, 32, 32, nat.F_AFFINE),
     "l7conv": (320, 256, 3, 1, 1, 280, 280, nat.F_RELU_PRE | nat.F_AFFINE),
     "l6conv": (768, 512, 3, 1, 1, 140, 140, nat.F_RELU_PRE | nat.F_AFFINE),

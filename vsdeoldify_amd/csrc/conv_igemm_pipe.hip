@@ -303,7 +303,9 @@ static int launch_pipe(const ConvArgs& a, hipStream_t s) {
     static_assert(LDS <= 160 * 1024, "LDS budget");
     if (EF >= 0 && ((a.flags & HAVC_EPI_MASK) != EF || a.oss != 1)) return (int)hipErrorInvalidValue;
     ensure_lds_optin<conv_pipe_kernel<WM, WN, FM, EXTRA, ABL, EF>>(LDS);
-    hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, ABL, EF>), dim3(MT * NT * SK), dim3(G::NW * 64), LDS, s, a);
+    ConvArgs ar = a;
+    if (!(a.flags & HAVC_F_PS_BLUR)) conv_raster(ar, MT, NT, G::BN);
+    hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, ABL, EF>), dim3(MT * NT * SK), dim3(G::NW * 64), LDS, s, ar);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || SK == 1) return (int)e;
     const int64_t work = (int64_t)a.M * (a.Npad >> 2);

@@ -26,7 +26,9 @@ int launch_ef(const ConvArgs& a, hipStream_t s) {
     if (a.splitk > 1) return (int)hipErrorInvalidValue;   // split-K main loops store raw partial sums and never reach an epilogue: the run-time-flag kernel serves them
     constexpr int LDS = G::LDS_BYTES;
     ensure_lds_optin<conv_pipe_kernel<WM, WN, FM, EXTRA, 0, EF>>(LDS);
-    hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, 0, EF>), dim3(MT * NT), dim3(G::NW * 64), LDS, s, a);
+    ConvArgs ar = a;
+    if (!(EF & HAVC_F_PS_BLUR)) conv_raster(ar, MT, NT, G::BN);
+    hipLaunchKernelGGL((conv_pipe_kernel<WM, WN, FM, EXTRA, 0, EF>), dim3(MT * NT), dim3(G::NW * 64), LDS, s, ar);
     return (int)hipGetLastError();
 }
 

@@ -43,7 +43,20 @@ struct ConvArgs {
     int splitk;            // > 1: the K range is cut into `splitk` parts, one block per (tile, part) stores its fp32 partial sums to `ws`
     float* ws;             //      [splitk][M][Npad]; splitk_reduce_kernel adds them in a fixed order and runs the usual epilogue
     float pscale;          // HAVC_F_PRECISE: the accumulator is this factor away from the convolution (2^-11 x the weight pre-scale, op.f3)
+    int ngroup, rband;     // round 6, set by the pipelined launchers (conv_raster): > 0 = column tiles are walked in groups of `ngroup` inside bands of `rband` row tiles,
+                           //      so that the weight panels one XCD has in flight fit its 4 MiB L2 (a 768 -> 3072 GEMM cycles 4.7 MB of weights per row tile otherwise)
 };
+// grouped tile order for GEMMs whose weight matrix does not fit an XCD's L2 (HAVC_RASTER_GROUP=0 switches it off; same bytes: only the block -> tile map changes)
+inline void conv_raster(ConvArgs& a, int MT, int NT, int BN) {
+    static const int on = [] { const char* e = getenv("HAVC_RASTER_GROUP"); return e ? atoi(e) : 1; }();
+    a.ngroup = a.rband = 0;
+    const double tile_bytes = (double)BN * a.Kc * 16.0;            // one column tile's weight panel
+    if (!on || a.splitk > 1 || NT < 4 || MT < 16 || tile_bytes * NT < 3.5e6) return;
+    int ng = (int)(2.5e6 / tile_bytes);
+    if (ng < 2 || ng >= NT) return;                                  // (a panel of > 1.25 MB per column tile: nothing to group; huge-K layers stream their weights anyway)
+    a.ngroup = ng;
+    a.rband = (MT + 7) / 8;                                          // one band per XCD share of the row tiles
+}
 #define HAVC_KTAB_PAD_DH 0x7fff
 
 // returns hipError_t as int
