@@ -46,9 +46,12 @@ struct ConvArgs {
     int ngroup, rband;     // round 6, set by the pipelined launchers (conv_raster): > 0 = column tiles are walked in groups of `ngroup` inside bands of `rband` row tiles,
                            //      so that the weight panels one XCD has in flight fit its 4 MiB L2 (a 768 -> 3072 GEMM cycles 4.7 MB of weights per row tile otherwise)
 };
-// grouped tile order for GEMMs whose weight matrix does not fit an XCD's L2 (HAVC_RASTER_GROUP=0 switches it off; same bytes: only the block -> tile map changes)
+// grouped tile order for GEMMs whose weight matrix does not fit an XCD's L2.  Same bytes: only the block -> tile map changes.  MEASURED AND LEFT OFF (round 6,
+// profiles/r6_raster_group_ab.txt): on ConvNeXt-L's stage-2 pwconv1 (768 -> 3072, 128 frames) it cuts the kernel's HBM-side traffic from 2.13 to 1.76 GB per launch
+// (fetch 1.33 -> 0.96 GB) but the launch gets 2 % SLOWER (0.728 -> 0.745 ms; c3 1 339 -> 1 338 frames/s): six weight panels plus the pixel tiles of the 32 blocks an XCD
+// has in flight are still more than its 4 MiB, and every pixel tile is now read twice.  HAVC_RASTER_GROUP=1 switches it on (A/B).
 inline void conv_raster(ConvArgs& a, int MT, int NT, int BN) {
-    static const int on = [] { const char* e = getenv("HAVC_RASTER_GROUP"); return e ? atoi(e) : 1; }();
+    static const int on = [] { const char* e = getenv("HAVC_RASTER_GROUP"); return e ? atoi(e) : 0; }();
     a.ngroup = a.rband = 0;
     const double tile_bytes = (double)BN * a.Kc * 16.0;            // one column tile's weight panel
     if (!on || a.splitk > 1 || NT < 4 || MT < 16 || tile_bytes * NT < 3.5e6) return;
