@@ -129,6 +129,7 @@ def main():
     L = int(os.environ.get("STRESS_LOOKAHEAD", "8"))
     RA = os.environ.get("STRESS_READ_AHEAD", "1") != "0"
     ASYNC = os.environ.get("STRESS_ASYNC_LOOKAHEAD", "1") != "0"
+    SEED0 = int(os.environ.get("STRESS_SEED0", "1000"))            # first jitter seed (run i uses SEED0 + i)
     from vsdeoldify_amd import _native as nat
     from vsdeoldify_amd.colormnet_net import ColorMNetNetwork
     from vsdeoldify_amd.synth import synth_colormnet_state_dict
@@ -151,16 +152,16 @@ def main():
         describe("un-jittered product schedule", plain, base)
     t0 = time.time()
     for i in range(runs):
-        lib.havc_debug_stream_jitter(1000 + i, max_us)
+        lib.havc_debug_stream_jitter(SEED0 + i, max_us)
         got = run_clip(net, frames, ref, L, RA)
         lib.havc_debug_stream_jitter(0, 1)
         if got[0] != base[0] or got[1] != base[1]:
             bad += 1
-            print(f"run {i} (jitter seed {1000 + i}): MISMATCH", flush=True)
+            print(f"run {i} (jitter seed {SEED0 + i}): MISMATCH", flush=True)
             describe("jittered", got, base)
             describe_trace(LAST_TRACE[0], base_trace)
             for tag, la, ra in (("same seed, READ_AHEAD off", True, False), ("same seed, look-ahead synchronous", False, True)):
-                lib.havc_debug_stream_jitter(1000 + i, max_us)
+                lib.havc_debug_stream_jitter(SEED0 + i, max_us)
                 net.async_lookahead = la
                 again = run_clip(net, frames, ref, L, ra)
                 net.async_lookahead = ASYNC
