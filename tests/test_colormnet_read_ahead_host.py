@@ -155,3 +155,32 @@ def test_dropping_a_pending_read_on_reset():
     assert net.log == [("havc_cmn_side_wait", 0)] and core._ahead_read is None and net._side_owner is None
     core.drop_read_ahead()
     assert net.log == [("havc_cmn_side_wait", 0)]                                                            # nothing pending: no call
+
+
+def test_a_pending_read_is_dropped_before_a_step_that_has_no_read_or_memorises_first():
+    """round 6: a read enqueued ahead used to be waited for only inside the next _read.  A hinted frame that is stepped WITHOUT a _read (nothing to
+    segment), or an exemplar frame -- whose reference image is memorised before the frame's own read (inference_core.py:160-180) -- went on to add_memory on the
+    main stream while the second stream could still be reading the banks.  Both step functions now drop the pending read first (havc_cmn_side_wait(0))."""
+    import torch
+    net = _Net()
+    net.encode_key = lambda image, need_ek=True, need_sk=True: (_Buf("kN"), None, _Buf("kN.sel"), FEAT, FEAT, FEAT)
+    net.encode_value = lambda *a, **k: (_Buf("rv"), None)
+    core = _core(net)
+    core.curr_ti, core.enable_long_term, core.all_labels = 0, False, [1, 2]
+    core._schedule = lambda has_mask, end: (False, False, True)
+    core.memory.create_hidden_state = lambda n, k: net.log.append(("create_hidden",))
+    core.memory.add_memory = lambda *a, **k: net.log.append(("add_memory",))
+    _step(core, _entry("k0"), hint=_entry("k1"))
+    assert core._ahead_read is not None
+    # (1) the hinted frame arrives with the labels already known: need_segment is False, no _read runs -> the pending section is joined and forgotten first
+    core._labels_differ = lambda valid: False
+    net.log.clear()
+    core.step_padded(torch.zeros(3, 4, 4), (0, 0, 0, 0), mask=None, valid_labels=[1, 2])
+    assert net.log[0] == ("havc_cmn_side_wait", 0) and core._ahead_read is None and net._side_owner is None, net.log
+    # (2) an exemplar frame with a read pending: the drop comes before the reference image's add_memory
+    core._labels_differ = lambda valid: True
+    _step(core, _entry("k2"), hint=_entry("k3"))
+    assert core._ahead_read is not None
+    net.log.clear()
+    core.step_AnyExemplar_padded(torch.zeros(3, 4, 4), (0, 0, 0, 0), ref_image=torch.zeros(3, 4, 4), msk_ab=torch.zeros(2, 4, 4), valid_labels=None)
+    assert net.log.index(("havc_cmn_side_wait", 0)) < net.log.index(("add_memory",)), net.log
