@@ -395,3 +395,30 @@ def test_conv_views_that_do_not_fill_their_frame_run_frame_by_frame(ctx, cfg):
     head = F.conv2d(torch.from_numpy(got[:, :h * w, :Cout].reshape(B, h, w, Cout).transpose(0, 3, 1, 2).copy()), torch.from_numpy(f16(W2))).numpy()
     gy = out[y.buf][..., :32].astype(np.float32).transpose(0, 3, 1, 2)
     assert np.abs(gy - head).max() < 2e-2 * max(1.0, float(np.abs(head).max()))
+
+
+def test_grouped_tile_order_gives_the_same_bytes(ctx):
+    """round 6: HAVC_RASTER_GROUP=1 (kernels.h conv_raster: column tiles walked in L2-sized groups inside bands of row tiles, for GEMMs whose weight matrix
+    exceeds an XCD's L2 -- measured 2 % slower and left off) changes the block -> tile map only.  ConvNeXt-L's stage-2 pwconv1 shape (768 -> 3072 + GELU) with
+    17 row tiles (ragged last band) in a child process with the switch on, against this process (off): identical bytes."""
+    import hashlib
+    import subprocess
+    import sys
+    code = (
+        "import sys, hashlib, numpy as np; sys.path.insert(0, %r)\n"
+        "from tests import gpu_util as gu\n"
+        "from vsdeoldify_amd import _native as nat\n"
+        "from vsdeoldify_amd.render import get_context\n"
+        "r = np.random.default_rng(7)\n"
+        "x = (r.standard_normal((1, 768, 68, 64)) * 0.5).astype(np.float16).astype(np.float32)\n"
+        "W = (r.standard_normal((3072, 768, 1, 1)) / 28).astype(np.float16).astype(np.float32)\n"
+        "b = r.standard_normal(3072).astype(np.float32)\n"
+        "out = gu.conv_op(get_context(0), x, W, bias=b, flags=nat.F_GELU, cfg=60)[1]\n"
+        "print('SHA', hashlib.sha1(out.tobytes()).hexdigest())\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    shas = {}
+    for g in ("1", "0"):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=dict(os.environ, HAVC_RASTER_GROUP=g, HAVC_TUNE_CACHE="0"))
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("SHA ")]
+        assert p.returncode == 0 and lines, (p.stdout[-300:], p.stderr[-600:])
+        shas[g] = lines[-1]
+    assert shas["1"] == shas["0"], shas
