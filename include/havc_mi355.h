@@ -529,6 +529,10 @@ int havc_net_enqueue_slices(havc_net* net, int count, const int32_t* first_op, c
  * streams of a context and of the look-ahead context against each other; seed 0 switches it off.  Process-wide.  Results must not depend on it
  * (tools/cmn_race_stress.py, tests/test_gpu_colormnet_stress.py).  HAVC_STREAM_JITTER=<seed> / HAVC_STREAM_JITTER_US set the same state at load time. */
 int havc_debug_stream_jitter(int seed, int max_us);
+/* SHA-1 (hex) of the sources this library was built from (tools/build_stamp.py: every .hip / .cpp / .h / .inc file of vsdeoldify_amd/csrc, its Makefile, this header), written into csrc/build_stamp.h
+ * by the Makefile.  The shared object is git-ignored and travels prebuilt to the GPU box: tests/test_host_logic.py compares this with the tree, so a stale binary fails a
+ * CPU test wherever the suite runs (round 6; no reference counterpart). */
+const char* havc_build_stamp(void);
 
 /* timing of the dominant kernel for bench.py's roofline object: average duration (ms) and launch count
  * of HAVC_OP_CONV ops with the given tag over the launches since havc_reset_stats (HIP events on the

@@ -348,3 +348,15 @@ def test_default_precision_is_the_contract_meeting_mode(monkeypatch):
     monkeypatch.setenv("HAVC_PRECISION", "half")
     with pytest.raises(ValueError):
         P.resolve()
+
+
+def test_the_built_library_matches_its_sources():
+    """round 6: libhavc_mi355.so is git-ignored and travels prebuilt to the GPU box.  The Makefile writes the SHA-1 of every source it is built from
+    into the library (csrc/build_stamp.h -> havc_build_stamp()); tools/build_stamp.py recomputes it from the tree.  A stale binary fails HERE, on the CPU, wherever the
+    suite runs -- `python -c "import __graft_entry__ as g; g.build()"` rebuilds it."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import build_stamp
+    from vsdeoldify_amd import _native as nat
+    lib = nat.load()
+    assert lib.havc_build_stamp().decode() == build_stamp.stamp(), "vsdeoldify_amd/lib/libhavc_mi355.so was not built from the sources in this tree: rebuild it (make -C vsdeoldify_amd/csrc)"

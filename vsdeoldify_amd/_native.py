@@ -162,6 +162,7 @@ SYMBOLS = [
     ("havc_net_bind_many", _I, [_P, _I, _P, _P]),
     ("havc_net_enqueue_slices", _I, [_P, _I, _P, _P, _P]),
     ("havc_debug_stream_jitter", _I, [_I, _I]),
+    ("havc_build_stamp", C.c_char_p, []),
     ("havc_tag_timing_enable", _I, [_P, _I, _I]),
     ("havc_tag_timing_read", _I, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 ]

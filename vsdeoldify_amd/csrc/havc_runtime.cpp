@@ -2,6 +2,7 @@
 // Implements include/havc_mi355.h.  No torch, no Python: plain HIP runtime + the kernels in this directory.
 #include "../../include/havc_mi355.h"
 #include "kernels.h"
+#include "build_stamp.h"
 
 #include <algorithm>
 #include <atomic>
@@ -2694,6 +2695,8 @@ int havc_net_enqueue_slices(havc_net* n, int count, const int32_t* first_op, con
         if (int rc = run_ops_locked(n, first_op[i], n_ops[i], batch[i])) return rc;
     return HAVC_OK;
 }
+
+const char* havc_build_stamp(void) { return HAVC_BUILD_STAMP; }
 
 int havc_debug_stream_jitter(int seed, int max_us) {
     g_jitter.on = false;
