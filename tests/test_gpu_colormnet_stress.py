@@ -4,7 +4,7 @@ The reference steps a frame on ONE stream (colormnet/inference/inference_core.py
 context's second stream for the read of frame t+1 / the short-term attention, the look-ahead context's stream for the key encoder).  Whatever the
 relative timing of those streams, every frame must carry the bytes of the one-stream schedule: the library's delay kernels
 (havc_debug_stream_jitter) move them against each other and every frame's SHA-1 is compared with the one-stream baseline.  Fail-fast: no retry.
-The long form is on record in profiles/r6_cmn_race_stress.txt: 76 600 jittered clips, ONE mismatch (cause unknown, ~1.3e-5 per clip: DESIGN.md section 9) -- if this
+The long form is on record in profiles/r6_cmn_race_stress.txt: 85 400 jittered clips, ONE mismatch (cause unknown, ~1.2e-5 per clip: DESIGN.md section 9) -- if this
 test ever fails, that event has shown up again: keep the printed description (first differing frame, usage counters)."""
 import os
 import sys
